@@ -1,0 +1,131 @@
+/*
+ * pwnhip.h -- C ABI of libpwnhip.so, the MI355X (gfx950) implementation of
+ * pwnfps's per-pixel portal ray-march path.
+ *
+ * Plain C: opaque context, plain pointers and sizes, int return codes
+ * (0 = ok, negative = PWN_E*).  Nothing here aborts or asserts.
+ * Each entry cites the reference interface it replaces (paths relative to
+ * the reference tree).  INTEGRATION.md shows the host-side change.
+ */
+#ifndef PWNHIP_H
+#define PWNHIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWN_OK            0
+#define PWN_EINVAL       -1  /* bad argument (NULL, size, row range, w%4 with blur) */
+#define PWN_ENODEV       -2  /* no usable HIP device / not gfx950 */
+#define PWN_ENOMEM       -3  /* host or device allocation failed */
+#define PWN_EIO          -4  /* level file could not be read (level.h:110-115) */
+#define PWN_EHIP         -5  /* a HIP runtime call failed; see pwn_last_error() */
+#define PWN_ENOLEVEL     -6  /* render called before a level was uploaded */
+#define PWN_ETOOBIG      -7  /* sphere tables exceed the on-chip (LDS) budget */
+
+typedef struct pwn_ctx pwn_ctx;
+
+/* reference `portal` (defs.h:87-94); double1/double2 are never read */
+typedef struct pwn_portal { int32_t x1, z1, x2, z2, rot12, c1, c2; } pwn_portal;
+
+/* the arguments of obj_set(...,"sphere",...) (script.h:20-32), i.e. the live
+   fields of `part.sph` (defs.h:73-79): radius, reflectivity, centre, colour b,g,r */
+typedef struct pwn_sphere { float r, refl, x, y, z, cb, cg, cr; } pwn_sphere;
+
+/* work counters of the last counted frame + device timings of the last frame */
+typedef struct pwn_stats
+{
+	uint64_t rays;          /* trace_ray invocations            (trace.h:186) */
+	uint64_t steps;         /* iterations of the cell walk      (trace.h:250) */
+	uint64_t portals;       /* portal crossings                 (trace.h:576) */
+	uint64_t sphere_tests;  /* sphere candidates tested         (trace.h:253) */
+	uint64_t exhausted;     /* rays that ran out of maxsteps    (trace.h:677) */
+	float trace_ms;         /* trace kernel, HIP events                        */
+	float blur_ms;          /* blur kernel(s), HIP events                      */
+	float total_ms;         /* whole pwn_trace_screen_centred call incl. D2H   */
+} pwn_stats;
+
+/* options for pwn_set_option */
+#define PWN_OPT_BLUR_PASSES 1  /* POSTPROC_BLUR (defs.h:9); default 1, 0 = off */
+#define PWN_OPT_COUNTERS    2  /* 1: frames also fill pwn_stats counters (slower) */
+
+/*
+ * Replaces the buffer/global set-up of main.c:26-34,395-400 (rwidth, rheight,
+ * sbuf, tsbuf, zbuf).  `device` is the HIP ordinal.  Device depth is
+ * zero-initialised; like the reference's zbuf it keeps its previous value at
+ * pixels whose primary ray exhausts maxsteps (trace.h:677).
+ */
+int pwn_init(pwn_ctx **out, int device, int width, int height);
+void pwn_destroy(pwn_ctx *ctx);
+int pwn_set_option(pwn_ctx *ctx, int option, int value);
+const char *pwn_strerror(int code);
+const char *pwn_last_error(pwn_ctx *ctx);
+
+/* level_load (level.h:107-228): parse the ASCII grid (CR/LF rules, '*' spawn,
+   lower-case portal quirk), build pmap, upload.  */
+int pwn_level_load(pwn_ctx *ctx, const char *path);
+int pwn_level_load_mem(pwn_ctx *ctx, const char *text, int len);
+/* the same tables handed over ready-made: lv->data / lv->pmap (defs.h:103-105) */
+int pwn_upload_level(pwn_ctx *ctx, const uint8_t data[4096], const pwn_portal pmap[26]);
+int pwn_get_level(pwn_ctx *ctx, uint8_t data[4096], pwn_portal pmap[26], int32_t spawn[2]);
+
+/* level_prepare_render (level.h:64-81) + level_part_add_bbox (level.h:1-19):
+   bins the live spheres per cell in object order and uploads the lists */
+int pwn_upload_spheres(pwn_ctx *ctx, const pwn_sphere *spheres, int n);
+int pwn_get_bins(pwn_ctx *ctx, uint16_t counts[4096], int32_t *idx, int cap);
+
+/*
+ * trace_screen_centred(lv, 0, 0, rwidth, rheight, &cam) (screen.h:31-124,
+ * called at main.c:107) with sec_current (defs.h:23) passed explicitly.
+ * cam = mat4 rows x,y,z,w (defs.h:46-52).  Blocking.  Fills the caller's
+ * host sbuf (BGRA8, pitch = width) and, if not NULL, zbuf -- the layouts of
+ * main.c:31,33.
+ */
+int pwn_trace_screen_centred(pwn_ctx *ctx, const float cam[16], float sec_current,
+	uint32_t *sbuf, float *zbuf);
+
+/*
+ * Strip forms for row tiling across GPUs (one process per GPU; the exchange
+ * between them is the caller's RCCL all-gather).
+ * Pointers are DEVICE pointers to FULL frames (pitch = width); only rows
+ * [y0,y1) are written.  Stream-ordered on `stream` (a hipStream_t, NULL =
+ * default stream); they do not synchronise.
+ *   trace:  the OpenMP loop of screen.h:61-67 restricted to rows [y0,y1)
+ *   blur:   one pass of screen.h:77-121 restricted to rows [y0,y1); reads
+ *           the whole pre-blur frame (the role of tsbuf) and depth rows [y0,y1)
+ */
+int pwn_trace_rows_device(pwn_ctx *ctx, const float cam[16], float sec_current,
+	int y0, int y1, void *d_sbuf, void *d_zbuf, void *stream);
+int pwn_blur_rows_device(pwn_ctx *ctx, int y0, int y1, const void *d_pre,
+	const void *d_zbuf, void *d_out, void *stream);
+
+/* screen_upscale (screen.h:126-149): replicate every pixel scale x scale into
+   a surface of `pitch_bytes` per row (SDL_Surface->pitch / ->pixels).
+   Host form (uploads sbuf... uses the last frame on the device if src is NULL)
+   and device form. */
+int pwn_screen_upscale(pwn_ctx *ctx, const uint32_t *sbuf, int scale, int pitch_bytes,
+	uint32_t *pixels);
+int pwn_upscale_device(pwn_ctx *ctx, const void *d_src, int scale, int pitch_bytes,
+	void *d_dst, void *stream);
+
+int pwn_get_stats(pwn_ctx *ctx, pwn_stats *out);
+
+/* device-side probes of the arithmetic primitives (rcp/rsqrt tables, sinf,
+   cosf, expf, sqrt, divide, colour pack, LCG); used by the parity tests.
+   op: see PWN_PROBE_*; in/out are HOST arrays of n 32-bit words. */
+#define PWN_PROBE_RCP    0
+#define PWN_PROBE_RSQRT  1
+#define PWN_PROBE_SINF   2
+#define PWN_PROBE_COSF   3
+#define PWN_PROBE_EXPF   4
+#define PWN_PROBE_SQRT   5
+#define PWN_PROBE_DIV    6  /* in = pairs (a,b), out = a/b */
+#define PWN_PROBE_FTOINT 7  /* in = 4 floats per output word (util.h:48-59) */
+#define PWN_PROBE_RANDFS 8  /* in = seed, out = randfs bits (util.h:13-16) */
+int pwn_probe(pwn_ctx *ctx, int op, const uint32_t *in, uint32_t *out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

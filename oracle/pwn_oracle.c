@@ -362,6 +362,9 @@ static void walk(frame_ctx *fc, v4 from, v4 iray, hit *h)
 	else if(wx < wz) { t_ = wx; ldir = ((gxa) < 0 ? FXN : FXP); } \
 	else { t_ = wz; ldir = (gz < 0 ? FZN : FZP); } \
 	cdist += t_; pos = v4_add(v4_scale(t_, ray), pos); } while(0)
+/* assoc (fog): the reference build evaluates  fog += cdist - fogbeg  as
+   (fog - fogbeg) + cdist  and  fog += aux_dist - fogbeg  as
+   (fog + aux_dist) - fogbeg  (both the inlined and the stand-alone copy) */
 /* trace.h:331-340 */
 #define ADVANCE_XZ() do { \
 	if(ldir == FXN || ldir == FXP) { wy -= wx; wz -= wx; wx = iax; cx += gx; } \
@@ -419,10 +422,10 @@ static void walk(frame_ctx *fc, v4 from, v4 iray, hit *h)
 				THROUGH(gx);
 				if(AUX_HIT())
 				{
-					if(this_cell == '$' && aux_dist > fogbeg) fog += aux_dist - fogbeg;
+					if(this_cell == '$' && aux_dist > fogbeg) fog = (fog + aux_dist) - fogbeg;
 					RET_SPHERE();
 				}
-				if(this_cell == '$') fog += cdist - fogbeg;
+				if(this_cell == '$') fog = (fog - fogbeg) + cdist;
 				if(ldir == FYN || ldir == FYP)
 					RET_WALL(gy > 0 ? COL_CEIL : COL_FLOOR);
 				ADVANCE_XZ();
@@ -442,10 +445,10 @@ static void walk(frame_ctx *fc, v4 from, v4 iray, hit *h)
 				THROUGH(gx);
 				if(AUX_HIT())
 				{
-					if(this_cell == '&' && aux_dist > fogbeg) fog += aux_dist - fogbeg;
+					if(this_cell == '&' && aux_dist > fogbeg) fog = (fog + aux_dist) - fogbeg;
 					RET_SPHERE();
 				}
-				if(this_cell == '&') fog += cdist - fogbeg;
+				if(this_cell == '&') fog = (fog - fogbeg) + cdist;
 				if(ldir == FYN || ldir == FYP)
 					RET_WALL(gy > 0 ? COL_CEIL : COL_FLOOR);
 				ADVANCE_XZ();
@@ -894,18 +897,22 @@ int pwno_render(const pwno_level *lv, int w, int h, const float cam[16], float s
 	return r;
 }
 
-/* screen.h:126-149 */
+/* screen.h:126-149.  The destination pointer advances by w*scale per source
+   row plus pitch*(scale-1) (screen.h:132,138-139), i.e. source row py starts
+   at py*(w*scale + pitch*(scale-1)) words: equal to py*scale*pitch only when
+   pitch == w*scale, which is what SDL hands the reference.  Reproduced as is. */
 int pwno_upscale(const uint32_t *src, int w, int h, int scale, int pitch_bytes, uint32_t *dst)
 {
 	if(scale <= 0 || pitch_bytes < w*scale*4) return -1;
-	int pitch = pitch_bytes / 4;
+	size_t pitch = (size_t)pitch_bytes / 4;
+	size_t rowadv = (size_t)w*scale + pitch*(size_t)(scale - 1);
 	for(int py = 0; py < h; py++)
 	for(int px = 0; px < w; px++)
 	{
 		uint32_t v = src[(size_t)py*w + px];
 		for(int y = 0; y < scale; y++)
 		for(int x = 0; x < scale; x++)
-			dst[(size_t)(py*scale + y)*pitch + px*scale + x] = v;
+			dst[(size_t)py*rowadv + (size_t)y*pitch + (size_t)px*scale + x] = v;
 	}
 	return 0;
 }

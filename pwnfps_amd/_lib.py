@@ -1,0 +1,69 @@
+"""ctypes binding of libpwnhip.so (include/pwnhip.h).
+
+The library is the product: there is no CPU fallback.  If it is missing or
+does not export the ABI, importing this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpwnhip.so")
+
+PWN_OK, PWN_EINVAL, PWN_ENODEV, PWN_ENOMEM, PWN_EIO, PWN_EHIP, PWN_ENOLEVEL, PWN_ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
+PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS = 1, 2
+(PROBE_RCP, PROBE_RSQRT, PROBE_SINF, PROBE_COSF, PROBE_EXPF, PROBE_SQRT, PROBE_DIV,
+ PROBE_FTOINT, PROBE_RANDFS) = range(9)
+
+
+class Portal(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("x1", "z1", "x2", "z2", "rot12", "c1", "c2")]
+
+
+class Sphere(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("r", "refl", "x", "y", "z", "cb", "cg", "cr")]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("portals", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("exhausted", C.c_uint64),
+                ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+# every symbol include/pwnhip.h declares: (name, restype, argtypes)
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+ABI = [
+    ("pwn_init", _i, [C.POINTER(_vp), _i, _i, _i]),
+    ("pwn_destroy", None, [_vp]),
+    ("pwn_set_option", _i, [_vp, _i, _i]),
+    ("pwn_strerror", C.c_char_p, [_i]),
+    ("pwn_last_error", C.c_char_p, [_vp]),
+    ("pwn_level_load", _i, [_vp, C.c_char_p]),
+    ("pwn_level_load_mem", _i, [_vp, C.c_char_p, _i]),
+    ("pwn_upload_level", _i, [_vp, _vp, _vp]),
+    ("pwn_get_level", _i, [_vp, _vp, _vp, _vp]),
+    ("pwn_upload_spheres", _i, [_vp, _vp, _i]),
+    ("pwn_get_bins", _i, [_vp, _vp, _vp, _i]),
+    ("pwn_trace_screen_centred", _i, [_vp, _vp, _f, _vp, _vp]),
+    ("pwn_trace_rows_device", _i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
+    ("pwn_blur_rows_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    ("pwn_screen_upscale", _i, [_vp, _vp, _i, _i, _vp]),
+    ("pwn_upscale_device", _i, [_vp, _vp, _i, _i, _vp, _vp]),
+    ("pwn_get_stats", _i, [_vp, C.POINTER(Stats)]),
+    ("pwn_probe", _i, [_vp, _i, _vp, _vp, _i]),
+]
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pwnfps_amd: %s is missing -- build it with `make -C pwnfps_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in ABI:
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load()

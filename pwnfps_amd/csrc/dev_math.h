@@ -1,0 +1,235 @@
+// dev_math.h -- gfx950 device arithmetic for the ray-march kernels.
+//
+// Everything here exists to reproduce, bit for bit, what the reference's
+// SSE2 + glibc build computes:
+//   rcp / rsqrt  : _mm_rcp_ps (trace.h:231) / _mm_rsqrt_ps (util.h:43) are
+//                  12-bit table functions on the reference host; the two
+//                  2048-entry tables live in LDS (approx_tables.inc).
+//   sinf/cosf/expf: glibc 2.35's float kernels (double-precision polynomials,
+//                  FMA-contracted as in its x86-64 *_fma builds), trace.h:42-46,97.
+//   v4 helpers   : util.h:18-46 (4-lane dot incl. w, summed (x+z)+(y+w)).
+//   LCG          : util.h:1-16.   colour pack: util.h:48-59.
+// The translation unit is compiled with -ffp-contract=off: every fp32
+// multiply/add below is rounded separately, like the reference's non-FMA SSE2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct v4 { float x, y, z, w; };
+
+__device__ __forceinline__ v4 v4_set(float x, float y, float z, float w) { v4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+__device__ __forceinline__ v4 v4_add(v4 a, v4 b) { return v4_set(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ v4 v4_sub(v4 a, v4 b) { return v4_set(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ v4 v4_mul(v4 a, v4 b) { return v4_set(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ v4 v4_scale(float s, v4 a) { return v4_set(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float v4_dot(v4 a, v4 b)
+{
+	return (a.x * b.x + a.z * b.z) + (a.y * b.y + a.w * b.w);
+}
+
+// ---- RCPPS / RSQRTPS emulation; tab points into LDS -----------------------
+// entry: bit 12 = exponent offset, bits 11..0 = mantissa bits 22..11
+__device__ __forceinline__ float tab_rcp(const uint16_t *tab, float x)
+{
+	uint32_t b = __float_as_uint(x);
+	uint32_t sign = b & 0x80000000u, e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
+	uint32_t r;
+	if(e == 0u) r = sign | 0x7f800000u;
+	else if(e == 255u) r = m ? (b | 0x00400000u) : sign;
+	else
+	{
+		uint32_t t = tab[m >> 12];
+		int re = 254 - (int)e - (int)(t >> 12);
+		r = re <= 0 ? sign : (sign | ((uint32_t)re << 23) | ((t & 0xfffu) << 11));
+	}
+	return __uint_as_float(r);
+}
+
+__device__ __forceinline__ float tab_rsqrt(const uint16_t *tab, float x)
+{
+	uint32_t b = __float_as_uint(x);
+	uint32_t sign = b & 0x80000000u, e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
+	uint32_t r;
+	if(e == 255u && m) r = b | 0x00400000u;
+	else if(e == 0u) r = sign | 0x7f800000u;
+	else if(sign) r = 0xffc00000u;
+	else if(e == 255u) r = 0u;
+	else
+	{
+		int E = (int)e - 127, par = E & 1;
+		uint32_t t = tab[(par << 10) | (m >> 13)];
+		int re = 127 - (int)(t >> 12) - ((E - par) >> 1);
+		r = ((uint32_t)re << 23) | ((t & 0xfffu) << 11);
+	}
+	return __uint_as_float(r);
+}
+
+__device__ __forceinline__ v4 v4_normalise(const uint16_t *rsq, v4 a)
+{
+	return v4_scale(tab_rsqrt(rsq, v4_dot(a, a)), a);
+}
+
+// ---- LCG -------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lcg_next(uint32_t &s)
+{
+	s = (s * 25739u + 4u) & 0x7FFFFFFFu;
+	return s;
+}
+__device__ __forceinline__ float lcg_fs(uint32_t &s)
+{
+	// (s % 3759) / 3759.0f compiled as a multiply by the float reciprocal
+	// under the reference's -ffast-math
+	const float inv = 1.0f / 3759.0f;
+	float u = (float)(lcg_next(s) % 3759u) * inv;
+	return u * 2.0f - 1.0f;
+}
+
+// ---- colour pack: cvtps2dq (RNE) + packs_epi32 + packus_epi16 --------------
+__device__ __forceinline__ uint32_t ftoint_lane(float f)
+{
+	float s = f * 255.0f;
+	int i;
+	if(!(s >= -2147483648.0f && s < 2147483648.0f)) i = INT32_MIN; // "integer indefinite"
+	else i = (int)rintf(s);
+	i = max(i, -32768); i = min(i, 32767);
+	i = max(i, 0); i = min(i, 255);
+	return (uint32_t)i;
+}
+__device__ __forceinline__ uint32_t col_pack(v4 c)
+{
+	return ftoint_lane(c.x) | (ftoint_lane(c.y) << 8) | (ftoint_lane(c.z) << 16) | (ftoint_lane(c.w) << 24);
+}
+
+// ---- glibc 2.35 sinf / cosf ------------------------------------------------
+// Published algorithm of sysdeps/ieee754/flt-32/s_sincosf.h (ARM optimized
+// routines).  fma() here is v_fma_f64; the placement of the fused operations
+// follows glibc's x86-64 FMA build, which is what the reference host runs.
+#define PWN_HPI_INV 0x1.45F306DC9C883p+23
+#define PWN_HPI     0x1.921FB54442D18p0
+#define PWN_PI63    0x1.921FB54442D18p-62
+
+__device__ __forceinline__ uint32_t abstop12(float x) { return (__float_as_uint(x) >> 20) & 0x7ffu; }
+
+// sign = +1/-1 flips the cosine polynomial (glibc's second table)
+__device__ __forceinline__ float sincos_poly(double x, double x2, double csign, int n)
+{
+	if((n & 1) == 0)
+	{
+		double x3 = x * x2;
+		double s1 = fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+		double x7 = x3 * x2;
+		double s = fma(x3, -0x1.555545995a603p-3, x);
+		return (float)fma(x7, s1, s);
+	}
+	else
+	{
+		double x4 = x2 * x2;
+		double c2 = fma(x2, csign * 0x1.99343027bf8c3p-16, csign * -0x1.6c087e89a359dp-10);
+		double c1 = fma(x2, csign * -0x1.ffffffd0c621cp-2, csign * 0x1p0);
+		double x6 = x4 * x2;
+		double c = fma(x4, csign * 0x1.55553e1068f19p-5, c1);
+		return (float)fma(x6, c2, c);
+	}
+}
+
+__device__ __forceinline__ uint32_t inv_pio4_word(int i)
+{
+	// 4/pi as overlapping 32-bit windows, 8 bits apart
+	const uint32_t t[24] = {
+		0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+		0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd,
+		0xf534ddc0, 0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43,
+		0x993c4390, 0x3c439041 };
+	return t[i];
+}
+
+// which = 0: sinf, 1: cosf
+__device__ __noinline__ float glibc_sincosf(float y, int which)
+{
+	double x = (double)y;
+	int n;
+	double s;
+	if(abstop12(y) < abstop12(0x1.921FB6p-1f))
+	{
+		if(abstop12(y) < abstop12(0x1p-12f)) return which ? 1.0f : y;
+		return sincos_poly(x, x * x, 1.0, which);
+	}
+	if(abstop12(y) < abstop12(120.0f))
+	{
+		double r = x * PWN_HPI_INV;
+		n = ((int)r + 0x800000) >> 24;
+		x = fma(-(double)n, PWN_HPI, x);
+		s = (n & 3) == 0 || (n & 3) == 3 ? 1.0 : -1.0;
+		return sincos_poly(x * s, x * x, (n & 2) ? -1.0 : 1.0, n ^ which);
+	}
+	if(abstop12(y) < abstop12(__builtin_inff()))
+	{
+		uint32_t xi = __float_as_uint(y);
+		int sign = (int)(xi >> 31);
+		int base = (int)((xi >> 26) & 15u);
+		int shift = (int)((xi >> 23) & 7u);
+		xi = (xi & 0xffffffu) | 0x800000u;
+		xi <<= shift;
+		uint64_t res0 = (uint64_t)(uint32_t)(xi * inv_pio4_word(base));
+		uint64_t res1 = (uint64_t)xi * inv_pio4_word(base + 4);
+		uint64_t res2 = (uint64_t)xi * inv_pio4_word(base + 8);
+		res0 = (res2 >> 32) | (res0 << 32);
+		res0 += res1;
+		uint64_t nn = (res0 + (1ULL << 61)) >> 62;
+		res0 -= nn << 62;
+		x = (double)(int64_t)res0 * PWN_PI63;
+		n = (int)nn;
+		int q = (n + sign) & 3;
+		s = (q == 0 || q == 3) ? 1.0 : -1.0;
+		return sincos_poly(x * s, x * x, ((n + sign) & 2) ? -1.0 : 1.0, n ^ which);
+	}
+	return __builtin_nanf("");
+}
+
+// ---- glibc 2.35 expf (e_expf.c, N = 32) -------------------------------------
+__device__ __forceinline__ uint64_t exp2f_tab(int i)
+{
+	const uint64_t t[32] = {
+		0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51,
+		0x3fef72b83c7d517b, 0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1,
+		0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
+		0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585,
+		0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
+		0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
+		0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069,
+		0x3fef5818dcfba487, 0x3fef7c97337b9b5f, 0x3fefa4afa2a490da, 0x3fefd0765b6e4540 };
+	return t[i];
+}
+
+__device__ __noinline__ float glibc_expf(float x)
+{
+	const double N = 32.0;
+	const double InvLn2N = 0x1.71547652b82fep+0 * N;
+	const double SHIFT = 0x1.8p+52;
+	const double C0 = 0x1.c6af84b912394p-5 / N / N / N;
+	const double C1 = 0x1.ebfce50fac4f3p-3 / N / N;
+	const double C2 = 0x1.62e42ff0c52d6p-1 / N;
+	double xd = (double)x;
+	uint32_t at = (__float_as_uint(x) >> 20) & 0x7ffu;
+	if(at >= ((__float_as_uint(88.0f) >> 20) & 0x7ffu))
+	{
+		if(__float_as_uint(x) == 0xff800000u) return 0.0f;
+		if(at >= 0x7f8u) return x + x;
+		if(x > 0x1.62e42ep6f) return __builtin_inff();
+		if(x < -0x1.9fe368p6f) return 0.0f;
+	}
+	// z = InvLn2N*xd is fused into both of its uses in glibc's FMA build
+	double kd = fma(InvLn2N, xd, SHIFT);
+	uint64_t ki = (uint64_t)__double_as_longlong(kd);
+	kd -= SHIFT;
+	double r = fma(InvLn2N, xd, -kd);
+	uint64_t t = exp2f_tab((int)(ki & 31u));
+	t += ki << (52 - 5);
+	double s = __longlong_as_double((long long)t);
+	double z = fma(C0, r, C1);
+	double r2 = r * r;
+	double yv = fma(C2, r, 1.0);
+	yv = fma(z, r2, yv);
+	yv = yv * s;
+	return (float)yv;
+}

@@ -1,0 +1,139 @@
+// post_kernels.hip -- framebuffer-side kernels: depth-driven blur
+// (screen.h:69-123), SDL-sink upscale (screen.h:126-149), primitive probes.
+#include <hip/hip_runtime.h>
+#include "dev_math.h"
+#include "tables.h"
+
+// ---------------------------------------------------------------- blur -----
+// The reference walks each row left to right, 4 pixels at a time, drawing 32
+// LCG values per group (x then y offset for tap i of pixel j, i-major) from a
+// per-row seed cy*cy+415135.  One thread takes one 4-pixel group; its seed is
+// the row seed advanced by 32*g draws, done with the precomputed affine
+// skip-ahead (A_g, C_g): s -> (A_g*s + C_g) mod 2^31  (the LCG is affine mod
+// 2^31 because of the & 0x7FFFFFFF).  Reads: 16 B of depth, 16 scattered 4-B
+// taps from the pre-blur frame; write: one 16-B store.
+struct pwn_blur_params
+{
+	int w, h, y0, y1;
+	int groups;                    // w / 4 (screen.h:91: cx < dimx-3)
+	const uint32_t *pre;           // full pre-blur frame ("tsbuf")
+	const float *zbuf;             // full frame depth
+	uint32_t *out;                 // full frame
+	const uint2 *skip;             // groups x (A_g, C_g)
+};
+
+__device__ __forceinline__ uint32_t avg_u8x4(uint32_t a, uint32_t b)
+{
+	// _mm_avg_epu8: per byte (p + q + 1) >> 1, without inter-byte carries:
+	// (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7f)
+	return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu);
+}
+
+__global__ void __launch_bounds__(256)
+pwn_blur_kernel(pwn_blur_params P)
+{
+	int g = blockIdx.x * blockDim.x + threadIdx.x;
+	int cy = P.y0 + blockIdx.y;
+	if(g >= P.groups || cy >= P.y1) return;
+
+	uint32_t seed = (uint32_t)cy * (uint32_t)cy + 415135u;
+	uint2 ac = P.skip[g];
+	if(g > 0) seed = (ac.x * seed + ac.y) & 0x7FFFFFFFu;
+
+	const float fstr = 0.002f * (float)P.h;
+	int cx = g * 4;
+	size_t row = (size_t)cy * (size_t)P.w;
+	float4 zv = *(const float4 *)(P.zbuf + row + cx);
+	float z[4] = { zv.x - 1.0f, zv.y - 1.0f, zv.z - 1.0f, zv.w - 1.0f };
+	uint32_t tap[4][4];
+#pragma unroll
+	for(int i = 0; i < 4; i++)
+	{
+#pragma unroll
+		for(int j = 0; j < 4; j++)
+		{
+			// screen.h:101-102: int + float, truncated toward zero on assignment
+			float fx = (float)(cx + j) + (lcg_fs(seed) * fstr) * z[j];
+			float fy = (float)cy + (lcg_fs(seed) * fstr) * z[j];
+			// cvttss2si yields INT_MIN for NaN / out-of-range; then the clamps
+			// of screen.h:103-106 send it to 0
+			int x = (fx >= -2147483648.0f && fx < 2147483648.0f) ? (int)fx : INT32_MIN;
+			int y = (fy >= -2147483648.0f && fy < 2147483648.0f) ? (int)fy : INT32_MIN;
+			x = max(x, 0); y = max(y, 0);
+			x = min(x, P.w - 1); y = min(y, P.h - 1);
+			tap[i][j] = P.pre[(size_t)y * (size_t)P.w + (size_t)x];
+		}
+	}
+	uint4 o;
+	o.x = avg_u8x4(avg_u8x4(tap[0][0], tap[1][0]), avg_u8x4(tap[2][0], tap[3][0]));
+	o.y = avg_u8x4(avg_u8x4(tap[0][1], tap[1][1]), avg_u8x4(tap[2][1], tap[3][1]));
+	o.z = avg_u8x4(avg_u8x4(tap[0][2], tap[1][2]), avg_u8x4(tap[2][2], tap[3][2]));
+	o.w = avg_u8x4(avg_u8x4(tap[0][3], tap[1][3]), avg_u8x4(tap[2][3], tap[3][3]));
+	*(uint4 *)(P.out + row + cx) = o;
+}
+
+extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream)
+{
+	if(P->groups <= 0 || P->y1 <= P->y0) return hipSuccess;
+	dim3 grid((P->groups + 255) / 256, P->y1 - P->y0);
+	hipLaunchKernelGGL(pwn_blur_kernel, grid, dim3(256), 0, stream, *P);
+	return hipGetLastError();
+}
+
+// -------------------------------------------------------------- upscale ----
+// screen.h:126-149: every source pixel becomes a scale x scale block.  The
+// reference's destination pointer advances w*scale per source row plus
+// pitch*(scale-1) (screen.h:132,138-139), so source row py starts at word
+// py*(w*scale + pitch*(scale-1)); that equals py*scale*pitch when
+// pitch == w*scale (what SDL gives it) and packs rows tighter otherwise.
+// Kept as is.  One thread per destination pixel, stores coalesced along x.
+__global__ void __launch_bounds__(256)
+pwn_upscale_kernel(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch)
+{
+	int dx = blockIdx.x * blockDim.x + threadIdx.x;
+	int dy = blockIdx.y;
+	if(dx >= w * scale || dy >= h * scale) return;
+	int py = dy / scale, y = dy - py * scale;
+	size_t rowadv = (size_t)w * scale + (size_t)pitch * (scale - 1);
+	dst[(size_t)py * rowadv + (size_t)y * pitch + dx] = src[(size_t)py * (size_t)w + (dx / scale)];
+}
+
+extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream)
+{
+	dim3 grid((w * scale + 255) / 256, h * scale);
+	hipLaunchKernelGGL(pwn_upscale_kernel, grid, dim3(256), 0, stream, src, dst, w, h, scale, pitch);
+	return hipGetLastError();
+}
+
+// --------------------------------------------------------------- probes ----
+// Device-side known-answer access to the arithmetic primitives (pwnhip.h
+// PWN_PROBE_*).  tabs = the rcp+rsqrt part of the blob.
+__global__ void pwn_probe_kernel(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs)
+{
+	__shared__ uint16_t t[4096];
+	for(int i = threadIdx.x; i < 4096; i += blockDim.x) t[i] = tabs[i];
+	__syncthreads();
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if(i >= n) return;
+	const uint16_t *rcp = t, *rsq = t + 2048;
+	switch(op)
+	{
+		case 0: out[i] = __float_as_uint(tab_rcp(rcp, __uint_as_float(in[i]))); break;
+		case 1: out[i] = __float_as_uint(tab_rsqrt(rsq, __uint_as_float(in[i]))); break;
+		case 2: out[i] = __float_as_uint(glibc_sincosf(__uint_as_float(in[i]), 0)); break;
+		case 3: out[i] = __float_as_uint(glibc_sincosf(__uint_as_float(in[i]), 1)); break;
+		case 4: out[i] = __float_as_uint(glibc_expf(__uint_as_float(in[i]))); break;
+		case 5: out[i] = __float_as_uint(sqrtf(__uint_as_float(in[i]))); break;
+		case 6: out[i] = __float_as_uint(__uint_as_float(in[2 * i]) / __uint_as_float(in[2 * i + 1])); break;
+		case 7: out[i] = col_pack(v4_set(__uint_as_float(in[4 * i]), __uint_as_float(in[4 * i + 1]),
+			__uint_as_float(in[4 * i + 2]), __uint_as_float(in[4 * i + 3]))); break;
+		case 8: { uint32_t s = in[i]; out[i] = __float_as_uint(lcg_fs(s)); break; }
+		default: out[i] = 0; break;
+	}
+}
+
+extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream)
+{
+	hipLaunchKernelGGL(pwn_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, in, out, n, tabs);
+	return hipGetLastError();
+}

@@ -1,0 +1,491 @@
+// pwn_api.cpp -- the C ABI of libpwnhip.so (include/pwnhip.h) over the HIP
+// runtime: context, table packing/upload, kernel launches, D2H.
+// Host code only; compiled with -ffp-contract=off because the camera set-up
+// of screen.h:43-57 is part of the bit-exact path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include "pwnhip.h"
+#include "level_host.h"
+#include "tables.h"
+#include "approx_tables.inc"
+
+struct pwn_blur_params
+{
+	int w, h, y0, y1;
+	int groups;
+	const uint32_t *pre;
+	const float *zbuf;
+	uint32_t *out;
+	const uint2 *skip;
+};
+
+extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
+extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
+extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
+extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
+
+// LDS budget for the table blob: leave room so that at least two workgroups
+// fit per CU (160 KiB LDS per CU on gfx950)
+#define PWN_BLOB_MAX (72u * 1024u)
+
+struct pwn_ctx
+{
+	int device, w, h;
+	int num_cus;
+	int blur_passes, counters_on;
+	bool have_level;
+
+	uint8_t cells[4096];
+	pwn_portal pmap[26];
+	int32_t spawn[2];
+	std::vector<pwn_sphere> spheres;
+	std::vector<int32_t> bin_off, bin_idx;
+
+	std::vector<uint8_t> blob;       // host image of the LDS blob
+	uint8_t *d_blob; size_t d_blob_cap;
+	uint32_t off_sph;
+	bool blob_dirty;
+
+	uint32_t *d_pre, *d_out;         // pre-blur ("tsbuf") and final ("sbuf") frames
+	float *d_z;
+	uint2 *d_skip;                   // blur LCG skip-ahead, w/4 entries
+	unsigned long long *d_counters;
+	uint32_t *d_scratch; size_t scratch_cap;   // upscale / probe staging
+
+	hipStream_t stream;
+	hipEvent_t ev[4];
+	pwn_stats stats;
+	char err[256];
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
+	snprintf((ctx)->err, sizeof((ctx)->err), "%s: %s", #call, hipGetErrorString(e_)); return PWN_EHIP; } } while(0)
+
+extern "C" const char *pwn_strerror(int code)
+{
+	switch(code)
+	{
+		case PWN_OK: return "ok";
+		case PWN_EINVAL: return "invalid argument";
+		case PWN_ENODEV: return "no usable HIP device";
+		case PWN_ENOMEM: return "out of memory";
+		case PWN_EIO: return "level file could not be read";
+		case PWN_EHIP: return "HIP runtime error";
+		case PWN_ENOLEVEL: return "no level uploaded";
+		case PWN_ETOOBIG: return "sphere tables exceed the LDS budget";
+	}
+	return "unknown error";
+}
+
+extern "C" const char *pwn_last_error(pwn_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+static int ensure_scratch(pwn_ctx *c, size_t bytes)
+{
+	if(bytes <= c->scratch_cap) return PWN_OK;
+	if(c->d_scratch) { (void)hipFree(c->d_scratch); c->d_scratch = NULL; c->scratch_cap = 0; }
+	HIPCHK(c, hipMalloc((void **)&c->d_scratch, bytes));
+	c->scratch_cap = bytes;
+	return PWN_OK;
+}
+
+extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
+{
+	if(out == NULL || width <= 0 || height <= 0 || width > 32768 || height > 32768) return PWN_EINVAL;
+	*out = NULL;
+	int ndev = 0;
+	if(hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PWN_ENODEV;
+	pwn_ctx *c = new(std::nothrow) pwn_ctx();
+	if(c == NULL) return PWN_ENOMEM;
+	c->device = device; c->w = width; c->h = height;
+	c->blur_passes = 1; c->counters_on = 0; c->have_level = false;
+	c->d_blob = NULL; c->d_blob_cap = 0; c->blob_dirty = true; c->off_sph = 0;
+	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL;
+	c->d_scratch = NULL; c->scratch_cap = 0;
+	c->stream = NULL;
+	memset(c->ev, 0, sizeof(c->ev));
+	memset(&c->stats, 0, sizeof(c->stats));
+	c->err[0] = 0;
+	pwn_level_clear(c->cells, c->pmap, c->spawn);
+	c->bin_off.assign(4097, 0);
+
+	int rc = PWN_OK;
+	do
+	{
+		hipDeviceProp_t prop;
+		if(hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) { rc = PWN_ENODEV; break; }
+		if(strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+		{
+			snprintf(c->err, sizeof(c->err), "device %d is %s; libpwnhip is built for gfx950 only", device, prop.gcnArchName);
+			rc = PWN_ENODEV; break;
+		}
+		c->num_cus = prop.multiProcessorCount;
+		size_t n = (size_t)width * (size_t)height;
+		if(hipMalloc((void **)&c->d_pre, n * 4) != hipSuccess ||
+		   hipMalloc((void **)&c->d_out, n * 4) != hipSuccess ||
+		   hipMalloc((void **)&c->d_z, n * 4) != hipSuccess ||
+		   hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+		   hipMalloc((void **)&c->d_skip, sizeof(uint2) * (size_t)(width / 4 + 1)) != hipSuccess) { rc = PWN_ENOMEM; break; }
+		if(hipMemset(c->d_z, 0, n * 4) != hipSuccess || hipMemset(c->d_pre, 0, n * 4) != hipSuccess ||
+		   hipMemset(c->d_out, 0, n * 4) != hipSuccess) { rc = PWN_EHIP; break; }
+		if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+		for(int i = 0; i < 4; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { rc = PWN_EHIP; break; }
+		if(rc != PWN_OK) break;
+
+		// blur LCG skip-ahead: entry g maps the row seed to the seed in front
+		// of group g, i.e. 32*g draws later (screen.h:82,95-109; util.h:1-6)
+		std::vector<uint2> skip((size_t)(width / 4 + 1));
+		uint32_t A = 1, C = 0;
+		for(size_t g = 0; g < skip.size(); g++)
+		{
+			skip[g].x = A; skip[g].y = C;
+			for(int k = 0; k < 32; k++) { A = (A * 25739u) & 0x7FFFFFFFu; C = (C * 25739u + 4u) & 0x7FFFFFFFu; }
+		}
+		if(hipMemcpy(c->d_skip, skip.data(), skip.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess) { rc = PWN_EHIP; break; }
+	} while(0);
+
+	if(rc != PWN_OK) { pwn_destroy(c); return rc; }
+	*out = c;
+	return PWN_OK;
+}
+
+extern "C" void pwn_destroy(pwn_ctx *c)
+{
+	if(c == NULL) return;
+	(void)hipSetDevice(c->device);
+	if(c->stream) (void)hipStreamSynchronize(c->stream);
+	for(int i = 0; i < 4; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	if(c->stream) (void)hipStreamDestroy(c->stream);
+	(void)hipFree(c->d_blob); (void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z);
+	(void)hipFree(c->d_skip); (void)hipFree(c->d_counters); (void)hipFree(c->d_scratch);
+	delete c;
+}
+
+extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
+{
+	if(c == NULL) return PWN_EINVAL;
+	switch(option)
+	{
+		case PWN_OPT_BLUR_PASSES: if(value < 0 || value > 16) return PWN_EINVAL; c->blur_passes = value; return PWN_OK;
+		case PWN_OPT_COUNTERS: c->counters_on = value ? 1 : 0; return PWN_OK;
+	}
+	return PWN_EINVAL;
+}
+
+// ---- level / spheres --------------------------------------------------------
+
+static int pack_blob(pwn_ctx *c)
+{
+	uint32_t nbin = (uint32_t)c->bin_off[4096], nsph = (uint32_t)c->spheres.size();
+	if(nbin > 65535u || nsph > 65535u) return PWN_ETOOBIG;
+	uint32_t total = (pwn_t_total(nbin, nsph) + 15u) & ~15u;
+	if(total > PWN_BLOB_MAX) return PWN_ETOOBIG;
+	c->blob.assign(total, 0);
+	uint8_t *b = c->blob.data();
+	memcpy(b + PWN_T_CELLS, c->cells, 4096);
+	memcpy(b + PWN_T_RCP, pwn_host_rcp_tab, 4096);
+	memcpy(b + PWN_T_RSQ, pwn_host_rsqrt_tab, 4096);
+	uint32_t *pm = (uint32_t *)(b + PWN_T_PMAP);
+	for(int i = 0; i < 26; i++)
+	{
+		const pwn_portal &p = c->pmap[i];
+		pm[2 * i] = (uint32_t)(p.x1 & 0xff) | ((uint32_t)(p.z1 & 0xff) << 8) | ((uint32_t)(p.x2 & 0xff) << 16) | ((uint32_t)(p.z2 & 0xff) << 24);
+		pm[2 * i + 1] = (uint32_t)(p.rot12 & 0xff) | ((uint32_t)(p.c1 & 0xff) << 8) | ((uint32_t)(p.c2 & 0xff) << 16);
+	}
+	uint16_t *bo = (uint16_t *)(b + PWN_T_BINOFF);
+	for(int i = 0; i <= 4096; i++) bo[i] = (uint16_t)c->bin_off[i];
+	uint16_t *bi = (uint16_t *)(b + PWN_T_BINIDX);
+	for(uint32_t i = 0; i < nbin; i++) bi[i] = (uint16_t)c->bin_idx[i];
+	c->off_sph = pwn_t_sph_offset(nbin);
+	if(nsph) memcpy(b + c->off_sph, c->spheres.data(), nsph * sizeof(pwn_sphere));
+
+	if(total > c->d_blob_cap)
+	{
+		if(c->d_blob) { (void)hipFree(c->d_blob); c->d_blob = NULL; c->d_blob_cap = 0; }
+		HIPCHK(c, hipMalloc((void **)&c->d_blob, total));
+		c->d_blob_cap = total;
+	}
+	// stream-ordered so that a frame in flight keeps its tables
+	HIPCHK(c, hipMemcpyAsync(c->d_blob, b, total, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	c->blob_dirty = false;
+	return PWN_OK;
+}
+
+static int valid_portals(const pwn_portal *pm)
+{
+	for(int i = 0; i < 26; i++)
+	{
+		const int32_t v[4] = { pm[i].x1, pm[i].z1, pm[i].x2, pm[i].z2 };
+		for(int k = 0; k < 4; k++) if(v[k] < -1 || v[k] > 63) return 0;
+	}
+	return 1;
+}
+
+extern "C" int pwn_upload_level(pwn_ctx *c, const uint8_t data[4096], const pwn_portal pmap[26])
+{
+	if(c == NULL || data == NULL || pmap == NULL || !valid_portals(pmap)) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	memcpy(c->cells, data, 4096);
+	memcpy(c->pmap, pmap, sizeof(c->pmap));
+	c->have_level = true;
+	c->blob_dirty = true;
+	return pack_blob(c);
+}
+
+extern "C" int pwn_level_load_mem(pwn_ctx *c, const char *text, int len)
+{
+	if(c == NULL || text == NULL || len < 0) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	if(pwn_parse_level(text, len, c->cells, c->pmap, c->spawn) != 0) return PWN_EINVAL;
+	c->have_level = true;
+	c->blob_dirty = true;
+	return pack_blob(c);
+}
+
+extern "C" int pwn_level_load(pwn_ctx *c, const char *path)
+{
+	if(c == NULL || path == NULL) return PWN_EINVAL;
+	FILE *fp = fopen(path, "rb");
+	if(fp == NULL) { snprintf(c->err, sizeof(c->err), "cannot open %s", path); return PWN_EIO; }
+	std::vector<char> buf(1 << 20);
+	size_t n = fread(buf.data(), 1, buf.size(), fp);
+	fclose(fp);
+	return pwn_level_load_mem(c, buf.data(), (int)n);
+}
+
+extern "C" int pwn_get_level(pwn_ctx *c, uint8_t data[4096], pwn_portal pmap[26], int32_t spawn[2])
+{
+	if(c == NULL) return PWN_EINVAL;
+	if(data) memcpy(data, c->cells, 4096);
+	if(pmap) memcpy(pmap, c->pmap, sizeof(c->pmap));
+	if(spawn) { spawn[0] = c->spawn[0]; spawn[1] = c->spawn[1]; }
+	return PWN_OK;
+}
+
+extern "C" int pwn_upload_spheres(pwn_ctx *c, const pwn_sphere *s, int n)
+{
+	if(c == NULL || n < 0 || (n > 0 && s == NULL)) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	std::vector<int32_t> off(4097, 0);
+	int nb = pwn_bin_spheres(s, n, off.data(), NULL, 0);
+	if(nb < 0) return PWN_ENOMEM;
+	std::vector<int32_t> idx((size_t)(nb > 0 ? nb : 1));
+	if(pwn_bin_spheres(s, n, off.data(), idx.data(), nb) != nb) return PWN_ENOMEM;
+	std::vector<pwn_sphere> keep_s(c->spheres);
+	std::vector<int32_t> keep_o(c->bin_off), keep_i(c->bin_idx);
+	c->spheres.assign(s, s + n);
+	c->bin_off.swap(off);
+	c->bin_idx.swap(idx);
+	c->blob_dirty = true;
+	int rc = pack_blob(c);
+	if(rc != PWN_OK)
+	{
+		// keep the previous, working set
+		c->spheres.swap(keep_s); c->bin_off.swap(keep_o); c->bin_idx.swap(keep_i);
+		(void)pack_blob(c);
+	}
+	return rc;
+}
+
+extern "C" int pwn_get_bins(pwn_ctx *c, uint16_t counts[4096], int32_t *idx, int cap)
+{
+	if(c == NULL || counts == NULL) return PWN_EINVAL;
+	for(int i = 0; i < 4096; i++) counts[i] = (uint16_t)(c->bin_off[i + 1] - c->bin_off[i]);
+	int n = c->bin_off[4096];
+	if(idx != NULL)
+	{
+		if(n > cap) return PWN_EINVAL;
+		for(int i = 0; i < n; i++) idx[i] = c->bin_idx[i];
+	}
+	return n;
+}
+
+// ---- frame ------------------------------------------------------------------
+
+// screen.h:43-57 in the reference build's operation order:
+// rayb = (cam.x + cam.z) + (-yrat)*cam.y
+static void frame_setup(int w, int h, const float cam[16], pwn_trace_params *P)
+{
+	float dimx = (float)w, dimy = (float)h;
+	float yrat = (-dimy) / dimx;
+	float xsrat = -2.0f / dimx;
+	float ysrat = (yrat + yrat) / dimy;
+	for(int i = 0; i < 4; i++)
+	{
+		P->rayb[i] = (cam[0 + i] + cam[8 + i]) + (-yrat) * cam[4 + i];
+		P->rdx[i] = xsrat * cam[0 + i];
+		P->rdy[i] = ysrat * cam[4 + i];
+		P->from[i] = cam[12 + i];
+	}
+}
+
+static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y1,
+	uint32_t *d_sbuf, float *d_zbuf, hipStream_t stream)
+{
+	if(!c->have_level) return PWN_ENOLEVEL;
+	if(c->blob_dirty) { int rc = pack_blob(c); if(rc != PWN_OK) return rc; }
+	if(y1 == y0) return PWN_OK;
+	pwn_trace_params P;
+	memset(&P, 0, sizeof(P));
+	frame_setup(c->w, c->h, cam, &P);
+	P.sec_current = sec;
+	P.w = c->w; P.h = c->h; P.y0 = y0; P.y1 = y1;
+	P.tiles_x = (c->w + 31) / 32;
+	P.tiles_total = P.tiles_x * ((y1 - y0 + 7) / 8);
+	P.blob_bytes = (uint32_t)c->blob.size();
+	P.off_sph = c->off_sph;
+	P.sbuf = d_sbuf; P.zbuf = d_zbuf;
+	P.blob = (const uint32_t *)c->d_blob;
+	P.counters = c->d_counters;
+	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+	// persistent grid: a few workgroups per CU, each striding over tiles
+	int per_cu = (int)((160u * 1024u) / (P.blob_bytes + 1024u));
+	if(per_cu > 8) per_cu = 8;
+	if(per_cu < 1) per_cu = 1;
+	int grid = c->num_cus * per_cu;
+	if(grid > P.tiles_total) grid = P.tiles_total;
+	HIPCHK(c, pwn_launch_trace(&P, grid, P.blob_bytes, c->counters_on != 0, stream));
+	return PWN_OK;
+}
+
+static int launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream)
+{
+	if((c->w & 3) != 0) return PWN_EINVAL; // screen.h:88,117: aligned 16-B store per group
+	pwn_blur_params B;
+	B.w = c->w; B.h = c->h; B.y0 = y0; B.y1 = y1;
+	B.groups = c->w / 4;
+	B.pre = d_pre; B.zbuf = d_z; B.out = d_out; B.skip = c->d_skip;
+	HIPCHK(c, pwn_launch_blur(&B, stream));
+	return PWN_OK;
+}
+
+extern "C" int pwn_trace_rows_device(pwn_ctx *c, const float cam[16], float sec, int y0, int y1,
+	void *d_sbuf, void *d_zbuf, void *stream)
+{
+	if(c == NULL || cam == NULL || d_sbuf == NULL || d_zbuf == NULL || y0 < 0 || y1 > c->h || y0 > y1) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	return launch_trace(c, cam, sec, y0, y1, (uint32_t *)d_sbuf, (float *)d_zbuf, (hipStream_t)stream);
+}
+
+extern "C" int pwn_blur_rows_device(pwn_ctx *c, int y0, int y1, const void *d_pre, const void *d_zbuf, void *d_out, void *stream)
+{
+	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || y0 < 0 || y1 > c->h || y0 > y1 || d_pre == d_out) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	return launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream);
+}
+
+extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float sec, uint32_t *sbuf, float *zbuf)
+{
+	if(c == NULL || cam == NULL || sbuf == NULL) return PWN_EINVAL;
+	if(c->blur_passes > 0 && (c->w & 3) != 0) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	size_t n = (size_t)c->w * (size_t)c->h;
+	hipStream_t s = c->stream;
+	HIPCHK(c, hipEventRecord(c->ev[0], s));
+	// trace into d_pre; with blur on, d_pre plays tsbuf and d_out plays sbuf
+	// (the memcpy of screen.h:75 becomes a pointer swap per pass)
+	uint32_t *cur = c->d_pre, *other = c->d_out;
+	int rc = launch_trace(c, cam, sec, 0, c->h, cur, c->d_z, s);
+	if(rc != PWN_OK) return rc;
+	HIPCHK(c, hipEventRecord(c->ev[1], s));
+	for(int p = 0; p < c->blur_passes; p++)
+	{
+		rc = launch_blur(c, 0, c->h, cur, c->d_z, other, s);
+		if(rc != PWN_OK) return rc;
+		uint32_t *t = cur; cur = other; other = t;
+	}
+	HIPCHK(c, hipEventRecord(c->ev[2], s));
+	HIPCHK(c, hipMemcpyAsync(sbuf, cur, n * 4, hipMemcpyDeviceToHost, s));
+	if(zbuf != NULL) HIPCHK(c, hipMemcpyAsync(zbuf, c->d_z, n * 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(c, hipEventRecord(c->ev[3], s));
+	HIPCHK(c, hipStreamSynchronize(s));
+	// keep the final frame addressable as d_out for pwn_screen_upscale(NULL,...)
+	if(cur != c->d_out) { c->d_pre = c->d_out; c->d_out = cur; }
+	(void)hipEventElapsedTime(&c->stats.trace_ms, c->ev[0], c->ev[1]);
+	(void)hipEventElapsedTime(&c->stats.blur_ms, c->ev[1], c->ev[2]);
+	(void)hipEventElapsedTime(&c->stats.total_ms, c->ev[0], c->ev[3]);
+	return PWN_OK;
+}
+
+extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
+{
+	if(c == NULL || out == NULL) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	if(c->counters_on)
+	{
+		unsigned long long v[8];
+		HIPCHK(c, hipMemcpy(v, c->d_counters, sizeof(v), hipMemcpyDeviceToHost));
+		c->stats.rays = v[0]; c->stats.steps = v[1]; c->stats.portals = v[2];
+		c->stats.sphere_tests = v[3]; c->stats.exhausted = v[4];
+	}
+	*out = c->stats;
+	return PWN_OK;
+}
+
+// ---- sink -------------------------------------------------------------------
+
+extern "C" int pwn_upscale_device(pwn_ctx *c, const void *d_src, int scale, int pitch_bytes, void *d_dst, void *stream)
+{
+	if(c == NULL || d_src == NULL || d_dst == NULL || scale <= 0 || (pitch_bytes & 3) != 0 ||
+	   (long long)pitch_bytes < (long long)c->w * scale * 4) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	HIPCHK(c, pwn_launch_upscale((const uint32_t *)d_src, (uint32_t *)d_dst, c->w, c->h, scale, pitch_bytes / 4, (hipStream_t)stream));
+	return PWN_OK;
+}
+
+extern "C" int pwn_screen_upscale(pwn_ctx *c, const uint32_t *sbuf, int scale, int pitch_bytes, uint32_t *pixels)
+{
+	if(c == NULL || pixels == NULL || scale <= 0 || (pitch_bytes & 3) != 0 ||
+	   (long long)pitch_bytes < (long long)c->w * scale * 4) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	size_t n = (size_t)c->w * (size_t)c->h;
+	size_t dst_bytes = (size_t)pitch_bytes * (size_t)c->h * (size_t)scale;
+	int rc = ensure_scratch(c, dst_bytes + n * 4);
+	if(rc != PWN_OK) return rc;
+	uint32_t *d_dst = c->d_scratch;
+	const uint32_t *d_src = c->d_out;
+	if(sbuf != NULL)
+	{
+		uint32_t *d_in = (uint32_t *)((uint8_t *)c->d_scratch + dst_bytes);
+		HIPCHK(c, hipMemcpyAsync(d_in, sbuf, n * 4, hipMemcpyHostToDevice, c->stream));
+		d_src = d_in;
+	}
+	// With pitch == w*scale*4 every byte of the surface is written.  Otherwise
+	// the reference leaves gaps untouched (and packs rows, see the kernel):
+	// start from the caller's surface so that untouched bytes survive.
+	bool padded = (long long)pitch_bytes != (long long)c->w * scale * 4;
+	if(padded) HIPCHK(c, hipMemcpyAsync(d_dst, pixels, dst_bytes, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, pwn_launch_upscale(d_src, d_dst, c->w, c->h, scale, pitch_bytes / 4, c->stream));
+	HIPCHK(c, hipMemcpyAsync(pixels, d_dst, dst_bytes, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return PWN_OK;
+}
+
+// ---- probes -----------------------------------------------------------------
+
+extern "C" int pwn_probe(pwn_ctx *c, int op, const uint32_t *in, uint32_t *out, int n)
+{
+	if(c == NULL || in == NULL || out == NULL || n < 0 || op < 0 || op > PWN_PROBE_RANDFS) return PWN_EINVAL;
+	if(n == 0) return PWN_OK;
+	(void)hipSetDevice(c->device);
+	size_t per = (op == PWN_PROBE_DIV) ? 2 : (op == PWN_PROBE_FTOINT ? 4 : 1);
+	size_t in_bytes = (size_t)n * per * 4, out_bytes = (size_t)n * 4;
+	int rc = ensure_scratch(c, in_bytes + out_bytes + 8192);
+	if(rc != PWN_OK) return rc;
+	uint8_t *base = (uint8_t *)c->d_scratch;
+	uint16_t *d_tabs = (uint16_t *)base;
+	uint32_t *d_in = (uint32_t *)(base + 8192), *d_out = (uint32_t *)(base + 8192 + in_bytes);
+	HIPCHK(c, hipMemcpyAsync(d_tabs, pwn_host_rcp_tab, 4096, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipMemcpyAsync(d_tabs + 2048, pwn_host_rsqrt_tab, 4096, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(c, pwn_launch_probe(op, d_in, d_out, n, d_tabs, c->stream));
+	HIPCHK(c, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(c, hipStreamSynchronize(c->stream));
+	return PWN_OK;
+}

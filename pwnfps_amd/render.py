@@ -1,0 +1,196 @@
+"""Host-side mirror of the reference's render interface, over libpwnhip.so.
+
+Names follow the reference: ``level_load`` (level.h:107), ``level_prepare_render``
+(level.h:64; here ``set_objects``), ``trace_screen_centred`` (screen.h:31),
+``screen_upscale`` (screen.h:126).  Errors the reference reports by returning
+NULL / asserting are raised as ``PwnError`` with the library's code.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib
+
+SPHERE_DTYPE = np.dtype([("r", "<f4"), ("refl", "<f4"), ("x", "<f4"), ("y", "<f4"),
+                         ("z", "<f4"), ("cb", "<f4"), ("cg", "<f4"), ("cr", "<f4")])
+PORTAL_DTYPE = np.dtype([(n, "<i4") for n in ("x1", "z1", "x2", "z2", "rot12", "c1", "c2")])
+
+
+class PwnError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = "%s: %s (%d)" % (where, lib.pwn_strerror(code).decode(), code)
+        if detail:
+            msg += ": " + detail
+        super().__init__(msg)
+
+
+class Renderer:
+    """One GPU context for a fixed frame size (rwidth x rheight, main.c:26-27)."""
+
+    def __init__(self, width, height, device=0):
+        self.w, self.h, self.device = int(width), int(height), int(device)
+        self._ctx = C.c_void_p()
+        rc = lib.pwn_init(C.byref(self._ctx), self.device, self.w, self.h)
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            raise PwnError(rc, "pwn_init(device=%d, %dx%d)" % (device, width, height))
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx.value:
+            lib.pwn_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where):
+        if rc < 0:
+            raise PwnError(rc, where, lib.pwn_last_error(self._ctx).decode(errors="replace"))
+        return rc
+
+    # -- options -----------------------------------------------------------
+    def set_blur_passes(self, n):
+        """POSTPROC_BLUR (defs.h:9); 0 disables the post-process."""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_BLUR_PASSES, int(n)), "pwn_set_option")
+
+    def set_counters(self, on):
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_COUNTERS, 1 if on else 0), "pwn_set_option")
+
+    # -- level (level.h:107-228) ---------------------------------------------
+    def level_load(self, path):
+        self._chk(lib.pwn_level_load(self._ctx, str(path).encode()), "pwn_level_load(%s)" % path)
+
+    def level_load_text(self, text):
+        if isinstance(text, str):
+            text = text.encode("latin-1")
+        self._chk(lib.pwn_level_load_mem(self._ctx, text, len(text)), "pwn_level_load_mem")
+
+    def upload_level(self, data, pmap):
+        data = np.ascontiguousarray(data, np.uint8)
+        pmap = np.ascontiguousarray(pmap, np.int32)
+        if data.shape != (64, 64) or pmap.shape != (26, 7):
+            raise ValueError("data must be (64,64) uint8 and pmap (26,7) int32")
+        self._chk(lib.pwn_upload_level(self._ctx, data.ctypes.data, pmap.ctypes.data), "pwn_upload_level")
+
+    def get_level(self):
+        data = np.zeros((64, 64), np.uint8)
+        pmap = np.zeros((26, 7), np.int32)
+        spawn = np.zeros(2, np.int32)
+        self._chk(lib.pwn_get_level(self._ctx, data.ctypes.data, pmap.ctypes.data, spawn.ctypes.data), "pwn_get_level")
+        return data, pmap, spawn
+
+    # -- objects (script.h:10-40 + level.h:64-81) ----------------------------
+    def set_objects(self, spheres):
+        """The live sphere set for the next frames; binning per cell
+        (level_prepare_render) happens inside."""
+        spheres = np.ascontiguousarray(spheres, SPHERE_DTYPE)
+        self._chk(lib.pwn_upload_spheres(self._ctx, spheres.ctypes.data if len(spheres) else None,
+                                         len(spheres)), "pwn_upload_spheres")
+
+    def get_bins(self):
+        counts = np.zeros(4096, np.uint16)
+        n = self._chk(lib.pwn_get_bins(self._ctx, counts.ctypes.data, None, 0), "pwn_get_bins")
+        idx = np.zeros(max(n, 1), np.int32)
+        self._chk(lib.pwn_get_bins(self._ctx, counts.ctypes.data, idx.ctypes.data, n), "pwn_get_bins")
+        return counts, idx[:n]
+
+    # -- frame (screen.h:31-124) ---------------------------------------------
+    def trace_screen_centred(self, cam, sec_current=0.0, want_z=True, sbuf=None, zbuf=None):
+        cam = np.ascontiguousarray(cam, np.float32).reshape(16)
+        if sbuf is None:
+            sbuf = np.empty((self.h, self.w), np.uint32)
+        if want_z and zbuf is None:
+            zbuf = np.empty((self.h, self.w), np.float32)
+        self._chk(lib.pwn_trace_screen_centred(self._ctx, cam.ctypes.data, float(sec_current),
+                                               sbuf.ctypes.data, zbuf.ctypes.data if want_z else None),
+                  "pwn_trace_screen_centred")
+        return (sbuf, zbuf) if want_z else sbuf
+
+    def trace_rows_device(self, cam, sec_current, y0, y1, d_sbuf, d_zbuf, stream=0):
+        """Rows [y0,y1) into device frames given as raw device pointers."""
+        cam = np.ascontiguousarray(cam, np.float32).reshape(16)
+        self._chk(lib.pwn_trace_rows_device(self._ctx, cam.ctypes.data, float(sec_current), int(y0), int(y1),
+                                            C.c_void_p(d_sbuf), C.c_void_p(d_zbuf), C.c_void_p(stream)),
+                  "pwn_trace_rows_device")
+
+    def blur_rows_device(self, y0, y1, d_pre, d_zbuf, d_out, stream=0):
+        self._chk(lib.pwn_blur_rows_device(self._ctx, int(y0), int(y1), C.c_void_p(d_pre), C.c_void_p(d_zbuf),
+                                           C.c_void_p(d_out), C.c_void_p(stream)), "pwn_blur_rows_device")
+
+    # -- sink (screen.h:126-149) ----------------------------------------------
+    def screen_upscale(self, sbuf, scale, pitch_bytes=None, pixels=None):
+        scale = int(scale)
+        if pitch_bytes is None:
+            pitch_bytes = self.w * scale * 4
+        if pixels is None:
+            pixels = np.zeros((self.h * scale, pitch_bytes // 4), np.uint32)
+        src = None
+        if sbuf is not None:
+            sbuf = np.ascontiguousarray(sbuf, np.uint32)
+            src = sbuf.ctypes.data
+        self._chk(lib.pwn_screen_upscale(self._ctx, src, scale, int(pitch_bytes), pixels.ctypes.data),
+                  "pwn_screen_upscale")
+        return pixels
+
+    def upscale_device(self, d_src, scale, pitch_bytes, d_dst, stream=0):
+        self._chk(lib.pwn_upscale_device(self._ctx, C.c_void_p(d_src), int(scale), int(pitch_bytes),
+                                         C.c_void_p(d_dst), C.c_void_p(stream)), "pwn_upscale_device")
+
+    # -- stats / probes --------------------------------------------------------
+    def stats(self):
+        st = _lib.Stats()
+        self._chk(lib.pwn_get_stats(self._ctx, C.byref(st)), "pwn_get_stats")
+        return {n: getattr(st, n) for n, _ in _lib.Stats._fields_}
+
+    def probe(self, op, words):
+        words = np.ascontiguousarray(words).view(np.uint32).ravel()
+        per = {_lib.PROBE_DIV: 2, _lib.PROBE_FTOINT: 4}.get(op, 1)
+        n = words.size // per
+        out = np.zeros(n, np.uint32)
+        self._chk(lib.pwn_probe(self._ctx, int(op), words.ctypes.data, out.ctypes.data, n), "pwn_probe")
+        return out
+
+
+# camera helpers the host uses to pose the view (util.h:61-110; outside the
+# kernel path, restated for drivers and tests)
+def mat4_iden():
+    return np.eye(4, dtype=np.float32)
+
+
+def mat4_roty(m, ang):
+    m = np.array(m, np.float32).reshape(4, 4).copy()
+    vs, vc = np.float32(np.sin(np.float32(ang))), np.float32(np.cos(np.float32(ang)))
+    vxx, vxz, vzx, vzz = m[0, 0], m[0, 2], m[2, 0], m[2, 2]
+    m[0, 0] = vc * vxx + vs * vxz
+    m[0, 2] = vc * vxz - vs * vxx
+    m[2, 0] = vc * vzx + vs * vzz
+    m[2, 2] = vc * vzz - vs * vzx
+    return m
+
+
+def mat4_rotx(m, ang):
+    m = np.array(m, np.float32).reshape(4, 4).copy()
+    vs, vc = np.float32(np.sin(np.float32(ang))), np.float32(np.cos(np.float32(ang)))
+    vyy, vyz, vzy, vzz = m[1, 1], m[1, 2], m[2, 1], m[2, 2]
+    m[1, 1] = vc * vyy + vs * vyz
+    m[1, 2] = vc * vyz - vs * vyy
+    m[2, 1] = vc * vzy + vs * vzz
+    m[2, 2] = vc * vzz - vs * vzy
+    return m
+
+
+def spawn_camera(spawn, ang_y=0.0, ang_x=0.0):
+    """mainloop's camera (main.c:61-64): identity at the spawn cell centre,
+    optionally turned like the arrow keys do (main.c:188-193)."""
+    cam = mat4_iden()
+    if ang_y:
+        cam = mat4_roty(cam, ang_y)
+    if ang_x:
+        cam = mat4_rotx(cam, ang_x)
+    cam[3, 0], cam[3, 1], cam[3, 2] = spawn[0] + 0.5, 0.5, spawn[1] + 0.5
+    return cam

@@ -1,0 +1,86 @@
+"""Direct oracle <-> compiled-reference comparisons.  They run wherever
+oracle/_ref/*.so exists (built by oracle/Makefile from /root/reference)."""
+import numpy as np
+import pytest
+
+import refharness
+from conftest import host_is_intel, level_path, load_spheres
+
+pytestmark = pytest.mark.skipif(not refharness.available("tab"), reason="oracle/_ref not built")
+
+
+def _pose(x, y, z, ay, ax):
+    cy, sy = np.float32(np.cos(ay)), np.float32(np.sin(ay))
+    cx, sx = np.float32(np.cos(ax)), np.float32(np.sin(ax))
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], np.float32)
+    rx = np.array([[1, 0, 0], [0, cx, sx], [0, -sx, cx]], np.float32)
+    m = np.eye(4, dtype=np.float32)
+    m[:3, :3] = (rx @ ry).astype(np.float32)
+    m[3, :3] = (x, y, z)
+    return m
+
+
+def test_random_scenes(oracle_lib):
+    rng = np.random.default_rng(777)
+    R = refharness.RefHarness("tab")
+    for lvl in ("pwnfps_level", "synth64", "synth256"):
+        R.load_level(level_path(lvl))
+        O = oracle_lib.Oracle()
+        O.load_level(level_path(lvl))
+        data, _, _ = O.get_level()
+        free = [(x, z) for z in range(64) for x in range(64) if chr(data[z, x]) in ';$"#&><,^']
+        for it in range(12):
+            x, z = free[rng.integers(len(free))]
+            cam = _pose(x + rng.uniform(0.05, 0.95), rng.uniform(0.05, 0.95), z + rng.uniform(0.05, 0.95),
+                        rng.uniform(0, 6.28), rng.uniform(-1.2, 1.2))
+            sph = np.zeros(int(rng.integers(0, 20)), oracle_lib.SPHERE_DTYPE)
+            for i in range(len(sph)):
+                sph[i] = (rng.uniform(0.03, 0.4), rng.choice([0.0, 0.3, 0.6]), x + rng.uniform(-1, 2), rng.uniform(0.1, 1.2),
+                          z + rng.uniform(-1, 2), *rng.uniform(0, 1.2, 3))
+            sph["x"] = np.clip(sph["x"], 0.6, 62.4); sph["z"] = np.clip(sph["z"], 0.6, 62.4)
+            sec = float(rng.uniform(0, 100))
+            R.set_spheres(sph); O.set_spheres(sph)
+            for blur in (0, 1):
+                a, za = R.render(200, 152, cam, sec=sec, blur=blur)
+                b, zb = O.render(200, 152, cam, sec=sec, blur=blur)
+                assert (a == b).all(), (lvl, it, blur, int((a != b).sum()))
+                assert (za.view(np.uint32) == zb.view(np.uint32)).all(), (lvl, it)
+
+
+def test_w_lane_generality(oracle_lib):
+    """v_dot / v_normalise are 4-lane (util.h:18-46): a camera matrix with
+    non-zero w entries must still agree."""
+    R = refharness.RefHarness("tab")
+    R.load_level(level_path("pwnfps_level"))
+    O = oracle_lib.Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    sph = load_spheres("t0")
+    R.set_spheres(sph); O.set_spheres(sph)
+    cam = _pose(9.5, 0.5, 4.5, 0.3, 0.1)
+    cam[0, 3], cam[1, 3], cam[2, 3], cam[3, 3] = 0.05, -0.02, 0.1, 0.7
+    a, za = R.render(256, 128, cam, blur=1)
+    b, zb = O.render(256, 128, cam, blur=1)
+    assert (a == b).all() and (za.view(np.uint32) == zb.view(np.uint32)).all()
+
+
+def test_native_and_table_builds_agree_on_intel():
+    if not (host_is_intel() and refharness.available("hw")):
+        pytest.skip("needs an Intel host")
+    H = refharness.RefHarness("hw")
+    T = refharness.RefHarness("tab")
+    for X in (H, T):
+        X.load_level(level_path("pwnfps_level"))
+        X.set_spheres(load_spheres("t0"))
+    cam = _pose(9.5, 0.5, 4.5, 1.0, -0.1)
+    a, za = H.render(320, 240, cam, sec=3.0)
+    b, zb = T.render(320, 240, cam, sec=3.0)
+    assert (a == b).all() and (za.view(np.uint32) == zb.view(np.uint32)).all()
+
+
+def test_upscale_vs_reference(oracle_lib):
+    R = refharness.RefHarness("tab")
+    O = oracle_lib.Oracle()
+    rng = np.random.default_rng(3)
+    src = rng.integers(0, 2 ** 32, (9, 20), dtype=np.uint32)
+    for scale, pitch in ((1, 80), (2, 176), (3, 240), (4, 336)):
+        assert (R.upscale(src, scale, pitch) == O.upscale(src, scale, pitch)).all()
