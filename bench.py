@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the portal ray-march path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one frame of the workload BASELINE.json quotes the metric on: the
+reference's level.txt scene (its 14 game.lua spheres, camera at the spawn
+pose, sec_current = 0) at 3840x2160 with the post-process blur on, i.e. one
+trace_screen_centred() (screen.h:31-124).  With N > 1 the frame is row-tiled:
+rank r traces rows [r*H/N, (r+1)*H/N), the pre-blur strips are all-gathered
+(RCCL), each rank blurs its strip, and the strips are gathered on rank 0
+(pwnfps_amd/dist.py).  Level/sphere tables and all frame buffers are resident
+in HBM before the timed region; the frame stays on the device (the
+PCIe-inclusive rate is reported separately as pcie_inclusive_mpix_s).
+
+Prints ONE JSON line on rank 0.  After the timed region the last frame is
+hashed and compared with the golden hash of the compiled reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+TRACE_BYTES_PER_PIXEL = 8      # colour 4 B + depth 4 B written; everything read is in LDS
+FRAME_BYTES_PER_PIXEL = 20     # + blur: read colour 4 + read depth 4 + write final 4
+
+
+def cpu_baseline(w, h, cam, spheres, level_file, target_s=10.0):
+    """The reference's own code (oracle/_ref, built from /root/reference with the
+    reference's flags) timed on this host's cores; falls back to the port."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    threads = os.cpu_count() or 1
+    try:
+        import refharness
+        if refharness.available("hw"):
+            R = refharness.RefHarness("hw")
+            R.load_level(level_file)
+            R.set_spheres(spheres)
+            R.render(w, h // 8, cam, threads=threads, want_z=False)       # page in, spin up the team
+            t0 = time.perf_counter()
+            R.render(w, h, cam, threads=threads, want_z=False)
+            t1 = time.perf_counter() - t0
+            reps = int(min(20, max(1, round(target_s / max(t1, 1e-3)))))
+            best = t1
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                R.render(w, h, cam, threads=threads, want_z=False)
+                best = min(best, time.perf_counter() - t0)
+            return {"value": round(w * h / best / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "reference",
+                    "sample": "%d full %dx%d frames (trace+blur) of the same scene, best of %d, reference "
+                              "sources compiled with its own flags (gcc -O3 -fopenmp -ffast-math -funroll-loops), "
+                              "OpenMP over 32-row chunks as screen.h:63" % (reps + 1, w, h, reps + 1)}
+    except Exception as e:  # noqa: BLE001 -- a broken checker must not kill the bench line
+        sys.stderr.write("cpu_baseline: reference build unusable (%s); using the port\n" % e)
+    import oracle
+    O = oracle.Oracle()
+    O.load_level(level_file)
+    O.set_spheres(spheres)
+    t0 = time.perf_counter()
+    O.render(w, h, cam, threads=threads)
+    t1 = time.perf_counter() - t0
+    reps = int(min(10, max(1, round(target_s / max(t1, 1e-3)))))
+    best = t1
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        O.render(w, h, cam, threads=threads)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(w * h / best / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "sample": "%d full %dx%d frames (trace+blur) of the same scene, best of %d, scalar C restatement "
+                      "with table-emulated rcpps/rsqrtps, OpenMP over rows" % (reps + 1, w, h, reps + 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--level", default="pwnfps_level")
+    ap.add_argument("--blur", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import pwnfps_amd
+    from pwnfps_amd.dist import HipStripBackend, RowTiledFrame
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: libpwnhip.so has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    w, h = args.width, args.height
+    level_file = os.path.join(GOLD, "levels", args.level + ".txt")
+    if args.level == "pwnfps_level":
+        spheres = np.load(os.path.join(GOLD, "spheres_t0.npy"))
+    else:
+        spheres = np.load(os.path.join(GOLD, "levels", args.level + "_spheres.npy"))
+
+    r = pwnfps_amd.Renderer(w, h, device=local)
+    r.level_load(level_file)
+    r.set_objects(spheres)
+    _, _, spawn = r.get_level()
+    cam = pwnfps_amd.spawn_camera(spawn)            # main.c:61-64
+    sec = 0.0
+
+    fr = RowTiledFrame(w, h, HipStripBackend(r), dev, rank=rank, world=world, blur_passes=args.blur)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # per-launch timing of the dominant (trace) kernel: HIP events on the stream
+    # the kernel is launched on (torch's current stream), inside the timed region
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    be = fr.backend
+    real_trace = be.trace_rows
+    slot = {"i": -1}
+
+    def timed_trace(*a):
+        i = slot["i"]
+        if i >= 0:
+            ev[i][0].record()
+        real_trace(*a)
+        if i >= 0:
+            ev[i][1].record()
+    be.trace_rows = timed_trace
+
+    out = None
+    for _ in range(args.warmup):
+        out = fr.render(cam, sec)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        slot["i"] = i
+        out = fr.render(cam, sec)
+    slot["i"] = -1
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    trace_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+    tr = torch.tensor([trace_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+    trace_ms = float(tr.item())
+
+    # ---- outside the timed region: parity of the last frame, work counters ----
+    parity = None
+    frame_hash = None
+    if rank == 0 and out is not None:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        try:
+            import oracle  # checker only: FNV of the frame vs the compiled reference's golden
+            frame_hash = oracle.fnv64(fr.to_host(out))
+            with open(os.path.join(GOLD, "frames.json")) as f:
+                cases = json.load(f)["cases"]
+            want = [c for c in cases if c["level"] == args.level and (c["w"], c["h"]) == (w, h)
+                    and c["sec"] == 0.0 and c["nspheres"] == len(spheres) and c["name"].startswith(("level_spawn", args.level + "_cam0"))]
+            if want and args.level == "pwnfps_level":
+                parity = bool(frame_hash == (want[0]["post"] if args.blur else want[0]["pre"]))
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("parity check skipped: %s\n" % e)
+
+    counters = None
+    pcie = None
+    if world == 1:
+        r.set_counters(True)
+        r.set_blur_passes(args.blur)
+        sb = np.empty((h, w), np.uint32)
+        r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
+        st = r.stats()
+        r.set_counters(False)
+        counters = {"rays_per_pixel": round(st["rays"] / (w * h), 4),
+                    "steps_per_ray": round(st["steps"] / max(st["rays"], 1), 4),
+                    "portal_crossings_per_ray": round(st["portals"] / max(st["rays"], 1), 4),
+                    "sphere_tests_per_ray": round(st["sphere_tests"] / max(st["rays"], 1), 4)}
+        best = 1e9
+        for _ in range(5):
+            t1 = time.perf_counter()
+            r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
+            best = min(best, time.perf_counter() - t1)
+        pcie = round(w * h / best / 1e6, 2)
+        st = r.stats()
+        kernel_ms = {"trace": round(st["trace_ms"], 4), "blur": round(st["blur_ms"], 4)}
+    else:
+        kernel_ms = None
+
+    if rank == 0:
+        pix = w * h
+        strip_pix = (fr.y1 - fr.y0) * w
+        achieved = TRACE_BYTES_PER_PIXEL * strip_pix / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        line = {
+            "metric": "Mpixels/s at 3840x2160 (level.txt scene, trace + blur), mean steps/ray alongside",
+            "value": round(pix * args.steps / dt / 1e6, 3),
+            "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "pwnfps level.txt scene (14 game.lua spheres, spawn pose, sec_current=0), "
+                                   "%dx%d, POSTPROC_BLUR=%d, one frame per step" % (w, h, args.blur),
+                       "level": args.level, "width": w, "height": h, "blur_passes": args.blur,
+                       "parallelism": "rows/%d" % world + ("" if world == 1 else " + RCCL all-gather(pre-blur) + gather(strips)")},
+            "roofline": {"bound": "hbm", "kernel": "pwn_trace_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "bytes_per_pixel": TRACE_BYTES_PER_PIXEL, "pixels_per_launch": strip_pix,
+                         "avg_launch_ms": round(trace_ms, 4),
+                         "note": "VALU/divergence-bound DDA: tables live in LDS, compulsory HBM traffic is the 8 B/pixel written"},
+            "frame_bytes_per_pixel": FRAME_BYTES_PER_PIXEL,
+            "frame_gbs": round(FRAME_BYTES_PER_PIXEL * pix * args.steps / dt / 1e9, 3),
+            "parity_vs_reference_golden": parity,
+            "frame_fnv64": frame_hash,
+        }
+        if counters:
+            line["work"] = counters
+        if kernel_ms:
+            line["kernel_ms"] = kernel_ms
+        if pcie:
+            line["pcie_inclusive_mpix_s"] = pcie
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, h, cam, spheres, level_file)
+        print(json.dumps(line), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
