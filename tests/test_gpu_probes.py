@@ -44,7 +44,13 @@ def test_libm_kat_and_oracle(R, oracle_lib):
     k = np.load(os.path.join(GOLD, "libm_kat.npz"))
     assert (R.probe(_lib.PROBE_SINF, k["x_sincos"]) == k["sinf"].view(np.uint32)).all()
     assert (R.probe(_lib.PROBE_COSF, k["x_sincos"]) == k["cosf"].view(np.uint32)).all()
-    assert (R.probe(_lib.PROBE_EXPF, k["x_exp"]) == k["expf"].view(np.uint32)).all()
+    # the fixture was produced by glibc in the default MXCSR mode; the reference
+    # executable (and the GPU build) flush results below FLT_MIN to zero
+    ge = R.probe(_lib.PROBE_EXPF, k["x_exp"])
+    norm = np.abs(k["expf"]) >= np.float32(1.17549435e-38)
+    assert norm.sum() > 20000 and (~norm).sum() > 100
+    assert (ge[norm] == k["expf"].view(np.uint32)[norm]).all()
+    assert (ge[~norm] == 0).all()
     # wider sweep against the oracle's restatement (itself pinned to glibc on all floats)
     L = oracle_lib.lib()
     rng = np.random.default_rng(2)

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Render a few frames through the C ABI; the program to put after `--` in
+rocprofv3 runs (kernel-trace or --pmc passes).
+    python3 tools/prof_frame.py [W H [frames [level [blur]]]]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import pwnfps_amd  # noqa: E402
+
+w = int(sys.argv[1]) if len(sys.argv) > 1 else 3840
+h = int(sys.argv[2]) if len(sys.argv) > 2 else 2160
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+level = sys.argv[4] if len(sys.argv) > 4 else "pwnfps_level"
+blur = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+gold = os.path.join(ROOT, "tests", "golden")
+r = pwnfps_amd.Renderer(w, h)
+r.level_load(os.path.join(gold, "levels", level + ".txt"))
+sph = np.load(os.path.join(gold, "spheres_t0.npy" if level == "pwnfps_level" else os.path.join("levels", level + "_spheres.npy")))
+r.set_objects(sph)
+r.set_blur_passes(blur)
+_, _, spawn = r.get_level()
+cam = pwnfps_amd.spawn_camera(spawn)
+if level != "pwnfps_level":
+    cam = np.load(os.path.join(gold, "levels", level + "_cams.npy"))[0]
+sb = np.empty((h, w), np.uint32)
+for _ in range(frames):
+    r.trace_screen_centred(cam, 0.0, want_z=False, sbuf=sb)
+st = r.stats()
+print("trace_ms %.4f blur_ms %.4f total_ms %.4f" % (st["trace_ms"], st["blur_ms"], st["total_ms"]))
