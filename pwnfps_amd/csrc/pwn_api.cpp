@@ -26,6 +26,7 @@ struct pwn_blur_params
 };
 
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
+extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w);
 extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
 extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
@@ -187,7 +188,12 @@ static int pack_blob(pwn_ctx *c)
 	if(total > PWN_BLOB_MAX) return PWN_ETOOBIG;
 	c->blob.assign(total, 0);
 	uint8_t *b = c->blob.data();
-	memcpy(b + PWN_T_CELLS, c->cells, 4096);
+	uint32_t *ci = (uint32_t *)(b + PWN_T_CELLINFO);
+	for(int i = 0; i < 4096; i++)
+	{
+		uint32_t cnt = (uint32_t)(c->bin_off[i + 1] - c->bin_off[i]);
+		ci[i] = (uint32_t)c->cells[i] | ((cnt > 255u ? 255u : cnt) << 8) | ((uint32_t)c->bin_off[i] << 16);
+	}
 	memcpy(b + PWN_T_RCP, pwn_host_rcp_tab, 4096);
 	memcpy(b + PWN_T_RSQ, pwn_host_rsqrt_tab, 4096);
 	uint32_t *pm = (uint32_t *)(b + PWN_T_PMAP);
@@ -343,10 +349,13 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	P.sbuf = d_sbuf; P.zbuf = d_zbuf;
 	P.blob = (const uint32_t *)c->d_blob;
 	P.counters = c->d_counters;
+	// ordinary cameras (rows x,y,z with w = 0, position w = 1: mat4_iden + rotations,
+	// main.c:61-64) never put anything but 0 / 1 into the w lanes; the kernel has a
+	// 3-lane specialisation for them that is arithmetically identical
+	P.has_w = !(cam[3] == 0.0f && cam[7] == 0.0f && cam[11] == 0.0f && cam[15] == 1.0f);
 	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
-	// persistent grid: a few workgroups per CU, each striding over tiles
-	int per_cu = (int)((160u * 1024u) / (P.blob_bytes + 1024u));
-	if(per_cu > 8) per_cu = 8;
+	// persistent grid: as many workgroups as are resident at once, each striding over tiles
+	int per_cu = pwn_trace_blocks_per_cu(P.blob_bytes, c->counters_on != 0, P.has_w != 0);
 	if(per_cu < 1) per_cu = 1;
 	int grid = c->num_cus * per_cu;
 	if(grid > P.tiles_total) grid = P.tiles_total;

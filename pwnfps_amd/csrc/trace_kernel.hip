@@ -3,16 +3,23 @@
 // Replaces trace_ray_prelude (screen.h:1-28) + trace_ray / trace_ray_through /
 // trace_hit_wall / trace_hit_bounce (trace.h) of the reference.
 //
-// Shape: persistent 256-thread workgroups (4 wave64).  Each workgroup copies
-// the level blob (cells, rcp/rsqrt tables, portals, per-cell sphere lists,
-// spheres: tables.h) HBM -> LDS once, then walks 32x8-pixel tiles of its row
-// strip, one thread per pixel.  The reference's recursion (depth <= REFLECT)
-// is a loop over at most three ray segments with the composites of
-// trace.h:91-101 applied on unwinding.  Output: BGRA8 colour + fp32 depth,
-// row-major, one 4-byte store each per pixel.
+// Shape: persistent 256-thread workgroups (4 wave64), exactly as many as are
+// resident at once.  Each workgroup copies the level blob (per-cell word,
+// rcp/rsqrt tables, portals, per-cell sphere lists, spheres: tables.h)
+// HBM -> LDS once, then walks 32x8-pixel tiles of its row strip, one thread
+// per pixel.  The reference's recursion (depth <= REFLECT) is a loop over at
+// most three ray segments; the composites of trace.h:91-101 are applied on
+// unwinding.  Output: BGRA8 colour + fp32 depth, row-major, 4-byte stores.
 //
 // No MFMA: this is a branchy DDA, not a contraction.  HBM traffic is the two
 // output planes only (8 B / pixel); everything the inner loop reads is in LDS.
+// The kernel is VALU-issue / latency bound, so the code is organised for a
+// small live register set (occupancy) and few scalar branch sequences:
+//   - one walk loop with a single exit (no per-exit struct copies),
+//   - the 1-high and 2-high room cases share one body,
+//   - one LDS word per step gives cell type + sphere count + list offset,
+//   - cameras without w components (the usual case) take a 3-lane path that
+//     is arithmetically identical to the 4-lane SSE code (see HAS_W below).
 #include <hip/hip_runtime.h>
 #include "dev_math.h"
 #include "tables.h"
@@ -24,399 +31,433 @@ enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
 
 #define TILE_W 32
 #define TILE_H 8
-#define WAVE_W 16                 // a wave64 covers WAVE_W x (64/WAVE_W) pixels
+#ifndef PWN_WAVE_W
+#define PWN_WAVE_W 16             // a wave64 covers PWN_WAVE_W x (64/PWN_WAVE_W) pixels
+#endif
+
+// min waves per SIMD the register allocator must leave room for (Makefile MINW)
+#ifndef PWN_MIN_WAVES
+#define PWN_MIN_WAVES 3
+#endif
 
 struct Lds
 {
-	const uint8_t *cells;
+	const uint32_t *cellinfo;
 	const uint16_t *rcp, *rsq;
 	const uint32_t *pmap;
 	const uint16_t *binoff, *binidx;
 	const float *sph;
 };
 
-__device__ __forceinline__ int cell_at(const Lds &L, int cx, int cz)
+// util.h:151-158 (per-axis clamp to 0) -> the packed cell word
+__device__ __forceinline__ uint32_t cellword_at(const Lds &L, int cx, int cz)
 {
-	// util.h:151-158: per-axis clamp to 0
-	if(cx < 0 || cx >= 64) cx = 0;
-	if(cz < 0 || cz >= 64) cz = 0;
-	return L.cells[cz * 64 + cx];
+	cx = ((unsigned)cx < 64u) ? cx : 0;
+	cz = ((unsigned)cz < 64u) ? cz : 0;
+	return L.cellinfo[cz * 64 + cx];
+}
+
+// HAS_W = false: the camera rows x,y,z carry w = 0 and the position w = 1
+// (mat4_iden + rotations, main.c:61-64).  Then every ray has w = +-0 and every
+// position w = 1, sphere-relative vectors have w = 0, and each 4-lane dot
+// (x+z)+(y+w) of util.h:18-30 equals (x+z)+y bit for bit (a product of zeros
+// adds +0; the only sign-of-zero effect is on a dot that is itself +-0, which
+// the code only compares with 0 or squares).  The w lanes are dropped.
+template<bool HAS_W> struct Vec { float x, y, z, w; };
+
+template<bool W> __device__ __forceinline__ float dot3(const Vec<W> &a, const Vec<W> &b)
+{
+	if constexpr(W) return (a.x * b.x + a.z * b.z) + (a.y * b.y + a.w * b.w);
+	else return (a.x * b.x + a.z * b.z) + a.y * b.y;
+}
+template<bool W> __device__ __forceinline__ Vec<W> vscale(float s, const Vec<W> &a)
+{
+	Vec<W> r; r.x = s * a.x; r.y = s * a.y; r.z = s * a.z;
+	if constexpr(W) r.w = s * a.w; else r.w = 0.0f;
+	return r;
+}
+template<bool W> __device__ __forceinline__ Vec<W> vadd(const Vec<W> &a, const Vec<W> &b)
+{
+	Vec<W> r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z;
+	if constexpr(W) r.w = a.w + b.w; else r.w = 0.0f;
+	return r;
+}
+template<bool W> __device__ __forceinline__ Vec<W> vsub(const Vec<W> &a, const Vec<W> &b)
+{
+	Vec<W> r; r.x = a.x - b.x; r.y = a.y - b.y; r.z = a.z - b.z;
+	if constexpr(W) r.w = a.w - b.w; else r.w = 0.0f;
+	return r;
+}
+// util.h:32-46
+template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const uint16_t *rsq, const Vec<W> &a)
+{
+	return vscale<W>(tab_rsqrt(rsq, dot3<W>(a, a)), a);
 }
 
 enum { EV_EXHAUSTED = 0, EV_WALL, EV_SPHERE };
-
-struct Hit
-{
-	int ev, ldir;
-	v4 ray, pos, norm, col;
-	float refl, fog, dist;
-};
+enum { BASE_CEIL = 0, BASE_FLOOR, BASE_WALL, BASE_MAGENTA };
 
 struct Counters { uint32_t rays, steps, portals, tests, exhausted; };
 
-template<bool COUNT>
-__device__ __forceinline__ void walk(const Lds &L, v4 from, v4 iray, Hit &h, Counters &cnt)
+// One pixel = trace_ray(0, ...) of screen.h:22-24 with the recursion unrolled.
+template<bool COUNT, bool HAS_W>
+__device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uint32_t seed,
+	Vec<HAS_W> from, Vec<HAS_W> iray, float &out_x, float &out_y, float &out_z, float &out_w,
+	float &dist, bool &have_dist, Counters &cnt)
 {
-	float cdist = 0.0f, fog = 0.0f, fogbeg = 0.0f;
-	float aux_dist = -1.0f, aux_refl = 0.25f;
-	v4 aux_pos = v4_set(0, 0, 0, 0), aux_norm = v4_set(0, 0, 0, 0), aux_col = v4_set(1, 1, 1, 1);
-	if(COUNT) cnt.rays++;
-
-	// trace.h:212-241
-	v4 pos = from;
-	v4 ray = v4_normalise(L.rsq, iray);
-	int cx = (int)from.x, cz = (int)from.z;
-	if(ray.x > -EPS && ray.x < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
-	if(ray.y > -EPS && ray.y < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
-	if(ray.z > -EPS && ray.z < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
-	int gx = (iray.x < 0.0f ? -1 : 1);
-	int gy = (iray.y < 0.0f ? -1 : 1);
-	int gz = (iray.z < 0.0f ? -1 : 1);
-	float iax = tab_rcp(L.rcp, fabsf(ray.x));
-	float iay = tab_rcp(L.rcp, fabsf(ray.y));
-	float iaz = tab_rcp(L.rcp, fabsf(ray.z));
-	float wx = pos.x - (float)cx, wy = pos.y, wz = pos.z - (float)cz;
-	if(ray.x >= 0.0f) wx = 1.0f - wx;
-	if(ray.y >= 0.0f) wy = 1.0f - wy;
-	if(ray.z >= 0.0f) wz = 1.0f - wz;
-	wx *= iax; wy *= iay; wz *= iaz;
-
-	int cell = cell_at(L, cx, cz);
-	int ldir = FYN;
-
-#define AUX_HIT() (aux_dist != -1.0f && cdist > aux_dist)
-#define RET_SPHERE() do { h.ev = EV_SPHERE; h.ray = ray; h.pos = aux_pos; h.norm = aux_norm; \
-	h.ldir = -1; h.refl = aux_refl; h.fog = fog; h.dist = aux_dist; h.col = aux_col; return; } while(0)
-#define RET_WALL(c) do { h.ev = EV_WALL; h.ray = ray; h.pos = pos; h.ldir = ldir; \
-	h.fog = fog; h.dist = cdist; h.col = (c); return; } while(0)
-// trace.h:156-184
-#define THROUGH(gxa) do { float t_; \
-	if(wy < wx && wy < wz) { t_ = wy; ldir = (gy < 0 ? FYN : FYP); } \
-	else if(wx < wz) { t_ = wx; ldir = ((gxa) < 0 ? FXN : FXP); } \
-	else { t_ = wz; ldir = (gz < 0 ? FZN : FZP); } \
-	cdist += t_; pos = v4_add(v4_scale(t_, ray), pos); } while(0)
-// fog sums below are written in the reference build's operation order:
-// (fog - fogbeg) + cdist and (fog + aux_dist) - fogbeg
-// trace.h:331-340
-#define ADVANCE_XZ() do { \
-	if(ldir == FXN || ldir == FXP) { wy -= wx; wz -= wx; wx = iax; cx += gx; } \
-	else { wx -= wz; wy -= wz; wz = iaz; cz += gz; } } while(0)
-#define COL_CEIL  v4_set(30.0f, 30.0f, 0.0f, 0.0f)
-#define COL_FLOOR v4_set(1.0f, 1.0f, 1.0f, 0.0f)
-#define COL_WALL  v4_set(0.8f, 0.8f, 1.0f, 0.0f)
-
-	for(int maxsteps = 1000; maxsteps > 0; maxsteps--)
-	{
-		if(COUNT) cnt.steps++;
-
-		// trace.h:252-296: spheres binned to this cell
-		if((unsigned)cx < 64u && (unsigned)cz < 64u)
-		{
-			int c = cz * 64 + cx;
-			int k1 = L.binoff[c + 1];
-			for(int k = L.binoff[c]; k < k1; k++)
-			{
-				const float *sp = L.sph + 8 * (int)L.binidx[k];
-				if(COUNT) cnt.tests++;
-				float sr = sp[0];
-				v4 spos = v4_set(sp[2], sp[3], sp[4], 1.0f);
-				float rad2 = sr * sr;
-				v4 rel = v4_sub(spos, pos);
-				float d2 = v4_dot(rel, rel);
-				float dt = v4_dot(rel, ray);
-				if(dt > 0.0f)
-				{
-					float calc = d2 - dt * dt;
-					if(calc < rad2)
-					{
-						float sd2 = 1.0f - calc / rad2;
-						float sdist = sqrtf(d2) - sqrtf(sd2);
-						if(aux_dist == -1.0f || sdist + cdist < aux_dist)
-						{
-							aux_dist = sdist + cdist;
-							aux_pos = v4_add(pos, v4_scale(sdist, ray));
-							aux_norm = v4_normalise(L.rsq, v4_sub(aux_pos, spos));
-							float diff = -v4_dot(ray, aux_norm);
-							if(diff < 0.0f) diff = 0.0f;
-							const float amb = 0.2f;
-							aux_refl = sp[1];
-							diff = amb + (1.0f - amb) * diff;
-							aux_col = v4_scale(diff, v4_set(sp[5], sp[6], sp[7], 0.0f));
-						}
-					}
-				}
-			}
-		}
-
-		int this_cell = cell;
-		if(this_cell == ';' || this_cell == '$' || this_cell == '"')
-		{
-			// trace.h:302-352: 1-high room
-			if(this_cell == '$') fogbeg = cdist;
-			THROUGH(gx);
-			if(AUX_HIT())
-			{
-				if(this_cell == '$' && aux_dist > fogbeg) fog = (fog + aux_dist) - fogbeg;
-				RET_SPHERE();
-			}
-			if(this_cell == '$') fog = (fog - fogbeg) + cdist;
-			if(ldir == FYN || ldir == FYP) RET_WALL(gy > 0 ? COL_CEIL : COL_FLOOR);
-			ADVANCE_XZ();
-			cell = cell_at(L, cx, cz);
-			if(this_cell == '"' && (cell == '#' || cell == '&'))
-			{
-				pos.y += 1.0f;
-				if(gy < 0) wy += iay; else wy -= iay;
-			}
-		}
-		else if(this_cell == '#' || this_cell == '&')
-		{
-			// trace.h:354-441: 2-high room
-			if(gy > 0) wy += iay;
-			if(this_cell == '&') fogbeg = cdist;
-			THROUGH(gx);
-			if(AUX_HIT())
-			{
-				if(this_cell == '&' && aux_dist > fogbeg) fog = (fog + aux_dist) - fogbeg;
-				RET_SPHERE();
-			}
-			if(this_cell == '&') fog = (fog - fogbeg) + cdist;
-			if(ldir == FYN || ldir == FYP) RET_WALL(gy > 0 ? COL_CEIL : COL_FLOOR);
-			ADVANCE_XZ();
-			if(gy > 0) wy -= iay;
-			cell = cell_at(L, cx, cz);
-			if(cell == '"')
-			{
-				pos.y -= 1.0f;
-				if(gy > 0) wy += iay; else wy -= iay;
-			}
-			int xcell = cell;
-			if(xcell >= 'A' && xcell <= 'Z')
-			{
-				// trace.h:404-413: look through a portal at the cell type behind it
-				uint32_t p0 = L.pmap[2 * (xcell - 'A')], p1 = L.pmap[2 * (xcell - 'A') + 1];
-				int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
-				int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
-				if(x1 == cx && z1 == cz) xcell = (int)((p1 >> 16) & 0xff);
-				else if(x2 == cx && z2 == cz) xcell = (int)((p1 >> 8) & 0xff);
-			}
-			if(pos.y < 0.0f || pos.y > 1.0f)
-			{
-				if(!(xcell == '#' || xcell == '&'))
-				{
-					if(xcell == '"')
-					{
-						pos.y += 1.0f;
-						if(gy > 0) wy -= iay; else wy += iay;
-					}
-					RET_WALL(COL_WALL);
-				}
-			}
-		}
-		else if(this_cell == '>' || this_cell == '<' || this_cell == ',' || this_cell == '^')
-		{
-			// trace.h:443-505: ramps
-			const float ramp = 0.5f;
-			float tilt = (this_cell == '>' || this_cell == '<') ? ray.x : ray.z;
-			bool minus = (this_cell == '>' || this_cell == ',');
-			if(minus) ray.y -= ramp * tilt; else ray.y += ramp * tilt;
-			wy = pos.y;
-			if(ray.y >= 0.0f) wy = 1.0f - wy;
-			wy *= 1.0f / (ray.y < 0.0f ? -ray.y : ray.y);
-			if(AUX_HIT()) RET_SPHERE();
-			THROUGH(gy); // sic: trace.h:470 passes gy for gx
-			if(ldir == FYN || ldir == FYP)
-			{
-				ldir = (ray.y < 0.0f ? FYN : FYP);
-				RET_WALL(ray.y >= 0.0f ? COL_CEIL : COL_FLOOR);
-			}
-			else if(ldir == FXN || ldir == FXP)
-			{
-				ldir = (ray.x < 0.0f ? FXN : FXP);
-				wy -= wx; wz -= wx; wx = iax; cx += gx;
-			}
-			else
-			{
-				ldir = (ray.z < 0.0f ? FZN : FZP);
-				wx -= wz; wy -= wz; wz = iaz; cz += gz;
-			}
-			tilt = (this_cell == '>' || this_cell == '<') ? ray.x : ray.z;
-			if(minus) ray.y += ramp * tilt; else ray.y -= ramp * tilt;
-			wy = pos.y;
-			if(ray.y >= 0.0f) wy = 1.0f - wy;
-			wy *= iay;
-			cell = cell_at(L, cx, cz);
-		}
-		else if(this_cell >= 'A' && this_cell <= 'Z')
-		{
-			// trace.h:508-650: portal
-			uint32_t p0 = L.pmap[2 * (this_cell - 'A')], p1 = L.pmap[2 * (this_cell - 'A') + 1];
-			int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
-			int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
-			int rot12 = (int)(p1 & 0xff);
-			int rot;
-			if(x2 == -1)
-			{
-				if(AUX_HIT()) RET_SPHERE();
-				RET_WALL(COL_WALL);
-			}
-			if(x1 == cx && z1 == cz)
-			{
-				cx = x2; cz = z2;
-				pos.x += (float)(x2 - x1);
-				pos.z += (float)(z2 - z1);
-				rot = (-rot12) & 3;
-			}
-			else if(x2 == cx && z2 == cz)
-			{
-				cx = x1; cz = z1;
-				pos.x -= (float)(x2 - x1);
-				pos.z -= (float)(z2 - z1);
-				rot = rot12 & 3;
-			}
-			else
-			{
-				if(AUX_HIT()) RET_SPHERE();
-				RET_WALL(v4_set(5.0f, 0.0f, 5.0f, 0.0f));
-			}
-			if(COUNT) cnt.portals++;
-
-			// trace.h:561-622.  The operation order is the one the reference
-			// build executes (its -ffast-math cancels the +-0.5 terms).
-			float trx = pos.x, trz = pos.z, trvx = ray.x, trvz = ray.z;
-			int tgx = gx, tgz = gz;
-			float fcx = (float)cx, fcz = (float)cz, t;
-			ldir = (ldir - rot) & 3;
-			if(rot == 1)
-			{
-				pos.x = (trz + fcx) - fcz;
-				pos.z = (1.0f - trx) + (fcx + fcz);
-				ray.x = trvz; ray.z = -trvx;
-				gx = tgz; gz = -tgx;
-				t = wx; wx = wz; wz = t;
-				t = iax; iax = iaz; iaz = t;
-			}
-			else if(rot == 2)
-			{
-				pos.x = (fcx + 0.5f) * 2.0f - trx;
-				pos.z = (fcz + 0.5f) * 2.0f - trz;
-				ray.x = -trvx; ray.z = -trvz;
-				gx = -tgx; gz = -tgz;
-			}
-			else if(rot == 3)
-			{
-				pos.x = (1.0f - trz) + (fcx + fcz);
-				pos.z = (fcz + trx) - fcx;
-				ray.x = -trvz; ray.z = trvx;
-				gx = -tgz; gz = tgx;
-				t = wx; wx = wz; wz = t;
-				t = iax; iax = iaz; iaz = t;
-			}
-			// trace.h:624-647: step out of the far endpoint
-			if(ldir == FZP) { cz++; pos.z += 1.0f; }
-			else if(ldir == FXN) { cx--; pos.x -= 1.0f; }
-			else if(ldir == FZN) { cz--; pos.z -= 1.0f; }
-			else { cx++; pos.x += 1.0f; }
-			cell = cell_at(L, cx, cz);
-		}
-		else
-		{
-			// trace.h:651-664: solid
-			if(AUX_HIT()) RET_SPHERE();
-			RET_WALL(ldir == FYP ? COL_CEIL : COL_WALL);
-		}
-
-		// trace.h:668-673
-		if(AUX_HIT()) RET_SPHERE();
-	}
-
-	// trace.h:677-678: out of steps -- the walked ray is the colour
-	if(COUNT) cnt.exhausted++;
-	h.ev = EV_EXHAUSTED;
-	h.ray = ray;
-#undef AUX_HIT
-#undef RET_SPHERE
-#undef RET_WALL
-#undef THROUGH
-#undef ADVANCE_XZ
-}
-
-// trace_ray(0, ...) of screen.h:22-24 with the recursion unrolled
-template<bool COUNT>
-__device__ __forceinline__ v4 trace_pixel(const Lds &L, float sec_current, uint32_t seed,
-	v4 from, v4 iray, float &dist, bool &have_dist, Counters &cnt)
-{
-	v4 icol = v4_set(1.0f, 1.0f, 1.0f, 1.0f);
-	float st_refl[REFLECT_MAX], st_fog[REFLECT_MAX];
-	v4 st_col[REFLECT_MAX];
+	typedef Vec<HAS_W> V;
+	float icx = 1.0f, icy = 1.0f, icz = 1.0f, icw = 1.0f;     // icol (screen.h:24)
+	float st_refl0 = 0.0f, st_refl1 = 0.0f, st_fog0 = 0.0f, st_fog1 = 0.0f;
+	float sc0x = 0.0f, sc0y = 0.0f, sc0z = 0.0f, sc0w = 0.0f;
+	float sc1x = 0.0f, sc1y = 0.0f, sc1z = 0.0f, sc1w = 0.0f;
 	int depth = 0;
-	v4 value;
+	float vx, vy, vz, vw;
 	have_dist = false;
 
 #pragma unroll 1
 	for(;;)
 	{
-		Hit h;
-		h.norm = v4_set(0, 0, 0, 0);
-		walk<COUNT>(L, from, iray, h, cnt);
-		if(h.ev == EV_EXHAUSTED) { value = h.ray; break; }
-		if(depth == 0) { dist = h.dist; have_dist = true; }
+		// ------------------------------------------------ trace.h:186-248
+		float cdist = 0.0f, fog = 0.0f, fogbeg = 0.0f;
+		float aux_dist = -1.0f, aux_refl = 0.25f;
+		V aux_pos, aux_norm;
+		aux_pos.x = aux_pos.y = aux_pos.z = aux_pos.w = 0.0f;
+		aux_norm = aux_pos;
+		float acx = 1.0f, acy = 1.0f, acz = 1.0f;
+		if(COUNT) cnt.rays++;
 
-		v4 col;
-		float refl;
-		if(h.ev == EV_WALL)
+		V pos = from;
+		V ray = vnormalise<HAS_W>(L.rsq, iray);
+		int cx = (int)from.x, cz = (int)from.z;
+		if(ray.x > -EPS && ray.x < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
+		if(ray.y > -EPS && ray.y < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
+		if(ray.z > -EPS && ray.z < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
+		// signs of the UN-normalised input (trace.h:225-227)
+		int gx = (iray.x < 0.0f ? -1 : 1);
+		int gy = (iray.y < 0.0f ? -1 : 1);
+		int gz = (iray.z < 0.0f ? -1 : 1);
+		float iax = tab_rcp(L.rcp, fabsf(ray.x));
+		float iay = tab_rcp(L.rcp, fabsf(ray.y));
+		float iaz = tab_rcp(L.rcp, fabsf(ray.z));
+		float wx = pos.x - (float)cx, wy = pos.y, wz = pos.z - (float)cz;
+		if(ray.x >= 0.0f) wx = 1.0f - wx;
+		if(ray.y >= 0.0f) wy = 1.0f - wy;
+		if(ray.z >= 0.0f) wz = 1.0f - wz;
+		wx *= iax; wy *= iay; wz *= iaz;
+
+		uint32_t cw = cellword_at(L, cx, cz);
+		int ldir = FYN;
+		int ev = EV_EXHAUSTED, base = BASE_WALL;
+
+#define AUX_HIT() (aux_dist != -1.0f && cdist > aux_dist)
+// trace.h:156-184
+#define THROUGH(gxa) do { float t_; \
+	if(wy < wx && wy < wz) { t_ = wy; ldir = (gy < 0 ? FYN : FYP); } \
+	else if(wx < wz) { t_ = wx; ldir = ((gxa) < 0 ? FXN : FXP); } \
+	else { t_ = wz; ldir = (gz < 0 ? FZN : FZP); } \
+	cdist += t_; pos = vadd<HAS_W>(vscale<HAS_W>(t_, ray), pos); } while(0)
+// trace.h:331-340
+#define ADVANCE_XZ() do { \
+	if(ldir == FXN || ldir == FXP) { wy -= wx; wz -= wx; wx = iax; cx += gx; } \
+	else { wx -= wz; wy -= wz; wz = iaz; cz += gz; } } while(0)
+
+		// ------------------------------------------------ trace.h:250-675
+#pragma unroll 1
+		for(int maxsteps = 1000; maxsteps > 0; maxsteps--)
+		{
+			if(COUNT) cnt.steps++;
+			const int cell = (int)(cw & 0xffu);
+
+			// trace.h:252-296: spheres binned to this cell (only real cells hold any)
+			int nsp = (int)((cw >> 8) & 0xffu);
+			if(nsp != 0 && (unsigned)cx < 64u && (unsigned)cz < 64u)
+			{
+				int k = (int)(cw >> 16);
+				if(nsp == 255) nsp = (int)L.binoff[cz * 64 + cx + 1] - k;
+				for(int k1 = k + nsp; k < k1; k++)
+				{
+					const float4 *sp = (const float4 *)(L.sph + 8 * (int)L.binidx[k]);
+					const float4 s0 = sp[0];         // r, refl, x, y
+					const float4 s1 = sp[1];         // z, cb, cg, cr
+					if(COUNT) cnt.tests++;
+					V rel;
+					rel.x = s0.z - pos.x; rel.y = s0.w - pos.y; rel.z = s1.x - pos.z;
+					if constexpr(HAS_W) rel.w = 1.0f - pos.w; else rel.w = 0.0f;
+					float rad2 = s0.x * s0.x;
+					float d2 = dot3<HAS_W>(rel, rel);
+					float dt = dot3<HAS_W>(rel, ray);
+					if(dt > 0.0f)
+					{
+						float calc = d2 - dt * dt;
+						if(calc < rad2)
+						{
+							float sd2 = 1.0f - calc / rad2;
+							float sdist = sqrtf(d2) - sqrtf(sd2);
+							if(aux_dist == -1.0f || sdist + cdist < aux_dist)
+							{
+								aux_dist = sdist + cdist;
+								aux_pos = vadd<HAS_W>(pos, vscale<HAS_W>(sdist, ray));
+								V d;
+								d.x = aux_pos.x - s0.z; d.y = aux_pos.y - s0.w; d.z = aux_pos.z - s1.x;
+								if constexpr(HAS_W) d.w = aux_pos.w - 1.0f; else d.w = 0.0f;
+								aux_norm = vnormalise<HAS_W>(L.rsq, d);
+								float diff = -dot3<HAS_W>(ray, aux_norm);
+								if(diff < 0.0f) diff = 0.0f;
+								const float amb = 0.2f;
+								aux_refl = s0.y;
+								diff = amb + (1.0f - amb) * diff;
+								acx = diff * s1.y; acy = diff * s1.z; acz = diff * s1.w;
+							}
+						}
+					}
+				}
+			}
+
+			const bool room1 = (cell == ';' || cell == '$' || cell == '"');
+			const bool room2 = (cell == '#' || cell == '&');
+			if(room1 || room2)
+			{
+				// trace.h:302-352 (1-high) and 354-441 (2-high) share this body
+				const bool foggy = (cell == '$' || cell == '&');
+				if(room2 && gy > 0) wy += iay;
+				if(foggy) fogbeg = cdist;
+				THROUGH(gx);
+				if(AUX_HIT())
+				{
+					// fog sums in the reference build's operation order
+					if(foggy && aux_dist > fogbeg) fog = (fog + aux_dist) - fogbeg;
+					ev = EV_SPHERE; break;
+				}
+				if(foggy) fog = (fog - fogbeg) + cdist;
+				if(ldir == FYN || ldir == FYP) { ev = EV_WALL; base = (gy > 0 ? BASE_CEIL : BASE_FLOOR); break; }
+				ADVANCE_XZ();
+				if(room2 && gy > 0) wy -= iay;
+				cw = cellword_at(L, cx, cz);
+				const int ncell = (int)(cw & 0xffu);
+				if(room1)
+				{
+					if(cell == '"' && (ncell == '#' || ncell == '&'))
+					{
+						pos.y += 1.0f;
+						if(gy < 0) wy += iay; else wy -= iay;
+					}
+				}
+				else
+				{
+					if(ncell == '"')
+					{
+						pos.y -= 1.0f;
+						if(gy > 0) wy += iay; else wy -= iay;
+					}
+					if(pos.y < 0.0f || pos.y > 1.0f)
+					{
+						// trace.h:404-413: look through a portal at the cell type behind it
+						int xcell = ncell;
+						if(xcell >= 'A' && xcell <= 'Z')
+						{
+							uint32_t p0 = L.pmap[2 * (xcell - 'A')], p1 = L.pmap[2 * (xcell - 'A') + 1];
+							int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
+							int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
+							if(x1 == cx && z1 == cz) xcell = (int)((p1 >> 16) & 0xff);
+							else if(x2 == cx && z2 == cz) xcell = (int)((p1 >> 8) & 0xff);
+						}
+						if(!(xcell == '#' || xcell == '&'))
+						{
+							if(xcell == '"')
+							{
+								pos.y += 1.0f;
+								if(gy > 0) wy -= iay; else wy += iay;
+							}
+							ev = EV_WALL; base = BASE_WALL; break;
+						}
+					}
+				}
+			}
+			else if(cell == '>' || cell == '<' || cell == ',' || cell == '^')
+			{
+				// trace.h:443-505: ramps
+				const float ramp = 0.5f;
+				const bool alongx = (cell == '>' || cell == '<');
+				const bool minus = (cell == '>' || cell == ',');
+				float tilt = alongx ? ray.x : ray.z;
+				if(minus) ray.y -= ramp * tilt; else ray.y += ramp * tilt;
+				wy = pos.y;
+				if(ray.y >= 0.0f) wy = 1.0f - wy;
+				wy *= 1.0f / (ray.y < 0.0f ? -ray.y : ray.y);
+				if(AUX_HIT()) { ev = EV_SPHERE; break; }
+				THROUGH(gy); // sic: trace.h:470 passes gy for gx
+				if(ldir == FYN || ldir == FYP)
+				{
+					ldir = (ray.y < 0.0f ? FYN : FYP);
+					ev = EV_WALL; base = (ray.y >= 0.0f ? BASE_CEIL : BASE_FLOOR); break;
+				}
+				else if(ldir == FXN || ldir == FXP)
+				{
+					ldir = (ray.x < 0.0f ? FXN : FXP);
+					wy -= wx; wz -= wx; wx = iax; cx += gx;
+				}
+				else
+				{
+					ldir = (ray.z < 0.0f ? FZN : FZP);
+					wx -= wz; wy -= wz; wz = iaz; cz += gz;
+				}
+				tilt = alongx ? ray.x : ray.z;
+				if(minus) ray.y += ramp * tilt; else ray.y -= ramp * tilt;
+				wy = pos.y;
+				if(ray.y >= 0.0f) wy = 1.0f - wy;
+				wy *= iay;
+				cw = cellword_at(L, cx, cz);
+			}
+			else if(cell >= 'A' && cell <= 'Z')
+			{
+				// trace.h:508-650: portal
+				uint32_t p0 = L.pmap[2 * (cell - 'A')], p1 = L.pmap[2 * (cell - 'A') + 1];
+				int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
+				int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
+				int rot12 = (int)(p1 & 0xff);
+				int rot;
+				if(x2 == -1)
+				{
+					if(AUX_HIT()) { ev = EV_SPHERE; break; }
+					ev = EV_WALL; base = BASE_WALL; break;
+				}
+				if(x1 == cx && z1 == cz)
+				{
+					cx = x2; cz = z2;
+					pos.x += (float)(x2 - x1);
+					pos.z += (float)(z2 - z1);
+					rot = (-rot12) & 3;
+				}
+				else if(x2 == cx && z2 == cz)
+				{
+					cx = x1; cz = z1;
+					pos.x -= (float)(x2 - x1);
+					pos.z -= (float)(z2 - z1);
+					rot = rot12 & 3;
+				}
+				else
+				{
+					if(AUX_HIT()) { ev = EV_SPHERE; break; }
+					ev = EV_WALL; base = BASE_MAGENTA; break;
+				}
+				if(COUNT) cnt.portals++;
+
+				// trace.h:561-622.  The operation order is the one the reference
+				// build executes (its -ffast-math cancels the +-0.5 terms).
+				const float trx = pos.x, trz = pos.z, trvx = ray.x, trvz = ray.z;
+				const int tgx = gx, tgz = gz;
+				const float fcx = (float)cx, fcz = (float)cz;
+				ldir = (ldir - rot) & 3;
+				if(rot & 1)
+				{
+					float t = wx; wx = wz; wz = t;
+					t = iax; iax = iaz; iaz = t;
+					if(rot == 1)
+					{
+						pos.x = (trz + fcx) - fcz;
+						pos.z = (1.0f - trx) + (fcx + fcz);
+						ray.x = trvz; ray.z = -trvx;
+						gx = tgz; gz = -tgx;
+					}
+					else
+					{
+						pos.x = (1.0f - trz) + (fcx + fcz);
+						pos.z = (fcz + trx) - fcx;
+						ray.x = -trvz; ray.z = trvx;
+						gx = -tgz; gz = tgx;
+					}
+				}
+				else if(rot == 2)
+				{
+					pos.x = (fcx + 0.5f) * 2.0f - trx;
+					pos.z = (fcz + 0.5f) * 2.0f - trz;
+					ray.x = -trvx; ray.z = -trvz;
+					gx = -tgx; gz = -tgz;
+				}
+				// trace.h:624-647: step out of the far endpoint
+				if(ldir == FZP) { cz++; pos.z += 1.0f; }
+				else if(ldir == FXN) { cx--; pos.x -= 1.0f; }
+				else if(ldir == FZN) { cz--; pos.z -= 1.0f; }
+				else { cx++; pos.x += 1.0f; }
+				cw = cellword_at(L, cx, cz);
+			}
+			else
+			{
+				// trace.h:651-664: solid
+				if(AUX_HIT()) { ev = EV_SPHERE; break; }
+				ev = EV_WALL; base = (ldir == FYP ? BASE_CEIL : BASE_WALL); break;
+			}
+
+			// trace.h:668-673
+			if(AUX_HIT()) { ev = EV_SPHERE; break; }
+		}
+#undef AUX_HIT
+#undef THROUGH
+#undef ADVANCE_XZ
+
+		if(ev == EV_EXHAUSTED)
+		{
+			// trace.h:677-678: out of steps -- the walked ray is the colour
+			if(COUNT) cnt.exhausted++;
+			vx = ray.x; vy = ray.y; vz = ray.z; vw = HAS_W ? ray.w : 0.0f;
+			break;
+		}
+		if(depth == 0) { dist = (ev == EV_SPHERE ? aux_dist : cdist); have_dist = true; }
+
+		float colx, coly, colz, colw, refl;
+		if(ev == EV_WALL)
 		{
 			// trace.h:108-154
+			float bx, by, bz;
+			if(base == BASE_CEIL) { bx = 30.0f; by = 30.0f; bz = 0.0f; }
+			else if(base == BASE_FLOOR) { bx = 1.0f; by = 1.0f; bz = 1.0f; }
+			else if(base == BASE_WALL) { bx = 0.8f; by = 0.8f; bz = 1.0f; }
+			else { bx = 5.0f; by = 0.0f; bz = 5.0f; }
 			float diffuse;
-			col = v4_mul(icol, h.col);
-			switch(h.ldir)
-			{
-				case FYP: diffuse = h.ray.y; break;
-				case FZP: diffuse = h.ray.z; break;
-				case FXN: diffuse = -h.ray.x; break;
-				case FYN: diffuse = -h.ray.y; break;
-				case FZN: diffuse = -h.ray.z; break;
-				default:  diffuse = h.ray.x; break;
-			}
+			if(ldir >= FYP) diffuse = ray.y; else diffuse = (ldir & 1) ? ray.z : ray.x;
+			if(ldir == FXN || ldir == FZN || ldir == FYN) diffuse = -diffuse;
 			if(diffuse < 0.0f) diffuse = 0.0f;
 			const float amb = 0.1f;
 			diffuse = (1.0f - amb) * diffuse + amb;
-			col = v4_scale(diffuse, col);
-			refl = (h.ldir == FYN ? 0.7f : 0.25f);
+			colx = diffuse * (icx * bx); coly = diffuse * (icy * by); colz = diffuse * (icz * bz);
+			colw = diffuse * (icw * 0.0f);
+			refl = (ldir == FYN ? 0.7f : 0.25f);
 		}
 		else
 		{
-			col = h.col;
-			refl = h.refl;
+			colx = acx; coly = acy; colz = acz;
+			colw = 0.0f;                                   // diff * sph.col.a with a == 0 (script.h:30-32), diff >= 0.2
+			refl = aux_refl;
+			ldir = -1;
+			pos = aux_pos;
 		}
 
 		// trace.h:3-7
-		if(depth >= REFLECT_MAX || refl == 0.0f) { value = col; break; }
+		if(depth >= REFLECT_MAX || refl == 0.0f) { vx = colx; vy = coly; vz = colz; vw = colw; break; }
 
 		// trace.h:9-75
-		v4 ray = h.ray, pos = h.pos;
-		if(h.ldir == FYN)
+		if(ldir == FYN)
 		{
 			pos.y -= 0.001f;
 			const float pi = (float)3.14159265358979323846;
 			float ang = (pi * 2.0f) * (
 				(glibc_sincosf((pi * 0.5f) * pos.x, 0) + glibc_sincosf((pi * 0.5f) * pos.z, 1))
 				+ sec_current);
-			v4 norm = v4_normalise(L.rsq, v4_set(glibc_sincosf(ang, 0), 38.0f, glibc_sincosf(ang, 1), 0.0f));
-			float rmul = -2.0f * ((ray.x * norm.x + ray.y * norm.y) + ray.z * norm.z);
-			ray = v4_normalise(L.rsq, v4_add(v4_scale(rmul, norm), ray));
+			V n; n.x = glibc_sincosf(ang, 0); n.y = 38.0f; n.z = glibc_sincosf(ang, 1); n.w = 0.0f;
+			n = vnormalise<HAS_W>(L.rsq, n);
+			float rmul = -2.0f * ((ray.x * n.x + ray.y * n.y) + ray.z * n.z);
+			ray = vnormalise<HAS_W>(L.rsq, vadd<HAS_W>(vscale<HAS_W>(rmul, n), ray));
 		}
-		else if(h.ldir < 0)
+		else if(ldir < 0)
 		{
-			pos = v4_sub(pos, v4_scale(0.001f, ray));
-			v4 norm = h.norm;
-			float rmul = -2.0f * ((ray.x * norm.x + ray.y * norm.y) + ray.z * norm.z);
-			ray = v4_normalise(L.rsq, v4_add(v4_scale(rmul, norm), ray));
+			pos = vsub<HAS_W>(pos, vscale<HAS_W>(0.001f, ray));
+			float rmul = -2.0f * ((ray.x * aux_norm.x + ray.y * aux_norm.y) + ray.z * aux_norm.z);
+			ray = vnormalise<HAS_W>(L.rsq, vadd<HAS_W>(vscale<HAS_W>(rmul, aux_norm), ray));
 		}
-		else if(h.ldir == FXP) { ray.x = -ray.x; pos.x -= 0.001f; }
-		else if(h.ldir == FXN) { ray.x = -ray.x; pos.x += 0.001f; }
-		else if(h.ldir == FZP) { ray.z = -ray.z; pos.z -= 0.001f; }
-		else if(h.ldir == FZN) { ray.z = -ray.z; pos.z += 0.001f; }
+		else if(ldir == FXP) { ray.x = -ray.x; pos.x -= 0.001f; }
+		else if(ldir == FXN) { ray.x = -ray.x; pos.x += 0.001f; }
+		else if(ldir == FZP) { ray.z = -ray.z; pos.z -= 0.001f; }
+		else if(ldir == FZN) { ray.z = -ray.z; pos.z += 0.001f; }
 		else { ray.y = -ray.y; pos.y -= 0.001f; }
 
 		// trace.h:77-84: five draws, two discarded
@@ -426,34 +467,40 @@ __device__ __forceinline__ v4 trace_pixel(const Lds &L, float sec_current, uint3
 		ray.z += lcg_fs(seed) * REFLECT_BLUR_F;
 		lcg_next(seed);
 
-		st_refl[depth] = refl; st_fog[depth] = h.fog; st_col[depth] = col;
+		if(depth == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; sc0w = colw; }
+		else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; sc1w = colw; }
 		depth++;
-		icol = col;
+		icx = colx; icy = coly; icz = colz; icw = colw;
 		from = pos;
 		iray = ray;
 	}
 
 	// trace.h:91-101, innermost first
-#pragma unroll
-	for(int d = REFLECT_MAX - 1; d >= 0; d--)
+	if(depth >= 2)
 	{
-		if(d < depth)
+		const float r1 = st_refl1, q1 = 1.0f - st_refl1;
+		vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw + q1 * sc1w;
+		if(st_fog1 != 0.0f)
 		{
-			float refl = st_refl[d];
-			value = v4_add(v4_scale(refl, value), v4_scale(1.0f - refl, st_col[d]));
-			if(st_fog[d] != 0.0f)
-			{
-				float f = glibc_expf(-0.6f * st_fog[d]);
-				float g = 1.0f - f;
-				value = v4_add(v4_scale(f, value), v4_set(g, g, g, g));
-			}
+			float f = glibc_expf(-0.6f * st_fog1), g = 1.0f - f;
+			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 		}
 	}
-	return value;
+	if(depth >= 1)
+	{
+		const float r0 = st_refl0, q0 = 1.0f - st_refl0;
+		vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw + q0 * sc0w;
+		if(st_fog0 != 0.0f)
+		{
+			float f = glibc_expf(-0.6f * st_fog0), g = 1.0f - f;
+			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
+		}
+	}
+	out_x = vx; out_y = vy; out_z = vz; out_w = vw;
 }
 
-template<bool COUNT>
-__global__ void __launch_bounds__(256)
+template<bool COUNT, bool HAS_W>
+__global__ void __launch_bounds__(256, PWN_MIN_WAVES)
 pwn_trace_kernel(pwn_trace_params P)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -468,7 +515,7 @@ pwn_trace_kernel(pwn_trace_params P)
 	__syncthreads();
 
 	Lds L;
-	L.cells = lds_raw + PWN_T_CELLS;
+	L.cellinfo = (const uint32_t *)(lds_raw + PWN_T_CELLINFO);
 	L.rcp = (const uint16_t *)(lds_raw + PWN_T_RCP);
 	L.rsq = (const uint16_t *)(lds_raw + PWN_T_RSQ);
 	L.pmap = (const uint32_t *)(lds_raw + PWN_T_PMAP);
@@ -476,16 +523,18 @@ pwn_trace_kernel(pwn_trace_params P)
 	L.binidx = (const uint16_t *)(lds_raw + PWN_T_BINIDX);
 	L.sph = (const float *)(lds_raw + P.off_sph);
 
-	const v4 rayb = v4_set(P.rayb[0], P.rayb[1], P.rayb[2], P.rayb[3]);
-	const v4 rdx = v4_set(P.rdx[0], P.rdx[1], P.rdx[2], P.rdx[3]);
-	const v4 rdy = v4_set(P.rdy[0], P.rdy[1], P.rdy[2], P.rdy[3]);
-	const v4 from = v4_set(P.from[0], P.from[1], P.from[2], P.from[3]);
+	typedef Vec<HAS_W> V;
+	V rayb, rdx, rdy, from;
+	rayb.x = P.rayb[0]; rayb.y = P.rayb[1]; rayb.z = P.rayb[2]; rayb.w = HAS_W ? P.rayb[3] : 0.0f;
+	rdx.x = P.rdx[0]; rdx.y = P.rdx[1]; rdx.z = P.rdx[2]; rdx.w = HAS_W ? P.rdx[3] : 0.0f;
+	rdy.x = P.rdy[0]; rdy.y = P.rdy[1]; rdy.z = P.rdy[2]; rdy.w = HAS_W ? P.rdy[3] : 0.0f;
+	from.x = P.from[0]; from.y = P.from[1]; from.z = P.from[2]; from.w = HAS_W ? P.from[3] : 1.0f;
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	// wave footprint WAVE_W x (64/WAVE_W); waves tile the 32x8 block
-	const int waves_x = TILE_W / WAVE_W;
-	const int lx = (wave % waves_x) * WAVE_W + (lane % WAVE_W);
-	const int ly = (wave / waves_x) * (64 / WAVE_W) + (lane / WAVE_W);
+	// wave footprint PWN_WAVE_W x (64/PWN_WAVE_W); the 4 waves tile the 32x8 block
+	const int waves_x = TILE_W / PWN_WAVE_W;
+	const int lx = (wave % waves_x) * PWN_WAVE_W + (lane % PWN_WAVE_W);
+	const int ly = (wave / waves_x) * (64 / PWN_WAVE_W) + (lane / PWN_WAVE_W);
 
 	Counters cnt = { 0, 0, 0, 0, 0 };
 
@@ -499,19 +548,19 @@ pwn_trace_kernel(pwn_trace_params P)
 			// screen.h:12-18, in the order the reference build evaluates it:
 			// rayl = (cx*rdx + rayb) + y*rdy, then one "+= rdx" per pixel of
 			// the 32-wide tile up to and including this one
-			v4 rayl = v4_add(v4_add(v4_scale((float)cx0, rdx), rayb), v4_scale((float)y, rdy));
-			for(int k = 0; k <= lx; k++) rayl = v4_add(rayl, rdx);
+			V rayl = vadd<HAS_W>(vadd<HAS_W>(vscale<HAS_W>((float)cx0, rdx), rayb), vscale<HAS_W>((float)y, rdy));
+			for(int k = 0; k <= lx; k++) rayl = vadd<HAS_W>(rayl, rdx);
 
 			// screen.h:19-21 (uint32 wrap-around)
 			uint32_t seed = (uint32_t)x + (uint32_t)y * (uint32_t)y * ((uint32_t)P.w + 1u);
 			seed *= seed * seed;
 			seed *= seed * seed;
 
-			float dist = 0.0f;
+			float dist = 0.0f, ox, oy, oz, ow;
 			bool have_dist;
-			v4 c = trace_pixel<COUNT>(L, P.sec_current, seed, from, rayl, dist, have_dist, cnt);
+			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, dist, have_dist, cnt);
 			size_t o = (size_t)y * (size_t)P.w + (size_t)x;
-			P.sbuf[o] = col_pack(c);
+			P.sbuf[o] = ftoint_lane(ox) | (ftoint_lane(oy) << 8) | (ftoint_lane(oz) << 16) | (ftoint_lane(ow) << 24);
 			if(have_dist) P.zbuf[o] = dist;
 		}
 	}
@@ -529,19 +578,31 @@ pwn_trace_kernel(pwn_trace_params P)
 	}
 }
 
+template<bool COUNT, bool HAS_W>
+static hipError_t launch_variant(const pwn_trace_params *P, int grid, size_t lds_bytes, hipStream_t stream)
+{
+	hipError_t e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W>,
+		hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+	if(e != hipSuccess) return e;
+	hipLaunchKernelGGL((pwn_trace_kernel<COUNT, HAS_W>), dim3(grid), dim3(256), lds_bytes, stream, *P);
+	return hipGetLastError();
+}
+
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream)
 {
-	if(count)
-	{
-		hipError_t e = hipFuncSetAttribute((const void *)pwn_trace_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-		if(e != hipSuccess) return e;
-		hipLaunchKernelGGL(pwn_trace_kernel<true>, dim3(grid), dim3(256), lds_bytes, stream, *P);
-	}
-	else
-	{
-		hipError_t e = hipFuncSetAttribute((const void *)pwn_trace_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-		if(e != hipSuccess) return e;
-		hipLaunchKernelGGL(pwn_trace_kernel<false>, dim3(grid), dim3(256), lds_bytes, stream, *P);
-	}
-	return hipGetLastError();
+	if(count) return P->has_w ? launch_variant<true, true>(P, grid, lds_bytes, stream) : launch_variant<true, false>(P, grid, lds_bytes, stream);
+	return P->has_w ? launch_variant<false, true>(P, grid, lds_bytes, stream) : launch_variant<false, false>(P, grid, lds_bytes, stream);
+}
+
+// resident 256-thread workgroups per CU for this variant and LDS size
+extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w)
+{
+	int n = 0;
+	hipError_t e;
+	if(count) e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, true>, 256, lds_bytes)
+	                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, false>, 256, lds_bytes);
+	else e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, true>, 256, lds_bytes)
+	               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, false>, 256, lds_bytes);
+	if(e != hipSuccess || n < 1) n = 2;
+	return n;
 }
