@@ -1,0 +1,202 @@
+/*
+ * pwnhost.c -- a plain-C host over libpwnhip.so, shaped like the reference's
+ * frame loop (main.c:93-109): prepare objects, trace_screen_centred,
+ * screen_upscale, present.  It is the drop-in demonstration of
+ * include/pwnhip.h: no HIP, no C++ and no Python on this side of the ABI.
+ *
+ * SDL and Lua are not in this image, so "present" writes the upscaled
+ * surface as a binary PPM (the role of SDL_Flip, main.c:109) and the
+ * objects come from a text file instead of game.lua's obj_set calls
+ * (script.h:10-40): one sphere per line,
+ *     r refl x y z  b g r
+ * which are obj_set's "sphere" arguments in its own order.
+ *
+ *   pwnhost level.txt [-s spheres.txt] [-w W] [-h H] [-x SCALE] [-n FRAMES]
+ *           [-a TURN_PER_FRAME] [-p PITCH] [-b BLUR_PASSES] [-o out.ppm] [-d DEVICE]
+ *
+ * Build: make -C host      (gcc only; links libpwnhip.so by path)
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#include <math.h>
+#include <time.h>
+
+#include "pwnhip.h"
+
+/* the globals a reference host owns (main.c:26-34) */
+static int rwidth = 320, rheight = 200, rscale = 3;
+static uint32_t *sbuf = NULL;
+static float *zbuf = NULL;
+static float sec_current = 0.0f;
+static struct { int pitch; uint32_t *pixels; } surface;
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* util.h:61-71 / 91-110: camera = identity turned about y */
+static void cam_identity(float cam[16])
+{
+	memset(cam, 0, 16 * sizeof(float));
+	cam[0] = cam[5] = cam[10] = cam[15] = 1.0f;
+}
+
+static void cam_roty(float cam[16], float ang)
+{
+	float vs = sinf(ang), vc = cosf(ang);
+	float vxx = cam[0], vxz = cam[2], vzx = cam[8], vzz = cam[10];
+	cam[0] = vc * vxx + vs * vxz;
+	cam[2] = vc * vxz - vs * vxx;
+	cam[8] = vc * vzx + vs * vzz;
+	cam[10] = vc * vzz - vs * vzx;
+}
+
+static int load_spheres(const char *path, pwn_sphere **out)
+{
+	FILE *fp = fopen(path, "r");
+	if(fp == NULL) return -1;
+	int n = 0, cap = 16;
+	pwn_sphere *s = malloc(sizeof(*s) * (size_t)cap);
+	char line[512];
+	while(s != NULL && fgets(line, sizeof(line), fp) != NULL)
+	{
+		pwn_sphere t;
+		if(line[0] == '#') continue;
+		if(sscanf(line, "%f %f %f %f %f %f %f %f", &t.r, &t.refl, &t.x, &t.y, &t.z, &t.cb, &t.cg, &t.cr) != 8) continue;
+		if(n == cap) { cap *= 2; s = realloc(s, sizeof(*s) * (size_t)cap); if(s == NULL) break; }
+		s[n++] = t;
+	}
+	fclose(fp);
+	*out = s;
+	return s == NULL ? -1 : n;
+}
+
+static int write_ppm(const char *path, const uint32_t *px, int w, int h, int pitch_words)
+{
+	FILE *fp = fopen(path, "wb");
+	if(fp == NULL) return -1;
+	fprintf(fp, "P6\n%d %d\n255\n", w, h);
+	unsigned char *row = malloc((size_t)w * 3);
+	for(int y = 0; y < h && row != NULL; y++)
+	{
+		for(int x = 0; x < w; x++)
+		{
+			uint32_t p = px[(size_t)y * (size_t)pitch_words + (size_t)x];   /* BGRA8 (util.h:48-59) */
+			row[3 * x + 0] = (unsigned char)(p >> 16);
+			row[3 * x + 1] = (unsigned char)(p >> 8);
+			row[3 * x + 2] = (unsigned char)p;
+		}
+		fwrite(row, 3, (size_t)w, fp);
+	}
+	free(row);
+	fclose(fp);
+	return 0;
+}
+
+static uint64_t fnv64(const uint32_t *p, size_t n)
+{
+	uint64_t h = 1469598103934665603ULL;
+	for(size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ULL; }
+	return h;
+}
+
+#define CHK(call) do { int rc_ = (call); if(rc_ != PWN_OK) { \
+	fprintf(stderr, "%s -> %s (%d): %s\n", #call, pwn_strerror(rc_), rc_, pwn_last_error(ctx)); \
+	pwn_destroy(ctx); return 1; } } while(0)
+
+int main(int argc, char **argv)
+{
+	const char *level = NULL, *sphfile = NULL, *out = NULL;
+	int frames = 1, device = 0, blur = 1, pitch = 0;
+	float turn = 0.0f;
+	for(int i = 1; i < argc; i++)
+	{
+		if(argv[i][0] != '-') { level = argv[i]; continue; }
+		if(i + 1 >= argc) { fprintf(stderr, "option %s needs a value\n", argv[i]); return 2; }
+		switch(argv[i][1])
+		{
+			case 's': sphfile = argv[++i]; break;
+			case 'w': rwidth = atoi(argv[++i]); break;
+			case 'h': rheight = atoi(argv[++i]); break;
+			case 'x': rscale = atoi(argv[++i]); break;
+			case 'n': frames = atoi(argv[++i]); break;
+			case 'a': turn = (float)atof(argv[++i]); break;
+			case 'p': pitch = atoi(argv[++i]); break;
+			case 'b': blur = atoi(argv[++i]); break;
+			case 'o': out = argv[++i]; break;
+			case 'd': device = atoi(argv[++i]); break;
+			default: fprintf(stderr, "unknown option %s\n", argv[i]); return 2;
+		}
+	}
+	if(level == NULL)
+	{
+		fprintf(stderr, "usage: pwnhost level.txt [-s spheres.txt] [-w W] [-h H] [-x SCALE] [-n FRAMES] "
+			"[-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE]\n");
+		return 2;
+	}
+	if(rscale < 1) rscale = 1;
+	if(pitch == 0) pitch = rwidth * rscale * 4;
+
+	/* main.c:395-400 */
+	size_t npix = (size_t)rwidth * (size_t)rheight;
+	sbuf = malloc(npix * 4);
+	zbuf = malloc(npix * 4);
+	surface.pitch = pitch;
+	surface.pixels = calloc((size_t)pitch * (size_t)rheight * (size_t)rscale, 1);
+	if(sbuf == NULL || zbuf == NULL || surface.pixels == NULL) { fprintf(stderr, "out of memory\n"); return 1; }
+
+	pwn_ctx *ctx = NULL;
+	int rc = pwn_init(&ctx, device, rwidth, rheight);
+	if(rc != PWN_OK) { fprintf(stderr, "pwn_init: %s (%d)\n", pwn_strerror(rc), rc); return 1; }
+	CHK(pwn_set_option(ctx, PWN_OPT_BLUR_PASSES, blur));
+
+	/* main.c:51-64 */
+	CHK(pwn_level_load(ctx, level));
+	int32_t spawn[2];
+	CHK(pwn_get_level(ctx, NULL, NULL, spawn));
+	printf("spawn: %d %d\n", spawn[0], spawn[1]);
+	pwn_sphere *sph = NULL;
+	int nsph = 0;
+	if(sphfile != NULL && (nsph = load_spheres(sphfile, &sph)) < 0) { fprintf(stderr, "cannot read %s\n", sphfile); pwn_destroy(ctx); return 1; }
+
+	float ang = 0.0f;
+	double t_first = 0.0, t_rest = 0.0;
+	for(int f = 0; f < frames; f++)
+	{
+		float cam[16];
+		cam_identity(cam);
+		if(ang != 0.0f) cam_roty(cam, ang);
+		cam[12] = 0.5f + (float)spawn[0]; cam[13] = 0.5f; cam[14] = 0.5f + (float)spawn[1];
+
+		double t0 = now_s();
+		CHK(pwn_upload_spheres(ctx, sph, nsph));                                /* level_prepare_render, main.c:95 */
+		CHK(pwn_trace_screen_centred(ctx, cam, sec_current, sbuf, zbuf));       /* main.c:107 */
+		CHK(pwn_screen_upscale(ctx, NULL, rscale, surface.pitch, surface.pixels)); /* main.c:108 */
+		double dt = now_s() - t0;
+		if(f == 0) t_first = dt; else t_rest += dt;
+
+		sec_current += (float)dt;                                                /* main.c:112-114 */
+		ang += turn;
+	}
+
+	pwn_stats st;
+	CHK(pwn_get_stats(ctx, &st));
+	printf("frame %dx%d x%d: sbuf fnv64 %016llx, surface fnv64 %016llx\n", rwidth, rheight, rscale,
+		(unsigned long long)fnv64(sbuf, npix),
+		(unsigned long long)fnv64(surface.pixels, (size_t)(pitch / 4) * (size_t)rheight * (size_t)rscale));
+	printf("last frame on the device: trace %.3f ms, blur %.3f ms, with D2H %.3f ms\n", st.trace_ms, st.blur_ms, st.total_ms);
+	if(frames > 1)
+		printf("host loop incl. upload, D2H and sink: %.2f Mpixels/s over %d frames (first frame %.1f ms)\n",
+			(double)npix * (frames - 1) / t_rest / 1e6, frames - 1, t_first * 1e3);
+	if(out != NULL && write_ppm(out, surface.pixels, rwidth * rscale, rheight * rscale, pitch / 4) != 0)
+		fprintf(stderr, "cannot write %s\n", out);
+
+	pwn_destroy(ctx);
+	free(sph); free(sbuf); free(zbuf); free(surface.pixels);
+	return 0;
+}

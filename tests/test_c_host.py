@@ -1,0 +1,69 @@
+"""The plain-C host (host/pwnhost.c) over the C ABI: the reference's frame loop
+(main.c:93-109) with libpwnhip.so in place of trace_screen_centred /
+screen_upscale.  CPU: it builds with gcc alone and reports errors like the
+ABI says.  GPU: its frame is the compiled reference's golden frame."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, level_path
+
+HOST = os.path.join(ROOT, "host", "pwnhost")
+
+
+@pytest.fixture(scope="module")
+def host_bin():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "pwnfps_amd", "csrc")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
+    return HOST
+
+
+def test_host_builds_with_gcc_only_and_links_the_abi(host_bin):
+    out = subprocess.check_output(["nm", "-D", "--undefined-only", host_bin]).decode()
+    used = set(re.findall(r"U (pwn_\w+)", out))
+    assert {"pwn_init", "pwn_level_load", "pwn_upload_spheres", "pwn_trace_screen_centred",
+            "pwn_screen_upscale", "pwn_destroy"} <= used
+    # nothing but the C ABI, libc and libm: no HIP / C++ symbols on the host side
+    assert not re.search(r"U (hip|_Z)", out)
+
+
+def test_host_usage_and_bad_option(host_bin):
+    p = subprocess.run([host_bin], capture_output=True)
+    assert p.returncode == 2 and b"usage" in p.stderr
+    p = subprocess.run([host_bin, level_path("pwnfps_level"), "-q", "1"], capture_output=True)
+    assert p.returncode == 2
+
+
+@pytest.mark.gpu
+def test_host_frame_is_the_reference_frame(host_bin, cases, tmp_path, oracle_lib):
+    # the reference's shipped configuration: 320x200, x3 upscale (defs.h:11-15)
+    want = [c for c in cases if c["name"] == "level_spawn_320x200"][0]
+    ppm = str(tmp_path / "f.ppm")
+    p = subprocess.run([host_bin, level_path("pwnfps_level"), "-s", os.path.join(GOLD, "spheres_t0.txt"),
+                        "-w", "320", "-h", "200", "-x", "3", "-o", ppm], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    out = p.stdout.decode()
+    assert "spawn: 9 4" in out
+    m = re.search(r"sbuf fnv64 ([0-9a-f]{16}), surface fnv64 ([0-9a-f]{16})", out)
+    assert m and m.group(1) == want["post"]
+    # the surface is the oracle's screen_upscale of that frame, and the PPM holds it
+    from oracle import Oracle
+    O = Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    O.set_spheres(np.load(os.path.join(GOLD, "spheres_t0.npy")))
+    sb, _ = O.render(320, 200, np.array(want["cam"], np.float32), sec=0.0, blur=1)
+    up = O.upscale(sb, 3)
+    assert oracle_lib.fnv64(up) == m.group(2)
+    raw = open(ppm, "rb").read()
+    assert raw.startswith(b"P6\n960 600\n255\n")
+    rgb = np.frombuffer(raw[len(b"P6\n960 600\n255\n"):], np.uint8).reshape(600, 960, 3)
+    assert (rgb[..., 0] == ((up >> 16) & 255)).all() and (rgb[..., 2] == (up & 255)).all()
+
+
+@pytest.mark.gpu
+def test_host_missing_level_reports_eio(host_bin):
+    p = subprocess.run([host_bin, "/nonexistent/level.txt"], capture_output=True, timeout=120)
+    assert p.returncode == 1 and b"level file could not be read" in p.stderr
