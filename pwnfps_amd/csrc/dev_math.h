@@ -28,43 +28,64 @@ __device__ __forceinline__ float v4_dot(v4 a, v4 b)
 }
 
 // ---- RCPPS / RSQRTPS emulation; tab points into LDS -----------------------
-// entry: bit 12 = exponent offset, bits 11..0 = mantissa bits 22..11
-__device__ __forceinline__ float tab_rcp(const uint16_t *tab, float x)
+// Both are pure table functions on the reference host:
+//   rcp:   index = mantissa bits 22..12;  result = 2^(253-e+flag) * 1.m12
+//   rsqrt: index = (e odd ? 1024 : 0) + mantissa bits 22..13 (i.e. bits 23..13
+//          of the input as they lie);     result = 2^(190-h+flag) * 1.m12,
+//          h = (e+1)>>1
+// The LDS tables hold the result for e = 0 (rcp) / h = 0 (rsqrt) as a ready
+// fp32 bit pattern, built by pack_blob() from approx_tables.inc:
+//   rcp_tab[i]   = (254 - off_i) << 23 | m12_i << 11
+//   rsqrt_tab[j] = (191 - off_j) << 23 | m12_j << 11
+// so that a positive normal input costs an index, one ds_read_b32 and a
+// subtract in the exponent field.  Everything else takes the general path.
+__device__ __forceinline__ float tab_rcp(const uint32_t *tab, float x)
 {
 	uint32_t b = __float_as_uint(x);
-	uint32_t sign = b & 0x80000000u, e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
+	uint32_t sign = b & 0x80000000u, a = b & 0x7fffffffu;
 	uint32_t r;
-	if(e == 0u) r = sign | 0x7f800000u;
-	else if(e == 255u) r = m ? (b | 0x00400000u) : sign;
+	if(a - 0x00800000u < 0x7e000000u)          // 1 <= e <= 252: result is a normal number
+		r = sign | (tab[(a >> 12) & 2047u] - (a & 0x7f800000u));
 	else
 	{
-		uint32_t t = tab[m >> 12];
-		int re = 254 - (int)e - (int)(t >> 12);
-		r = re <= 0 ? sign : (sign | ((uint32_t)re << 23) | ((t & 0xfffu) << 11));
+		uint32_t e = a >> 23, m = a & 0x7fffffu;
+		if(e == 0u) r = sign | 0x7f800000u;      // zero / denormal (DAZ) -> inf
+		else if(e == 255u) r = m ? (b | 0x00400000u) : sign;
+		else
+		{
+			// e = 253, 254: the result is denormal (flushed) unless the entry's exponent allows it
+			uint32_t t = tab[(a >> 12) & 2047u];
+			int re = (int)(t >> 23) - (int)e;
+			r = re <= 0 ? sign : (sign | (t - (e << 23)));
+		}
+	}
+	return __uint_as_float(r);
+}
+// x >= EPSILON is known (ray components after the clamp of trace.h:220-222)
+__device__ __forceinline__ float tab_rcp_pos(const uint32_t *tab, float x)
+{
+	uint32_t a = __float_as_uint(x);
+	return __uint_as_float(tab[(a >> 12) & 2047u] - (a & 0x7f800000u));
+}
+
+__device__ __forceinline__ float tab_rsqrt(const uint32_t *tab, float x)
+{
+	uint32_t b = __float_as_uint(x);
+	uint32_t r;
+	if(b - 0x00800000u < 0x7f000000u)          // positive normal
+		r = tab[(b >> 13) & 2047u] - (((b + 0x00800000u) >> 1) & 0x7f800000u);
+	else
+	{
+		uint32_t sign = b & 0x80000000u, e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
+		if(e == 255u && m) r = b | 0x00400000u;
+		else if(e == 0u) r = sign | 0x7f800000u;
+		else if(sign) r = 0xffc00000u;
+		else r = 0u;                               // +inf
 	}
 	return __uint_as_float(r);
 }
 
-__device__ __forceinline__ float tab_rsqrt(const uint16_t *tab, float x)
-{
-	uint32_t b = __float_as_uint(x);
-	uint32_t sign = b & 0x80000000u, e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
-	uint32_t r;
-	if(e == 255u && m) r = b | 0x00400000u;
-	else if(e == 0u) r = sign | 0x7f800000u;
-	else if(sign) r = 0xffc00000u;
-	else if(e == 255u) r = 0u;
-	else
-	{
-		int E = (int)e - 127, par = E & 1;
-		uint32_t t = tab[(par << 10) | (m >> 13)];
-		int re = 127 - (int)(t >> 12) - ((E - par) >> 1);
-		r = ((uint32_t)re << 23) | ((t & 0xfffu) << 11);
-	}
-	return __uint_as_float(r);
-}
-
-__device__ __forceinline__ v4 v4_normalise(const uint16_t *rsq, v4 a)
+__device__ __forceinline__ v4 v4_normalise(const uint32_t *rsq, v4 a)
 {
 	return v4_scale(tab_rsqrt(rsq, v4_dot(a, a)), a);
 }

@@ -107,15 +107,15 @@ extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int
 
 // --------------------------------------------------------------- probes ----
 // Device-side known-answer access to the arithmetic primitives (pwnhip.h
-// PWN_PROBE_*).  tabs = the rcp+rsqrt part of the blob.
-__global__ void pwn_probe_kernel(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs)
+// PWN_PROBE_*).  tabs = the rcp+rsqrt part of the blob (2 x 2048 u32).
+__global__ void pwn_probe_kernel(int op, const uint32_t *in, uint32_t *out, int n, const uint32_t *tabs)
 {
-	__shared__ uint16_t t[4096];
+	__shared__ uint32_t t[4096];
 	for(int i = threadIdx.x; i < 4096; i += blockDim.x) t[i] = tabs[i];
 	__syncthreads();
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if(i >= n) return;
-	const uint16_t *rcp = t, *rsq = t + 2048;
+	const uint32_t *rcp = t, *rsq = t + 2048;
 	switch(op)
 	{
 		case 0: out[i] = __float_as_uint(tab_rcp(rcp, __uint_as_float(in[i]))); break;
@@ -132,7 +132,7 @@ __global__ void pwn_probe_kernel(int op, const uint32_t *in, uint32_t *out, int 
 	}
 }
 
-extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream)
+extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint32_t *tabs, hipStream_t stream)
 {
 	hipLaunchKernelGGL(pwn_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, in, out, n, tabs);
 	return hipGetLastError();

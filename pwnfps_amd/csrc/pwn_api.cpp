@@ -27,9 +27,10 @@ struct pwn_blur_params
 
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
 extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w);
+extern "C" int pwn_trace_tile_h(void);
 extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
-extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
+extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint32_t *tabs, hipStream_t stream);
 
 // LDS budget for the table blob: leave room so that at least two workgroups
 // fit per CU (160 KiB LDS per CU on gfx950)
@@ -180,22 +181,59 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 
 // ---- level / spheres --------------------------------------------------------
 
+// RCPPS / RSQRTPS tables in the form the kernels read (dev_math.h): the result
+// for a zero exponent field as a ready fp32 pattern.  approx_tables.inc entry:
+// bit 12 = exponent offset, bits 11..0 = result mantissa bits 22..11.
+static void expand_tables(uint32_t *rcp, uint32_t *rsq)
+{
+	for(int i = 0; i < 2048; i++)
+	{
+		uint32_t t = pwn_host_rcp_tab[i];
+		rcp[i] = ((254u - (t >> 12)) << 23) | ((t & 0xfffu) << 11);
+		// kernel index = input bits 23..13: bit 10 = low exponent bit; the generated
+		// table is indexed by parity of (e - 127), i.e. with that bit flipped
+		uint32_t u = pwn_host_rsqrt_tab[i ^ 0x400];
+		rsq[i] = ((191u - (u >> 12)) << 23) | ((u & 0xfffu) << 11);
+	}
+}
+
 static int pack_blob(pwn_ctx *c)
 {
-	uint32_t nbin = (uint32_t)c->bin_off[4096], nsph = (uint32_t)c->spheres.size();
-	if(nbin > 65535u || nsph > 65535u) return PWN_ETOOBIG;
+	// per-cell sphere lists, each closed by PWN_LIST_END; only non-empty cells get one
+	uint32_t nsph = (uint32_t)c->spheres.size();
+	uint32_t nbin = 0;
+	for(int i = 0; i < 4096; i++)
+	{
+		uint32_t cnt = (uint32_t)(c->bin_off[i + 1] - c->bin_off[i]);
+		if(cnt) nbin += cnt + 1u;
+	}
+	if(nbin > 32767u || nsph >= PWN_LIST_END) return PWN_ETOOBIG;
 	uint32_t total = (pwn_t_total(nbin, nsph) + 15u) & ~15u;
 	if(total > PWN_BLOB_MAX) return PWN_ETOOBIG;
 	c->blob.assign(total, 0);
 	uint8_t *b = c->blob.data();
 	uint32_t *ci = (uint32_t *)(b + PWN_T_CELLINFO);
-	for(int i = 0; i < 4096; i++)
+	uint16_t *bi = (uint16_t *)(b + PWN_T_BINIDX);
+	uint32_t at = 0;
+	for(int z = 0; z < 64; z++)
+	for(int x = 0; x < 64; x++)
 	{
-		uint32_t cnt = (uint32_t)(c->bin_off[i + 1] - c->bin_off[i]);
-		ci[i] = (uint32_t)c->cells[i] | ((cnt > 255u ? 255u : cnt) << 8) | ((uint32_t)c->bin_off[i] << 16);
+		int i = z * 64 + x;
+		uint32_t word = (uint32_t)c->cells[i] | pwn_cell_class(c->cells[i]);
+		int32_t k0 = c->bin_off[i], k1 = c->bin_off[i + 1];
+		if(k1 > k0)
+		{
+			word |= PWN_C_SPH | (at << 16);
+			for(int32_t k = k0; k < k1; k++) bi[at++] = (uint16_t)c->bin_idx[k];
+			bi[at++] = (uint16_t)PWN_LIST_END;
+		}
+		ci[z * PWN_GRID_PITCH + x] = word;
 	}
-	memcpy(b + PWN_T_RCP, pwn_host_rcp_tab, 4096);
-	memcpy(b + PWN_T_RSQ, pwn_host_rsqrt_tab, 4096);
+	// row / column 64 = what get_cell returns outside the grid on that axis (util.h:151-158),
+	// never with spheres (the sphere loop runs for in-grid cells only, trace.h:252)
+	for(int z = 0; z < 64; z++) ci[z * PWN_GRID_PITCH + 64] = ci[z * PWN_GRID_PITCH] & ~(PWN_C_SPH | 0x7fff0000u);
+	for(int x = 0; x <= 64; x++) ci[64 * PWN_GRID_PITCH + x] = ci[x] & ~(PWN_C_SPH | 0x7fff0000u);
+	expand_tables((uint32_t *)(b + PWN_T_RCP), (uint32_t *)(b + PWN_T_RSQ));
 	uint32_t *pm = (uint32_t *)(b + PWN_T_PMAP);
 	for(int i = 0; i < 26; i++)
 	{
@@ -203,10 +241,6 @@ static int pack_blob(pwn_ctx *c)
 		pm[2 * i] = (uint32_t)(p.x1 & 0xff) | ((uint32_t)(p.z1 & 0xff) << 8) | ((uint32_t)(p.x2 & 0xff) << 16) | ((uint32_t)(p.z2 & 0xff) << 24);
 		pm[2 * i + 1] = (uint32_t)(p.rot12 & 0xff) | ((uint32_t)(p.c1 & 0xff) << 8) | ((uint32_t)(p.c2 & 0xff) << 16);
 	}
-	uint16_t *bo = (uint16_t *)(b + PWN_T_BINOFF);
-	for(int i = 0; i <= 4096; i++) bo[i] = (uint16_t)c->bin_off[i];
-	uint16_t *bi = (uint16_t *)(b + PWN_T_BINIDX);
-	for(uint32_t i = 0; i < nbin; i++) bi[i] = (uint16_t)c->bin_idx[i];
 	c->off_sph = pwn_t_sph_offset(nbin);
 	if(nsph) memcpy(b + c->off_sph, c->spheres.data(), nsph * sizeof(pwn_sphere));
 
@@ -343,7 +377,8 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	P.sec_current = sec;
 	P.w = c->w; P.h = c->h; P.y0 = y0; P.y1 = y1;
 	P.tiles_x = (c->w + 31) / 32;
-	P.tiles_total = P.tiles_x * ((y1 - y0 + 7) / 8);
+	const int th = pwn_trace_tile_h();
+	P.tiles_total = P.tiles_x * ((y1 - y0 + th - 1) / th);
 	P.blob_bytes = (uint32_t)c->blob.size();
 	P.off_sph = c->off_sph;
 	P.sbuf = d_sbuf; P.zbuf = d_zbuf;
@@ -485,13 +520,14 @@ extern "C" int pwn_probe(pwn_ctx *c, int op, const uint32_t *in, uint32_t *out, 
 	(void)hipSetDevice(c->device);
 	size_t per = (op == PWN_PROBE_DIV) ? 2 : (op == PWN_PROBE_FTOINT ? 4 : 1);
 	size_t in_bytes = (size_t)n * per * 4, out_bytes = (size_t)n * 4;
-	int rc = ensure_scratch(c, in_bytes + out_bytes + 8192);
+	int rc = ensure_scratch(c, in_bytes + out_bytes + 16384);
 	if(rc != PWN_OK) return rc;
 	uint8_t *base = (uint8_t *)c->d_scratch;
-	uint16_t *d_tabs = (uint16_t *)base;
-	uint32_t *d_in = (uint32_t *)(base + 8192), *d_out = (uint32_t *)(base + 8192 + in_bytes);
-	HIPCHK(c, hipMemcpyAsync(d_tabs, pwn_host_rcp_tab, 4096, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(c, hipMemcpyAsync(d_tabs + 2048, pwn_host_rsqrt_tab, 4096, hipMemcpyHostToDevice, c->stream));
+	uint32_t *d_tabs = (uint32_t *)base;
+	uint32_t *d_in = (uint32_t *)(base + 16384), *d_out = (uint32_t *)(base + 16384 + in_bytes);
+	std::vector<uint32_t> tabs(4096);
+	expand_tables(tabs.data(), tabs.data() + 2048);
+	HIPCHK(c, hipMemcpy(d_tabs, tabs.data(), 16384, hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, pwn_launch_probe(op, d_in, d_out, n, d_tabs, c->stream));
 	HIPCHK(c, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));

@@ -2,28 +2,50 @@
 // (pwn_api.cpp) and the kernels.  The blob is built once per level / sphere
 // upload, lives in HBM, and is copied verbatim into LDS by every workgroup.
 //
-//   [0      .. 16384)  cellinfo u32 [64][64]      per cell, ONE word for the walk loop:
+//   [0      .. 16912)  cellinfo u32 [65][65]     ONE word per cell for the walk loop.
+//                       Row/column 64 repeat row/column 0 WITHOUT the sphere bit:
+//                       get_cell's per-axis clamp-to-0 (util.h:151-158) becomes
+//                       min(c, 64) and the in-bounds test in front of the sphere
+//                       loop (trace.h:252) is folded into the word.
 //                       bits 0..7   cell type char        level.data   (defs.h:105)
-//                       bits 8..15  min(#spheres, 255)    parts_num    (defs.h:108)
-//                       bits 16..31 first entry in binidx (level.h:64-81 lists as CSR)
-//   [16384  .. 20480)  rcp      u16 [2048]        RCPPS table     (trace.h:231)
-//   [20480  .. 24576)  rsqrt    u16 [2048]        RSQRTPS table   (util.h:43)
-//   [24576  .. 24784)  pmap     2 x u32 [26]      portals         (defs.h:87-94)
+//                       bit  8      PWN_C_ROOM   ; $ "  #  &   (1-high or 2-high room)
+//                       bit  9      PWN_C_ROOM2  # &
+//                       bit  10     PWN_C_FOG    $ &
+//                       bit  11     PWN_C_DQ     "
+//                       bit  12     PWN_C_RAMP   > < , ^
+//                       bit  13     PWN_C_RAMPX  > <            (tilt along x)
+//                       bit  14     PWN_C_RAMPM  > ,            (ray.y -= ramp*tilt)
+//                       bit  15     PWN_C_PORTAL A..Z
+//                       bits 16..30 first entry of this cell's sphere list in binidx
+//                       bit  31     PWN_C_SPH    the cell holds >= 1 sphere
+//   [16912  .. 25104)  rcp      u32 [2048]        RCPPS table     (trace.h:231), see dev_math.h
+//   [25104  .. 33296)  rsqrt    u32 [2048]        RSQRTPS table   (util.h:43)
+//   [33296  .. 33504)  pmap     2 x u32 [26]      portals         (defs.h:87-94)
 //                       word0 = x1 | z1<<8 | x2<<16 | z2<<24   (0xff = -1)
 //                       word1 = rot12 | c1<<8 | c2<<16
-//   [24784  .. 32992)  binoff   u16 [4104]        CSR offsets (only read when a cell
-//                                                 holds >= 255 spheres)
-//   [32992  .. +2*nbin pad 16)  binidx u16        sphere indices, object order
+//   [33504  .. +2*nbin pad 16)  binidx u16        per-cell sphere lists (level.h:64-81),
+//                                                 object order, each list closed by 0xffff
 //   [...    .. +32*nsph)        spheres 8 x f32   r, refl, x, y, z, cb, cg, cr
 #pragma once
 #include <stdint.h>
 
+#define PWN_GRID_PITCH 65u
 #define PWN_T_CELLINFO 0u
-#define PWN_T_RCP      16384u
-#define PWN_T_RSQ      20480u
-#define PWN_T_PMAP     24576u
-#define PWN_T_BINOFF   24784u
-#define PWN_T_BINIDX   32992u
+#define PWN_T_RCP      16912u
+#define PWN_T_RSQ      25104u
+#define PWN_T_PMAP     33296u
+#define PWN_T_BINIDX   33504u
+
+#define PWN_C_ROOM   0x0100u
+#define PWN_C_ROOM2  0x0200u
+#define PWN_C_FOG    0x0400u
+#define PWN_C_DQ     0x0800u
+#define PWN_C_RAMP   0x1000u
+#define PWN_C_RAMPX  0x2000u
+#define PWN_C_RAMPM  0x4000u
+#define PWN_C_PORTAL 0x8000u
+#define PWN_C_SPH    0x80000000u
+#define PWN_LIST_END 0xffffu
 
 static inline uint32_t pwn_t_sph_offset(uint32_t nbin)
 {
@@ -32,6 +54,24 @@ static inline uint32_t pwn_t_sph_offset(uint32_t nbin)
 static inline uint32_t pwn_t_total(uint32_t nbin, uint32_t nsph)
 {
 	return pwn_t_sph_offset(nbin) + nsph * 32u;
+}
+
+// class bits of a cell type (trace.h:300-666 switch labels)
+static inline uint32_t pwn_cell_class(uint32_t c)
+{
+	switch(c)
+	{
+		case ';': return PWN_C_ROOM;
+		case '$': return PWN_C_ROOM | PWN_C_FOG;
+		case '"': return PWN_C_ROOM | PWN_C_DQ;
+		case '#': return PWN_C_ROOM | PWN_C_ROOM2;
+		case '&': return PWN_C_ROOM | PWN_C_ROOM2 | PWN_C_FOG;
+		case '>': return PWN_C_RAMP | PWN_C_RAMPX | PWN_C_RAMPM;
+		case '<': return PWN_C_RAMP | PWN_C_RAMPX;
+		case ',': return PWN_C_RAMP | PWN_C_RAMPM;
+		case '^': return PWN_C_RAMP;
+	}
+	return (c >= 'A' && c <= 'Z') ? PWN_C_PORTAL : 0u;
 }
 
 // kernel arguments of one trace launch (rows [y0,y1) of a w x h frame)

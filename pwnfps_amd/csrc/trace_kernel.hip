@@ -26,11 +26,19 @@
 
 #define EPS 0.0000000000001f      // defs.h:1
 #define REFLECT_BLUR_F 0.03f      // defs.h:5
+#ifdef PWN_DBG_REFLECT            // timing experiments only (changes the pixels)
+#define REFLECT_MAX PWN_DBG_REFLECT
+#else
 #define REFLECT_MAX 2             // defs.h:7
+#endif
 enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
 
+// workgroup = PWN_BLOCK threads = one 32 x (PWN_BLOCK/32) pixel tile
+#ifndef PWN_BLOCK
+#define PWN_BLOCK 256
+#endif
 #define TILE_W 32
-#define TILE_H 8
+#define TILE_H (PWN_BLOCK / 32)
 #ifndef PWN_WAVE_W
 #define PWN_WAVE_W 16             // a wave64 covers PWN_WAVE_W x (64/PWN_WAVE_W) pixels
 #endif
@@ -43,18 +51,18 @@ enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
 struct Lds
 {
 	const uint32_t *cellinfo;
-	const uint16_t *rcp, *rsq;
+	const uint32_t *rcp, *rsq;
 	const uint32_t *pmap;
-	const uint16_t *binoff, *binidx;
+	const uint16_t *binidx;
 	const float *sph;
 };
 
-// util.h:151-158 (per-axis clamp to 0) -> the packed cell word
+// util.h:151-158 (per-axis clamp to 0) -> the packed cell word.  The table has
+// 65 rows / columns; index 64 repeats index 0 (tables.h), so the clamp is a min.
 __device__ __forceinline__ uint32_t cellword_at(const Lds &L, int cx, int cz)
 {
-	cx = ((unsigned)cx < 64u) ? cx : 0;
-	cz = ((unsigned)cz < 64u) ? cz : 0;
-	return L.cellinfo[cz * 64 + cx];
+	uint32_t ux = min((uint32_t)cx, 64u), uz = min((uint32_t)cz, 64u);
+	return L.cellinfo[uz * PWN_GRID_PITCH + ux];
 }
 
 // HAS_W = false: the camera rows x,y,z carry w = 0 and the position w = 1
@@ -89,7 +97,7 @@ template<bool W> __device__ __forceinline__ Vec<W> vsub(const Vec<W> &a, const V
 	return r;
 }
 // util.h:32-46
-template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const uint16_t *rsq, const Vec<W> &a)
+template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const uint32_t *rsq, const Vec<W> &a)
 {
 	return vscale<W>(tab_rsqrt(rsq, dot3<W>(a, a)), a);
 }
@@ -129,21 +137,25 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		V pos = from;
 		V ray = vnormalise<HAS_W>(L.rsq, iray);
 		int cx = (int)from.x, cz = (int)from.z;
-		if(ray.x > -EPS && ray.x < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
-		if(ray.y > -EPS && ray.y < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
-		if(ray.z > -EPS && ray.z < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
+		if(fabsf(ray.x) < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
+		if(fabsf(ray.y) < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
+		if(fabsf(ray.z) < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
 		// signs of the UN-normalised input (trace.h:225-227)
 		int gx = (iray.x < 0.0f ? -1 : 1);
-		int gy = (iray.y < 0.0f ? -1 : 1);
 		int gz = (iray.z < 0.0f ? -1 : 1);
+		const bool gyp = !(iray.y < 0.0f);          // gy > 0
 		float iax = tab_rcp(L.rcp, fabsf(ray.x));
-		float iay = tab_rcp(L.rcp, fabsf(ray.y));
+		const float iay = tab_rcp(L.rcp, fabsf(ray.y));
 		float iaz = tab_rcp(L.rcp, fabsf(ray.z));
 		float wx = pos.x - (float)cx, wy = pos.y, wz = pos.z - (float)cz;
 		if(ray.x >= 0.0f) wx = 1.0f - wx;
 		if(ray.y >= 0.0f) wy = 1.0f - wy;
 		if(ray.z >= 0.0f) wz = 1.0f - wz;
 		wx *= iax; wy *= iay; wz *= iaz;
+		// the "-part of a two-level room shifts the floor by one: wy moves by -+iay
+		// (trace.h:345-349,381-385); iay_dn is the amount added when stepping DOWN into it
+		const float iay_dn = gyp ? iay : -iay;
+		const int ldy = gyp ? FYP : FYN;
 
 		uint32_t cw = cellword_at(L, cx, cz);
 		int ldir = FYN;
@@ -152,31 +164,26 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #define AUX_HIT() (aux_dist != -1.0f && cdist > aux_dist)
 // trace.h:156-184
 #define THROUGH(gxa) do { float t_; \
-	if(wy < wx && wy < wz) { t_ = wy; ldir = (gy < 0 ? FYN : FYP); } \
+	if(wy < wx && wy < wz) { t_ = wy; ldir = ldy; } \
 	else if(wx < wz) { t_ = wx; ldir = ((gxa) < 0 ? FXN : FXP); } \
 	else { t_ = wz; ldir = (gz < 0 ? FZN : FZP); } \
 	cdist += t_; pos = vadd<HAS_W>(vscale<HAS_W>(t_, ray), pos); } while(0)
-// trace.h:331-340
-#define ADVANCE_XZ() do { \
-	if(ldir == FXN || ldir == FXP) { wy -= wx; wz -= wx; wx = iax; cx += gx; } \
-	else { wx -= wz; wy -= wz; wz = iaz; cz += gz; } } while(0)
 
 		// ------------------------------------------------ trace.h:250-675
+		// One cell per iteration.  The cell class is a bit test on the LDS word
+		// (tables.h), so the four bodies below are entered by one compare each.
 #pragma unroll 1
 		for(int maxsteps = 1000; maxsteps > 0; maxsteps--)
 		{
 			if(COUNT) cnt.steps++;
-			const int cell = (int)(cw & 0xffu);
 
-			// trace.h:252-296: spheres binned to this cell (only real cells hold any)
-			int nsp = (int)((cw >> 8) & 0xffu);
-			if(nsp != 0 && (unsigned)cx < 64u && (unsigned)cz < 64u)
+			// trace.h:252-296: spheres binned to this cell
+			if((int)cw < 0)
 			{
-				int k = (int)(cw >> 16);
-				if(nsp == 255) nsp = (int)L.binoff[cz * 64 + cx + 1] - k;
-				for(int k1 = k + nsp; k < k1; k++)
+				const uint16_t *lp = L.binidx + ((cw >> 16) & 0x7fffu);
+				for(uint32_t si = *lp; si != PWN_LIST_END; si = *++lp)
 				{
-					const float4 *sp = (const float4 *)(L.sph + 8 * (int)L.binidx[k]);
+					const float4 *sp = (const float4 *)(L.sph + 8 * si);
 					const float4 s0 = sp[0];         // r, refl, x, y
 					const float4 s1 = sp[1];         // z, cb, cg, cr
 					if(COUNT) cnt.tests++;
@@ -213,15 +220,22 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 				}
 			}
 
-			const bool room1 = (cell == ';' || cell == '$' || cell == '"');
-			const bool room2 = (cell == '#' || cell == '&');
-			if(room1 || room2)
+			if(cw & PWN_C_ROOM)
 			{
 				// trace.h:302-352 (1-high) and 354-441 (2-high) share this body
-				const bool foggy = (cell == '$' || cell == '&');
-				if(room2 && gy > 0) wy += iay;
+				const bool room2 = (cw & PWN_C_ROOM2) != 0u;
+				const bool foggy = (cw & PWN_C_FOG) != 0u;
+				// 2-high: the ceiling is one unit further when looking up (trace.h:357,392)
+				const float up2 = (room2 && gyp) ? iay : 0.0f;
+				wy += up2;
 				if(foggy) fogbeg = cdist;
-				THROUGH(gx);
+				// trace.h:156-184, then 331-340 on the same comparison
+				const bool ymin = (wy < wx) && (wy < wz);
+				const bool xlt = wx < wz;
+				const float txz = xlt ? wx : wz;
+				const float t = ymin ? wy : txz;
+				cdist += t;
+				pos = vadd<HAS_W>(vscale<HAS_W>(t, ray), pos);
 				if(AUX_HIT())
 				{
 					// fog sums in the reference build's operation order
@@ -229,31 +243,31 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 					ev = EV_SPHERE; break;
 				}
 				if(foggy) fog = (fog - fogbeg) + cdist;
-				if(ldir == FYN || ldir == FYP) { ev = EV_WALL; base = (gy > 0 ? BASE_CEIL : BASE_FLOOR); break; }
-				ADVANCE_XZ();
-				if(room2 && gy > 0) wy -= iay;
-				cw = cellword_at(L, cx, cz);
-				const int ncell = (int)(cw & 0xffu);
-				if(room1)
+				if(ymin) { ldir = ldy; ev = EV_WALL; base = (gyp ? BASE_CEIL : BASE_FLOOR); break; }
+				wy = (wy - txz) - up2;
+				if(xlt) { ldir = (gx < 0 ? FXN : FXP); wz -= txz; wx = iax; cx += gx; }
+				else { ldir = (gz < 0 ? FZN : FZP); wx -= txz; wz = iaz; cz += gz; }
+				const uint32_t ncw = cellword_at(L, cx, cz);
+				if(!room2)
 				{
-					if(cell == '"' && (ncell == '#' || ncell == '&'))
+					if((cw & PWN_C_DQ) && (ncw & PWN_C_ROOM2))
 					{
 						pos.y += 1.0f;
-						if(gy < 0) wy += iay; else wy -= iay;
+						wy -= iay_dn;
 					}
 				}
 				else
 				{
-					if(ncell == '"')
+					if(ncw & PWN_C_DQ)
 					{
 						pos.y -= 1.0f;
-						if(gy > 0) wy += iay; else wy -= iay;
+						wy += iay_dn;
 					}
 					if(pos.y < 0.0f || pos.y > 1.0f)
 					{
 						// trace.h:404-413: look through a portal at the cell type behind it
-						int xcell = ncell;
-						if(xcell >= 'A' && xcell <= 'Z')
+						int xcell = (int)(ncw & 0xffu);
+						if(ncw & PWN_C_PORTAL)
 						{
 							uint32_t p0 = L.pmap[2 * (xcell - 'A')], p1 = L.pmap[2 * (xcell - 'A') + 1];
 							int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
@@ -266,19 +280,22 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 							if(xcell == '"')
 							{
 								pos.y += 1.0f;
-								if(gy > 0) wy -= iay; else wy += iay;
+								wy -= iay_dn;
 							}
+							cw = ncw;
 							ev = EV_WALL; base = BASE_WALL; break;
 						}
 					}
 				}
+				cw = ncw;
 			}
-			else if(cell == '>' || cell == '<' || cell == ',' || cell == '^')
+			else if(cw & PWN_C_RAMP)
 			{
 				// trace.h:443-505: ramps
 				const float ramp = 0.5f;
-				const bool alongx = (cell == '>' || cell == '<');
-				const bool minus = (cell == '>' || cell == ',');
+				const bool alongx = (cw & PWN_C_RAMPX) != 0u;
+				const bool minus = (cw & PWN_C_RAMPM) != 0u;
+				const int gy = gyp ? 1 : -1;
 				float tilt = alongx ? ray.x : ray.z;
 				if(minus) ray.y -= ramp * tilt; else ray.y += ramp * tilt;
 				wy = pos.y;
@@ -308,10 +325,11 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 				wy *= iay;
 				cw = cellword_at(L, cx, cz);
 			}
-			else if(cell >= 'A' && cell <= 'Z')
+			else if(cw & PWN_C_PORTAL)
 			{
 				// trace.h:508-650: portal
-				uint32_t p0 = L.pmap[2 * (cell - 'A')], p1 = L.pmap[2 * (cell - 'A') + 1];
+				const int pi = (int)(cw & 0xffu) - 'A';
+				uint32_t p0 = L.pmap[2 * pi], p1 = L.pmap[2 * pi + 1];
 				int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
 				int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
 				int rot12 = (int)(p1 & 0xff);
@@ -393,7 +411,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		}
 #undef AUX_HIT
 #undef THROUGH
-#undef ADVANCE_XZ
 
 		if(ev == EV_EXHAUSTED)
 		{
@@ -500,7 +517,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 }
 
 template<bool COUNT, bool HAS_W>
-__global__ void __launch_bounds__(256, PWN_MIN_WAVES)
+__global__ void __launch_bounds__(PWN_BLOCK, PWN_MIN_WAVES)
 pwn_trace_kernel(pwn_trace_params P)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -510,16 +527,15 @@ pwn_trace_kernel(pwn_trace_params P)
 		const uint4 *src = (const uint4 *)P.blob;
 		uint4 *dst = (uint4 *)lds_raw;
 		int n16 = (int)(P.blob_bytes >> 4);
-		for(int i = threadIdx.x; i < n16; i += 256) dst[i] = src[i];
+		for(int i = threadIdx.x; i < n16; i += PWN_BLOCK) dst[i] = src[i];
 	}
 	__syncthreads();
 
 	Lds L;
 	L.cellinfo = (const uint32_t *)(lds_raw + PWN_T_CELLINFO);
-	L.rcp = (const uint16_t *)(lds_raw + PWN_T_RCP);
-	L.rsq = (const uint16_t *)(lds_raw + PWN_T_RSQ);
+	L.rcp = (const uint32_t *)(lds_raw + PWN_T_RCP);
+	L.rsq = (const uint32_t *)(lds_raw + PWN_T_RSQ);
 	L.pmap = (const uint32_t *)(lds_raw + PWN_T_PMAP);
-	L.binoff = (const uint16_t *)(lds_raw + PWN_T_BINOFF);
 	L.binidx = (const uint16_t *)(lds_raw + PWN_T_BINIDX);
 	L.sph = (const float *)(lds_raw + P.off_sph);
 
@@ -584,7 +600,7 @@ static hipError_t launch_variant(const pwn_trace_params *P, int grid, size_t lds
 	hipError_t e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W>,
 		hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 	if(e != hipSuccess) return e;
-	hipLaunchKernelGGL((pwn_trace_kernel<COUNT, HAS_W>), dim3(grid), dim3(256), lds_bytes, stream, *P);
+	hipLaunchKernelGGL((pwn_trace_kernel<COUNT, HAS_W>), dim3(grid), dim3(PWN_BLOCK), lds_bytes, stream, *P);
 	return hipGetLastError();
 }
 
@@ -595,14 +611,16 @@ extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size
 }
 
 // resident 256-thread workgroups per CU for this variant and LDS size
+extern "C" int pwn_trace_tile_h(void) { return TILE_H; }
+
 extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w)
 {
 	int n = 0;
 	hipError_t e;
-	if(count) e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, true>, 256, lds_bytes)
-	                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, false>, 256, lds_bytes);
-	else e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, true>, 256, lds_bytes)
-	               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, false>, 256, lds_bytes);
+	if(count) e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, true>, PWN_BLOCK, lds_bytes)
+	                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, false>, PWN_BLOCK, lds_bytes);
+	else e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, true>, PWN_BLOCK, lds_bytes)
+	               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, false>, PWN_BLOCK, lds_bytes);
 	if(e != hipSuccess || n < 1) n = 2;
 	return n;
 }

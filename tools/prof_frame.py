@@ -20,6 +20,8 @@ gold = os.path.join(ROOT, "tests", "golden")
 r = pwnfps_amd.Renderer(w, h)
 r.level_load(os.path.join(gold, "levels", level + ".txt"))
 sph = np.load(os.path.join(gold, "spheres_t0.npy" if level == "pwnfps_level" else os.path.join("levels", level + "_spheres.npy")))
+if os.environ.get("PWN_NOSPH"):
+    sph = sph[:0]
 r.set_objects(sph)
 r.set_blur_passes(blur)
 _, _, spawn = r.get_level()
@@ -27,7 +29,17 @@ cam = pwnfps_amd.spawn_camera(spawn)
 if level != "pwnfps_level":
     cam = np.load(os.path.join(gold, "levels", level + "_cams.npy"))[0]
 sb = np.empty((h, w), np.uint32)
+tr, bl = [], []
 for _ in range(frames):
     r.trace_screen_centred(cam, 0.0, want_z=False, sbuf=sb)
-st = r.stats()
-print("trace_ms %.4f blur_ms %.4f total_ms %.4f" % (st["trace_ms"], st["blur_ms"], st["total_ms"]))
+    st = r.stats()
+    tr.append(st["trace_ms"])
+    bl.append(st["blur_ms"])
+hsh = "-"
+if os.environ.get("PWN_HASH"):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle  # checker only
+    hsh = oracle.fnv64(sb)
+print("%s %s %dx%d trace_ms min %.4f med %.4f blur_ms min %.4f fnv %s" % (
+    os.path.basename(os.environ.get("PWNHIP_LIB", "libpwnhip.so")), level, w, h,
+    min(tr), sorted(tr)[len(tr) // 2], min(bl), hsh))

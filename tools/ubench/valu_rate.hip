@@ -1,0 +1,125 @@
+// valu_rate.hip -- issue cost of single VALU/SALU instructions on gfx950, per SIMD,
+// at 1..8 waves per SIMD.  Each wave runs ITER x 16 independent copies of one
+// instruction (inline asm, distinct destinations) and stamps s_memtime around it.
+// Output: cycles per wave-instruction per SIMD = elapsed / (ITER*16*waves_per_simd).
+//   hipcc --offload-arch=gfx950 -O2 -o valu_rate valu_rate.hip && ./valu_rate
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#define ITER 4096
+
+#define REP16(OP) \
+	OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
+
+#define KERNEL(NAME, ASMSTR) \
+__global__ void __launch_bounds__(1024) NAME(unsigned long long *out, float seed) \
+{ \
+	float a = seed + threadIdx.x, b = seed * 3.0f; \
+	float r[16]; \
+	for(int i = 0; i < 16; i++) r[i] = a + i; \
+	unsigned long long q0 = __builtin_amdgcn_s_memrealtime(); \
+	unsigned long long t0 = __builtin_amdgcn_s_memtime(); \
+	for(int it = 0; it < ITER; it++) \
+	{ \
+		asm volatile(ASMSTR \
+			: "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), \
+			  "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15]) \
+			: "v"(a), "v"(b) : "vcc", "scc", "s4", "s5", "s6", "s7"); \
+	} \
+	unsigned long long t1 = __builtin_amdgcn_s_memtime(); \
+	unsigned long long q1 = __builtin_amdgcn_s_memrealtime(); \
+	float s = 0; for(int i = 0; i < 16; i++) s += r[i]; \
+	if(s == 12345.678f) out[0] = 1; \
+	if((threadIdx.x & 63) == 0) out[1 + blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = ((t1 - t0) << 24) | (q1 - q0); \
+}
+
+#define L(n, txt) txt "\n"
+// one line per destination %0..%15; %16 = a, %17 = b
+#define ASM16(fmt_pre, fmt_post) \
+	fmt_pre "%0" fmt_post "\n" fmt_pre "%1" fmt_post "\n" fmt_pre "%2" fmt_post "\n" fmt_pre "%3" fmt_post "\n" \
+	fmt_pre "%4" fmt_post "\n" fmt_pre "%5" fmt_post "\n" fmt_pre "%6" fmt_post "\n" fmt_pre "%7" fmt_post "\n" \
+	fmt_pre "%8" fmt_post "\n" fmt_pre "%9" fmt_post "\n" fmt_pre "%10" fmt_post "\n" fmt_pre "%11" fmt_post "\n" \
+	fmt_pre "%12" fmt_post "\n" fmt_pre "%13" fmt_post "\n" fmt_pre "%14" fmt_post "\n" fmt_pre "%15" fmt_post "\n"
+
+KERNEL(k_add_f32,   ASM16("v_add_f32 ", ", %16, %17"))
+KERNEL(k_mul_f32,   ASM16("v_mul_f32 ", ", %16, %17"))
+KERNEL(k_fma_f32,   ASM16("v_fma_f32 ", ", %16, %17, %16"))
+KERNEL(k_add_u32,   ASM16("v_add_u32 ", ", %16, %17"))
+KERNEL(k_and_b32,   ASM16("v_and_b32 ", ", %16, %17"))
+KERNEL(k_lshl,      ASM16("v_lshlrev_b32 ", ", 3, %17"))
+KERNEL(k_bfe,       ASM16("v_bfe_u32 ", ", %16, 8, 8"))
+KERNEL(k_mov,       ASM16("v_mov_b32 ", ", %16"))
+KERNEL(k_cndmask,   ASM16("v_cndmask_b32 ", ", %16, %17, vcc"))
+KERNEL(k_cndmask64, ASM16("v_cndmask_b32 ", ", %16, %17, s[4:5]"))
+KERNEL(k_cmp,       "v_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\n" \
+                    "v_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\n" \
+                    "v_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\n" \
+                    "v_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\nv_cmp_lt_f32 vcc, %16, %17\n")
+KERNEL(k_cmp_e64,   "v_cmp_lt_f32 s[4:5], %16, %17\nv_cmp_lt_f32 s[6:7], %16, %17\nv_cmp_lt_f32 s[4:5], %16, %17\nv_cmp_lt_f32 s[6:7], %16, %17\n" \
+                    "v_cmp_lt_f32 s[4:5], %16, %17\nv_cmp_lt_f32 s[6:7], %16, %17\nv_cmp_lt_f32 s[4:5], %16, %17\nv_cmp_lt_f32 s[6:7], %16, %17\n" \
+                    "v_cmp_lt_f32 s[4:5], %16, %17\nv_cmp_lt_f32 s[6:7], %16, %17\nv_cmp_lt_f32 s[4:5], %16, %17\nv_cmp_lt_f32 s[6:7], %16, %17\n" \
+                    "v_cmp_lt_f32 s[4:5], %16, %17\nv_cmp_lt_f32 s[6:7], %16, %17\nv_cmp_lt_f32 s[4:5], %16, %17\nv_cmp_lt_f32 s[6:7], %16, %17\n")
+KERNEL(k_max_f32,   ASM16("v_max_f32 ", ", %16, %17"))
+KERNEL(k_cvt,       ASM16("v_cvt_f32_i32 ", ", %16"))
+KERNEL(k_mul_lo,    ASM16("v_mul_lo_u32 ", ", %16, %17"))
+KERNEL(k_mul_hi,    ASM16("v_mul_hi_u32 ", ", %16, %17"))
+KERNEL(k_mad_u32,   ASM16("v_mad_u32_u24 ", ", %16, %17, %16"))
+KERNEL(k_add3,      ASM16("v_add3_u32 ", ", %16, %17, %16"))
+KERNEL(k_rcp,       ASM16("v_rcp_f32 ", ", %16"))
+KERNEL(k_sqrt,      ASM16("v_sqrt_f32 ", ", %16"))
+KERNEL(k_salu,      "s_add_u32 s4, s4, 1\ns_add_u32 s5, s5, 1\ns_add_u32 s6, s6, 1\ns_add_u32 s7, s7, 1\ns_add_u32 s4, s4, 1\ns_add_u32 s5, s5, 1\ns_add_u32 s6, s6, 1\ns_add_u32 s7, s7, 1\n" \
+                    "s_add_u32 s4, s4, 1\ns_add_u32 s5, s5, 1\ns_add_u32 s6, s6, 1\ns_add_u32 s7, s7, 1\ns_add_u32 s4, s4, 1\ns_add_u32 s5, s5, 1\ns_add_u32 s6, s6, 1\ns_add_u32 s7, s7, 1\n")
+KERNEL(k_salu64,    "s_and_b64 s[4:5], s[4:5], exec\ns_or_b64 s[6:7], s[6:7], exec\ns_and_b64 s[4:5], s[4:5], exec\ns_or_b64 s[6:7], s[6:7], exec\n" \
+                    "s_and_b64 s[4:5], s[4:5], exec\ns_or_b64 s[6:7], s[6:7], exec\ns_and_b64 s[4:5], s[4:5], exec\ns_or_b64 s[6:7], s[6:7], exec\n" \
+                    "s_and_b64 s[4:5], s[4:5], exec\ns_or_b64 s[6:7], s[6:7], exec\ns_and_b64 s[4:5], s[4:5], exec\ns_or_b64 s[6:7], s[6:7], exec\n" \
+                    "s_and_b64 s[4:5], s[4:5], exec\ns_or_b64 s[6:7], s[6:7], exec\ns_and_b64 s[4:5], s[4:5], exec\ns_or_b64 s[6:7], s[6:7], exec\n")
+KERNEL(k_cmpcnd,    "v_cmp_lt_f32 vcc, %16, %17\nv_cndmask_b32 %0, %16, %17, vcc\nv_cmp_lt_f32 vcc, %16, %17\nv_cndmask_b32 %1, %16, %17, vcc\nv_cmp_lt_f32 vcc, %16, %17\nv_cndmask_b32 %2, %16, %17, vcc\nv_cmp_lt_f32 vcc, %16, %17\nv_cndmask_b32 %3, %16, %17, vcc\n" \
+                    "v_cmp_lt_f32 vcc, %16, %17\nv_cndmask_b32 %4, %16, %17, vcc\nv_cmp_lt_f32 vcc, %16, %17\nv_cndmask_b32 %5, %16, %17, vcc\nv_cmp_lt_f32 vcc, %16, %17\nv_cndmask_b32 %6, %16, %17, vcc\nv_cmp_lt_f32 vcc, %16, %17\nv_cndmask_b32 %7, %16, %17, vcc\n")
+// saveexec / restore pairs around one VALU op, as hipcc emits for a divergent if
+KERNEL(k_ifblock,   "v_cmp_lt_f32 vcc, %16, %17\ns_and_saveexec_b64 s[4:5], vcc\nv_add_f32 %0, %16, %17\ns_or_b64 exec, exec, s[4:5]\nv_cmp_lt_f32 vcc, %16, %17\ns_and_saveexec_b64 s[4:5], vcc\nv_add_f32 %1, %16, %17\ns_or_b64 exec, exec, s[4:5]\n" \
+                    "v_cmp_lt_f32 vcc, %16, %17\ns_and_saveexec_b64 s[4:5], vcc\nv_add_f32 %2, %16, %17\ns_or_b64 exec, exec, s[4:5]\nv_cmp_lt_f32 vcc, %16, %17\ns_and_saveexec_b64 s[4:5], vcc\nv_add_f32 %3, %16, %17\ns_or_b64 exec, exec, s[4:5]\n")
+// alternating VALU / SALU: does the scalar stream ride along for free?
+KERNEL(k_mix_vs,    "v_add_f32 %0, %16, %17\ns_add_u32 s4, s4, 1\nv_add_f32 %1, %16, %17\ns_add_u32 s5, s5, 1\nv_add_f32 %2, %16, %17\ns_add_u32 s6, s6, 1\nv_add_f32 %3, %16, %17\ns_add_u32 s7, s7, 1\n" \
+                    "v_add_f32 %4, %16, %17\ns_add_u32 s4, s4, 1\nv_add_f32 %5, %16, %17\ns_add_u32 s5, s5, 1\nv_add_f32 %6, %16, %17\ns_add_u32 s6, s6, 1\nv_add_f32 %7, %16, %17\ns_add_u32 s7, s7, 1\n")
+
+template<int OPS> static void run(const char *name, void (*k)(unsigned long long *, float), unsigned long long *d, int ncu)
+{
+	printf("%-12s", name);
+	for(int wps = 1; wps <= 8; wps *= 2)
+	{
+		int threads = 64 * 4 * (wps > 4 ? 4 : wps);     // 4 SIMDs x wps waves (two blocks per CU at 8)
+		int nblk = ncu * (wps > 4 ? 2 : 1);
+		int nw = ncu * 4 * wps;
+		hipMemset(d, 0, 8 * (nw + 1));
+		hipLaunchKernelGGL(k, dim3(nblk), dim3(threads), 0, 0, d, 1.0f);
+		hipLaunchKernelGGL(k, dim3(nblk), dim3(threads), 0, 0, d, 1.0f);
+		hipDeviceSynchronize();
+		std::vector<unsigned long long> h(nw + 1);
+		hipMemcpy(h.data(), d, 8 * (nw + 1), hipMemcpyDeviceToHost);
+		double s = 0, q = 0; for(int i = 1; i <= nw; i++) { s += (double)(h[i] >> 24); q += (double)(h[i] & 0xffffff); }
+		double per = s / nw / ((double)ITER * OPS * wps);
+		double ns = q / nw * 10.0;   // s_memrealtime: 100 MHz
+		printf("  w%d: %5.2f tick %5.3f ns (%.2f GHz)", wps, per, ns / ((double)ITER * OPS * wps), s / nw / ns);
+	}
+	printf("   cycles per wave-instruction per SIMD\n");
+}
+
+int main(int argc, char **argv)
+{
+	setvbuf(stdout, NULL, _IONBF, 0);
+	const char *only = argc > 1 ? argv[1] : NULL;
+	printf("start\n");
+	hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+	int ncu = p.multiProcessorCount;
+	printf("%s, %d CUs; s_memtime ticks (100 MHz realtime? see below)\n", p.gcnArchName, ncu);
+	unsigned long long *d; hipMalloc(&d, 8 * (ncu * 32 + 1));
+#define R(n) if(only == NULL || strcmp(only, #n) == 0) run<16>(#n, k_##n, d, ncu)
+	R(add_f32); R(mul_f32); R(fma_f32); R(add_u32); R(and_b32); R(lshl); R(bfe); R(mov); R(cndmask); R(cndmask64);
+	R(cmp); R(cmp_e64); R(max_f32); R(cvt); R(mul_lo); R(mul_hi); R(mad_u32); R(add3); R(rcp); R(sqrt); R(salu); R(salu64);
+	R(cmpcnd); R(ifblock);
+	if(only == NULL || strcmp(only, "mix_vs") == 0) run<16>("mix_vs(8v+8s)", k_mix_vs, d, ncu);
+	return 0;
+}
