@@ -126,7 +126,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	for(;;)
 	{
 		// ------------------------------------------------ trace.h:186-248
-		float cdist = 0.0f, fog = 0.0f, fogbeg = 0.0f;
+		float cdist = 0.0f, fog = 0.0f;
 		float aux_dist = -1.0f, aux_refl = 0.25f;
 		V aux_pos, aux_norm;
 		aux_pos.x = aux_pos.y = aux_pos.z = aux_pos.w = 0.0f;
@@ -156,24 +156,22 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		// (trace.h:345-349,381-385); iay_dn is the amount added when stepping DOWN into it
 		const float iay_dn = gyp ? iay : -iay;
 		const int ldy = gyp ? FYP : FYN;
+		int ldx = (gx < 0 ? FXN : FXP), ldz = (gz < 0 ? FZN : FZP);
 
 		uint32_t cw = cellword_at(L, cx, cz);
 		int ldir = FYN;
-		int ev = EV_EXHAUSTED, base = BASE_WALL;
+		int ev = EV_EXHAUSTED, base = BASE_WALL;     // ev == 0: still walking
 
 #define AUX_HIT() (aux_dist != -1.0f && cdist > aux_dist)
-// trace.h:156-184
-#define THROUGH(gxa) do { float t_; \
-	if(wy < wx && wy < wz) { t_ = wy; ldir = ldy; } \
-	else if(wx < wz) { t_ = wx; ldir = ((gxa) < 0 ? FXN : FXP); } \
-	else { t_ = wz; ldir = (gz < 0 ? FZN : FZP); } \
-	cdist += t_; pos = vadd<HAS_W>(vscale<HAS_W>(t_, ray), pos); } while(0)
 
 		// ------------------------------------------------ trace.h:250-675
-		// One cell per iteration.  The cell class is a bit test on the LDS word
-		// (tables.h), so the four bodies below are entered by one compare each.
+		// One cell per iteration, one loop exit at the bottom.  The cell class is a
+		// bit test on the LDS word (tables.h).  The room body - by far the most
+		// frequent - is written with selects; lanes whose ray ended in it carry on
+		// through the (then meaningless) cell advance and leave at the bottom.
+		int maxsteps = 1000;
 #pragma unroll 1
-		for(int maxsteps = 1000; maxsteps > 0; maxsteps--)
+		do
 		{
 			if(COUNT) cnt.steps++;
 
@@ -224,193 +222,214 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			{
 				// trace.h:302-352 (1-high) and 354-441 (2-high) share this body
 				const bool room2 = (cw & PWN_C_ROOM2) != 0u;
-				const bool foggy = (cw & PWN_C_FOG) != 0u;
 				// 2-high: the ceiling is one unit further when looking up (trace.h:357,392)
 				const float up2 = (room2 && gyp) ? iay : 0.0f;
 				wy += up2;
-				if(foggy) fogbeg = cdist;
-				// trace.h:156-184, then 331-340 on the same comparison
+				const float cdist0 = cdist;
+				// trace.h:156-184, then 331-340 on the same comparisons
 				const bool ymin = (wy < wx) && (wy < wz);
 				const bool xlt = wx < wz;
 				const float txz = xlt ? wx : wz;
 				const float t = ymin ? wy : txz;
 				cdist += t;
 				pos = vadd<HAS_W>(vscale<HAS_W>(t, ray), pos);
-				if(AUX_HIT())
+				const bool hit = AUX_HIT();
+				if(cw & PWN_C_FOG)
 				{
-					// fog sums in the reference build's operation order
-					if(foggy && aux_dist > fogbeg) fog = (fog + aux_dist) - fogbeg;
-					ev = EV_SPHERE; break;
+					// fogbeg = distance at entry (trace.h:309,359); sums in the
+					// reference build's operation order
+					const float fh = (fog + aux_dist) - cdist0;
+					const float fn = (fog - cdist0) + cdist;
+					fog = hit ? (aux_dist > cdist0 ? fh : fog) : fn;
 				}
-				if(foggy) fog = (fog - fogbeg) + cdist;
-				if(ymin) { ldir = ldy; ev = EV_WALL; base = (gyp ? BASE_CEIL : BASE_FLOOR); break; }
+				ldir = ymin ? ldy : (xlt ? ldx : ldz);
+				ev = hit ? EV_SPHERE : (ymin ? EV_WALL : 0);
+				base = gyp ? BASE_CEIL : BASE_FLOOR;
 				wy = (wy - txz) - up2;
-				if(xlt) { ldir = (gx < 0 ? FXN : FXP); wz -= txz; wx = iax; cx += gx; }
-				else { ldir = (gz < 0 ? FZN : FZP); wx -= txz; wz = iaz; cz += gz; }
+				wz = xlt ? wz - txz : iaz;
+				wx = xlt ? iax : wx - txz;
+				cx += xlt ? gx : 0;
+				cz += xlt ? 0 : gz;
 				const uint32_t ncw = cellword_at(L, cx, cz);
-				if(!room2)
+				if((cw & (PWN_C_DQ | PWN_C_ROOM2)) != 0u && ev == 0)
 				{
-					if((cw & PWN_C_DQ) && (ncw & PWN_C_ROOM2))
+					if(!room2)
 					{
-						pos.y += 1.0f;
-						wy -= iay_dn;
-					}
-				}
-				else
-				{
-					if(ncw & PWN_C_DQ)
-					{
-						pos.y -= 1.0f;
-						wy += iay_dn;
-					}
-					if(pos.y < 0.0f || pos.y > 1.0f)
-					{
-						// trace.h:404-413: look through a portal at the cell type behind it
-						int xcell = (int)(ncw & 0xffu);
-						if(ncw & PWN_C_PORTAL)
+						if(ncw & PWN_C_ROOM2)        // here cw is the "-cell
 						{
-							uint32_t p0 = L.pmap[2 * (xcell - 'A')], p1 = L.pmap[2 * (xcell - 'A') + 1];
-							int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
-							int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
-							if(x1 == cx && z1 == cz) xcell = (int)((p1 >> 16) & 0xff);
-							else if(x2 == cx && z2 == cz) xcell = (int)((p1 >> 8) & 0xff);
+							pos.y += 1.0f;
+							wy -= iay_dn;
 						}
-						if(!(xcell == '#' || xcell == '&'))
+					}
+					else
+					{
+						if(ncw & PWN_C_DQ)
 						{
-							if(xcell == '"')
+							pos.y -= 1.0f;
+							wy += iay_dn;
+						}
+						if(pos.y < 0.0f || pos.y > 1.0f)
+						{
+							// trace.h:404-413: look through a portal at the cell type behind it
+							int xcell = (int)(ncw & 0xffu);
+							if(ncw & PWN_C_PORTAL)
 							{
-								pos.y += 1.0f;
-								wy -= iay_dn;
+								uint32_t p0 = L.pmap[2 * (xcell - 'A')], p1 = L.pmap[2 * (xcell - 'A') + 1];
+								int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
+								int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
+								if(x1 == cx && z1 == cz) xcell = (int)((p1 >> 16) & 0xff);
+								else if(x2 == cx && z2 == cz) xcell = (int)((p1 >> 8) & 0xff);
 							}
-							cw = ncw;
-							ev = EV_WALL; base = BASE_WALL; break;
+							if(!(xcell == '#' || xcell == '&'))
+							{
+								if(xcell == '"')
+								{
+									pos.y += 1.0f;
+									wy -= iay_dn;
+								}
+								ev = EV_WALL; base = BASE_WALL;
+							}
 						}
 					}
 				}
 				cw = ncw;
 			}
-			else if(cw & PWN_C_RAMP)
+			else
 			{
-				// trace.h:443-505: ramps
-				const float ramp = 0.5f;
-				const bool alongx = (cw & PWN_C_RAMPX) != 0u;
-				const bool minus = (cw & PWN_C_RAMPM) != 0u;
-				const int gy = gyp ? 1 : -1;
-				float tilt = alongx ? ray.x : ray.z;
-				if(minus) ray.y -= ramp * tilt; else ray.y += ramp * tilt;
-				wy = pos.y;
-				if(ray.y >= 0.0f) wy = 1.0f - wy;
-				wy *= 1.0f / (ray.y < 0.0f ? -ray.y : ray.y);
-				if(AUX_HIT()) { ev = EV_SPHERE; break; }
-				THROUGH(gy); // sic: trace.h:470 passes gy for gx
-				if(ldir == FYN || ldir == FYP)
+				if(cw & PWN_C_RAMP)
 				{
-					ldir = (ray.y < 0.0f ? FYN : FYP);
-					ev = EV_WALL; base = (ray.y >= 0.0f ? BASE_CEIL : BASE_FLOOR); break;
-				}
-				else if(ldir == FXN || ldir == FXP)
-				{
-					ldir = (ray.x < 0.0f ? FXN : FXP);
-					wy -= wx; wz -= wx; wx = iax; cx += gx;
-				}
-				else
-				{
-					ldir = (ray.z < 0.0f ? FZN : FZP);
-					wx -= wz; wy -= wz; wz = iaz; cz += gz;
-				}
-				tilt = alongx ? ray.x : ray.z;
-				if(minus) ray.y += ramp * tilt; else ray.y -= ramp * tilt;
-				wy = pos.y;
-				if(ray.y >= 0.0f) wy = 1.0f - wy;
-				wy *= iay;
-				cw = cellword_at(L, cx, cz);
-			}
-			else if(cw & PWN_C_PORTAL)
-			{
-				// trace.h:508-650: portal
-				const int pi = (int)(cw & 0xffu) - 'A';
-				uint32_t p0 = L.pmap[2 * pi], p1 = L.pmap[2 * pi + 1];
-				int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
-				int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
-				int rot12 = (int)(p1 & 0xff);
-				int rot;
-				if(x2 == -1)
-				{
-					if(AUX_HIT()) { ev = EV_SPHERE; break; }
-					ev = EV_WALL; base = BASE_WALL; break;
-				}
-				if(x1 == cx && z1 == cz)
-				{
-					cx = x2; cz = z2;
-					pos.x += (float)(x2 - x1);
-					pos.z += (float)(z2 - z1);
-					rot = (-rot12) & 3;
-				}
-				else if(x2 == cx && z2 == cz)
-				{
-					cx = x1; cz = z1;
-					pos.x -= (float)(x2 - x1);
-					pos.z -= (float)(z2 - z1);
-					rot = rot12 & 3;
-				}
-				else
-				{
-					if(AUX_HIT()) { ev = EV_SPHERE; break; }
-					ev = EV_WALL; base = BASE_MAGENTA; break;
-				}
-				if(COUNT) cnt.portals++;
-
-				// trace.h:561-622.  The operation order is the one the reference
-				// build executes (its -ffast-math cancels the +-0.5 terms).
-				const float trx = pos.x, trz = pos.z, trvx = ray.x, trvz = ray.z;
-				const int tgx = gx, tgz = gz;
-				const float fcx = (float)cx, fcz = (float)cz;
-				ldir = (ldir - rot) & 3;
-				if(rot & 1)
-				{
-					float t = wx; wx = wz; wz = t;
-					t = iax; iax = iaz; iaz = t;
-					if(rot == 1)
+					// trace.h:443-505: ramps
+					const float ramp = 0.5f;
+					const bool alongx = (cw & PWN_C_RAMPX) != 0u;
+					const bool minus = (cw & PWN_C_RAMPM) != 0u;
+					float tilt = alongx ? ray.x : ray.z;
+					if(minus) ray.y -= ramp * tilt; else ray.y += ramp * tilt;
+					wy = pos.y;
+					if(ray.y >= 0.0f) wy = 1.0f - wy;
+					wy *= 1.0f / (ray.y < 0.0f ? -ray.y : ray.y);
+					if(AUX_HIT()) ev = EV_SPHERE;
+					else
 					{
-						pos.x = (trz + fcx) - fcz;
-						pos.z = (1.0f - trx) + (fcx + fcz);
-						ray.x = trvz; ray.z = -trvx;
-						gx = tgz; gz = -tgx;
+						// trace.h:470 passes gy where trace_ray_through expects gx; the
+						// face is recomputed from the ray signs right after (:474-487)
+						const bool ymin = (wy < wx) && (wy < wz);
+						const bool xlt = wx < wz;
+						const float t = ymin ? wy : (xlt ? wx : wz);
+						cdist += t;
+						pos = vadd<HAS_W>(vscale<HAS_W>(t, ray), pos);
+						if(ymin)
+						{
+							ldir = (ray.y < 0.0f ? FYN : FYP);
+							ev = EV_WALL; base = (ray.y >= 0.0f ? BASE_CEIL : BASE_FLOOR);
+						}
+						else
+						{
+							if(xlt)
+							{
+								ldir = (ray.x < 0.0f ? FXN : FXP);
+								wy -= wx; wz -= wx; wx = iax; cx += gx;
+							}
+							else
+							{
+								ldir = (ray.z < 0.0f ? FZN : FZP);
+								wx -= wz; wy -= wz; wz = iaz; cz += gz;
+							}
+							tilt = alongx ? ray.x : ray.z;
+							if(minus) ray.y += ramp * tilt; else ray.y -= ramp * tilt;
+							wy = pos.y;
+							if(ray.y >= 0.0f) wy = 1.0f - wy;
+							wy *= iay;
+							cw = cellword_at(L, cx, cz);
+						}
+					}
+				}
+				else if(cw & PWN_C_PORTAL)
+				{
+					// trace.h:508-650: portal
+					const int pi = (int)(cw & 0xffu) - 'A';
+					uint32_t p0 = L.pmap[2 * pi], p1 = L.pmap[2 * pi + 1];
+					int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
+					int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
+					int rot12 = (int)(p1 & 0xff);
+					const bool at1 = (x1 == cx && z1 == cz), at2 = (x2 == cx && z2 == cz);
+					if(x2 == -1 || !(at1 || at2))
+					{
+						// unpaired letter, or a letter standing in a cell that is not one
+						// of its endpoints (trace.h:514-520,551-559)
+						if(AUX_HIT()) ev = EV_SPHERE;
+						else { ev = EV_WALL; base = (x2 == -1 ? BASE_WALL : BASE_MAGENTA); }
 					}
 					else
 					{
-						pos.x = (1.0f - trz) + (fcx + fcz);
-						pos.z = (fcz + trx) - fcx;
-						ray.x = -trvz; ray.z = trvx;
-						gx = -tgz; gz = tgx;
+						int rot;
+						if(at1)
+						{
+							cx = x2; cz = z2;
+							pos.x += (float)(x2 - x1);
+							pos.z += (float)(z2 - z1);
+							rot = (-rot12) & 3;
+						}
+						else
+						{
+							cx = x1; cz = z1;
+							pos.x -= (float)(x2 - x1);
+							pos.z -= (float)(z2 - z1);
+							rot = rot12 & 3;
+						}
+						if(COUNT) cnt.portals++;
+
+						// trace.h:561-622.  The operation order is the one the reference
+						// build executes (its -ffast-math cancels the +-0.5 terms).
+						const float trx = pos.x, trz = pos.z, trvx = ray.x, trvz = ray.z;
+						const int tgx = gx, tgz = gz;
+						const float fcx = (float)cx, fcz = (float)cz;
+						ldir = (ldir - rot) & 3;
+						if(rot & 1)
+						{
+							float t = wx; wx = wz; wz = t;
+							t = iax; iax = iaz; iaz = t;
+							if(rot == 1)
+							{
+								pos.x = (trz + fcx) - fcz;
+								pos.z = (1.0f - trx) + (fcx + fcz);
+								ray.x = trvz; ray.z = -trvx;
+								gx = tgz; gz = -tgx;
+							}
+							else
+							{
+								pos.x = (1.0f - trz) + (fcx + fcz);
+								pos.z = (fcz + trx) - fcx;
+								ray.x = -trvz; ray.z = trvx;
+								gx = -tgz; gz = tgx;
+							}
+						}
+						else if(rot == 2)
+						{
+							pos.x = (fcx + 0.5f) * 2.0f - trx;
+							pos.z = (fcz + 0.5f) * 2.0f - trz;
+							ray.x = -trvx; ray.z = -trvz;
+							gx = -tgx; gz = -tgz;
+						}
+						ldx = (gx < 0 ? FXN : FXP); ldz = (gz < 0 ? FZN : FZP);
+						// trace.h:624-647: step out of the far endpoint
+						if(ldir == FZP) { cz++; pos.z += 1.0f; }
+						else if(ldir == FXN) { cx--; pos.x -= 1.0f; }
+						else if(ldir == FZN) { cz--; pos.z -= 1.0f; }
+						else { cx++; pos.x += 1.0f; }
+						cw = cellword_at(L, cx, cz);
 					}
 				}
-				else if(rot == 2)
+				else
 				{
-					pos.x = (fcx + 0.5f) * 2.0f - trx;
-					pos.z = (fcz + 0.5f) * 2.0f - trz;
-					ray.x = -trvx; ray.z = -trvz;
-					gx = -tgx; gz = -tgz;
+					// trace.h:651-664: solid
+					if(AUX_HIT()) ev = EV_SPHERE;
+					else { ev = EV_WALL; base = (ldir == FYP ? BASE_CEIL : BASE_WALL); }
 				}
-				// trace.h:624-647: step out of the far endpoint
-				if(ldir == FZP) { cz++; pos.z += 1.0f; }
-				else if(ldir == FXN) { cx--; pos.x -= 1.0f; }
-				else if(ldir == FZN) { cz--; pos.z -= 1.0f; }
-				else { cx++; pos.x += 1.0f; }
-				cw = cellword_at(L, cx, cz);
+				// trace.h:668-673 (in the room body the same test sits right after the step)
+				if(ev == 0 && AUX_HIT()) ev = EV_SPHERE;
 			}
-			else
-			{
-				// trace.h:651-664: solid
-				if(AUX_HIT()) { ev = EV_SPHERE; break; }
-				ev = EV_WALL; base = (ldir == FYP ? BASE_CEIL : BASE_WALL); break;
-			}
-
-			// trace.h:668-673
-			if(AUX_HIT()) { ev = EV_SPHERE; break; }
-		}
+		} while(ev == 0 && --maxsteps > 0);
 #undef AUX_HIT
-#undef THROUGH
 
 		if(ev == EV_EXHAUSTED)
 		{
