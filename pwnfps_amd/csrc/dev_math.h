@@ -108,13 +108,14 @@ __device__ __forceinline__ float lcg_fs(uint32_t &s)
 // ---- colour pack: cvtps2dq (RNE) + packs_epi32 + packus_epi16 --------------
 __device__ __forceinline__ uint32_t ftoint_lane(float f)
 {
+	// cvtps2dq gives 0x80000000 ("integer indefinite") for NaN and for anything
+	// outside int32; the two saturating packs then clamp to [-32768,32767] and
+	// [0,255], i.e. to [0,255], and the indefinite value ends as 0.
+	// v_cvt_i32_f32 saturates instead, which differs only for s >= 2^31.
 	float s = f * 255.0f;
-	int i;
-	if(!(s >= -2147483648.0f && s < 2147483648.0f)) i = INT32_MIN; // "integer indefinite"
-	else i = (int)rintf(s);
-	i = max(i, -32768); i = min(i, 32767);
-	i = max(i, 0); i = min(i, 255);
-	return (uint32_t)i;
+	int i = (int)rintf(s);
+	i = min(max(i, 0), 255);
+	return (s < 2147483648.0f) ? (uint32_t)i : 0u;
 }
 __device__ __forceinline__ uint32_t col_pack(v4 c)
 {

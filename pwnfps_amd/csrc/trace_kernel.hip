@@ -39,9 +39,6 @@ enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
 #endif
 #define TILE_W 32
 #define TILE_H (PWN_BLOCK / 32)
-#ifndef PWN_WAVE_W
-#define PWN_WAVE_W 16             // a wave64 covers PWN_WAVE_W x (64/PWN_WAVE_W) pixels
-#endif
 
 // min waves per SIMD the register allocator must leave room for (Makefile MINW)
 #ifndef PWN_MIN_WAVES
@@ -102,7 +99,13 @@ template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const uint32_t *rs
 	return vscale<W>(tab_rsqrt(rsq, dot3<W>(a, a)), a);
 }
 
-enum { EV_EXHAUSTED = 0, EV_WALL, EV_SPHERE };
+// lane j of each 16-lane DPP row reads lane j-1; lane 0 reads 0.0f
+__device__ __forceinline__ float dpp_row_shr1(float v)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xf, 0xf, true));
+}
+
+enum { EV_NONE = 0, EV_WALL, EV_SPHERE, EV_EXHAUSTED };
 enum { BASE_CEIL = 0, BASE_FLOOR, BASE_WALL, BASE_MAGENTA };
 
 struct Counters { uint32_t rays, steps, portals, tests, exhausted; };
@@ -144,9 +147,23 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		int gx = (iray.x < 0.0f ? -1 : 1);
 		int gz = (iray.z < 0.0f ? -1 : 1);
 		const bool gyp = !(iray.y < 0.0f);          // gy > 0
-		float iax = tab_rcp(L.rcp, fabsf(ray.x));
-		const float iay = tab_rcp(L.rcp, fabsf(ray.y));
-		float iaz = tab_rcp(L.rcp, fabsf(ray.z));
+		// trace.h:230-231: |ray| >= EPSILON here, so all three reciprocals normally
+		// take the one-subtract table path together (one LDS round trip)
+		float iax, iaz, iay_;
+		{
+			const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
+			const uint32_t ux = __float_as_uint(ax) - 0x00800000u, uy = __float_as_uint(ay) - 0x00800000u,
+				uz = __float_as_uint(az) - 0x00800000u;
+			if(max(max(ux, uy), uz) < 0x7e000000u)
+			{
+				iax = tab_rcp_pos(L.rcp, ax); iay_ = tab_rcp_pos(L.rcp, ay); iaz = tab_rcp_pos(L.rcp, az);
+			}
+			else
+			{
+				iax = tab_rcp(L.rcp, ax); iay_ = tab_rcp(L.rcp, ay); iaz = tab_rcp(L.rcp, az);
+			}
+		}
+		const float iay = iay_;
 		float wx = pos.x - (float)cx, wy = pos.y, wz = pos.z - (float)cz;
 		if(ray.x >= 0.0f) wx = 1.0f - wx;
 		if(ray.y >= 0.0f) wy = 1.0f - wy;
@@ -160,7 +177,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 
 		uint32_t cw = cellword_at(L, cx, cz);
 		int ldir = FYN;
-		int ev = EV_EXHAUSTED, base = BASE_WALL;     // ev == 0: still walking
+		int ev = EV_NONE, base = BASE_WALL;
 
 #define AUX_HIT() (aux_dist != -1.0f && cdist > aux_dist)
 
@@ -428,7 +445,9 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 				// trace.h:668-673 (in the room body the same test sits right after the step)
 				if(ev == 0 && AUX_HIT()) ev = EV_SPHERE;
 			}
-		} while(ev == 0 && --maxsteps > 0);
+			// trace.h:250,677: out of steps
+			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
+		} while(ev == 0);
 #undef AUX_HIT
 
 		if(ev == EV_EXHAUSTED)
@@ -566,10 +585,13 @@ pwn_trace_kernel(pwn_trace_params P)
 	from.x = P.from[0]; from.y = P.from[1]; from.z = P.from[2]; from.w = HAS_W ? P.from[3] : 1.0f;
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	// wave footprint PWN_WAVE_W x (64/PWN_WAVE_W); the 4 waves tile the 32x8 block
-	const int waves_x = TILE_W / PWN_WAVE_W;
-	const int lx = (wave % waves_x) * PWN_WAVE_W + (lane % PWN_WAVE_W);
-	const int ly = (wave / waves_x) * (64 / PWN_WAVE_W) + (lane / PWN_WAVE_W);
+	// a wave64 covers 16 x 4 pixels: lane & 15 = column inside one half of the
+	// 32-wide tile (= one DPP row), lane >> 4 = row; waves 2k / 2k+1 are the
+	// left / right half of rows 4k .. 4k+3
+	const int half = wave & 1;
+	const int l16 = lane & 15;
+	const int lx = half * 16 + l16;
+	const int ly = (wave >> 1) * 4 + (lane >> 4);
 
 	Counters cnt = { 0, 0, 0, 0, 0 };
 
@@ -578,14 +600,39 @@ pwn_trace_kernel(pwn_trace_params P)
 		int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
 		int cx0 = tx * TILE_W;
 		int x = cx0 + lx, y = P.y0 + ty * TILE_H + ly;
+
+		// screen.h:12-18, in the order the reference build evaluates it:
+		// rayl = (cx*rdx + rayb) + y*rdy, then one "+= rdx" per pixel of the
+		// 32-wide tile up to and including this one.  The chain is sequential
+		// in fp32, but every pixel of a row walks the SAME chain, so the lanes of
+		// a DPP row build it systolically: after k rounds of
+		//     v[j] = v[j-1] + rdx      (lane 0 of the row keeps its value)
+		// lanes 0..k hold their final value.  All 64 lanes take part (also those
+		// outside the frame), so this sits in front of the bounds test.
+		V rayl = vadd<HAS_W>(vadd<HAS_W>(vscale<HAS_W>((float)cx0, rdx), rayb), vscale<HAS_W>((float)y, rdy));
+		if(half)
+		{
+#pragma unroll
+			for(int k = 0; k < 16; k++) rayl = vadd<HAS_W>(rayl, rdx);
+		}
+		rayl = vadd<HAS_W>(rayl, rdx);
+		{
+			const bool first = (l16 == 0);
+			V add;
+			add.x = first ? rayl.x : rdx.x; add.y = first ? rayl.y : rdx.y; add.z = first ? rayl.z : rdx.z;
+			add.w = HAS_W ? (first ? rayl.w : rdx.w) : 0.0f;
+#pragma unroll
+			for(int k = 1; k < 16; k++)
+			{
+				rayl.x = dpp_row_shr1(rayl.x) + add.x;
+				rayl.y = dpp_row_shr1(rayl.y) + add.y;
+				rayl.z = dpp_row_shr1(rayl.z) + add.z;
+				if constexpr(HAS_W) rayl.w = dpp_row_shr1(rayl.w) + add.w;
+			}
+		}
+
 		if(x < P.w && y < P.y1)
 		{
-			// screen.h:12-18, in the order the reference build evaluates it:
-			// rayl = (cx*rdx + rayb) + y*rdy, then one "+= rdx" per pixel of
-			// the 32-wide tile up to and including this one
-			V rayl = vadd<HAS_W>(vadd<HAS_W>(vscale<HAS_W>((float)cx0, rdx), rayb), vscale<HAS_W>((float)y, rdy));
-			for(int k = 0; k <= lx; k++) rayl = vadd<HAS_W>(rayl, rdx);
-
 			// screen.h:19-21 (uint32 wrap-around)
 			uint32_t seed = (uint32_t)x + (uint32_t)y * (uint32_t)y * ((uint32_t)P.w + 1u);
 			seed *= seed * seed;
