@@ -34,6 +34,24 @@ TRACE_BYTES_PER_PIXEL = 8      # colour 4 B + depth 4 B written; everything read
 FRAME_BYTES_PER_PIXEL = 20     # + blur: read colour 4 + read depth 4 + write final 4
 
 
+def pmc_traffic(kernel, w, h):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary
+    (tools/prof_pmc.sh + tools/pmc_summary.py -> profiles/pmc_latest.csv):
+    WRITE_SIZE + 2 x FETCH_SIZE, both in KiB, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950.  None if the summary is absent or
+    was taken at another frame size."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.csv")
+    try:
+        rows = [l.rstrip("\n").rsplit(",", 3) for l in open(path)]
+        meta = [l for l in open(path) if l.startswith("#")]
+        if not any("%dx%d" % (w, h) in m for m in meta):
+            return None
+        v = {r[1]: float(r[3]) for r in rows if len(r) == 4 and kernel in r[0] and "<true" not in r[0]}
+        return int((v["WRITE_SIZE"] + 2.0 * v["FETCH_SIZE"]) * 1024.0)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(w, h, cam, spheres, level_file, target_s=10.0):
     """The reference's own code (oracle/_ref, built from /root/reference with the
     reference's flags) timed on this host's cores; falls back to the port."""
@@ -199,7 +217,9 @@ def main():
         counters = {"rays_per_pixel": round(st["rays"] / (w * h), 4),
                     "steps_per_ray": round(st["steps"] / max(st["rays"], 1), 4),
                     "portal_crossings_per_ray": round(st["portals"] / max(st["rays"], 1), 4),
-                    "sphere_tests_per_ray": round(st["sphere_tests"] / max(st["rays"], 1), 4)}
+                    "sphere_tests_per_ray": round(st["sphere_tests"] / max(st["rays"], 1), 4),
+                    # lanes doing a cell step / lanes of the wave64s running the walk loop
+                    "walk_active_lane_fraction": round(st["steps"] / max(64 * st["wave_steps"], 1), 4)}
         best = 1e9
         for _ in range(5):
             t1 = time.perf_counter()
@@ -231,7 +251,10 @@ def main():
                        "level": args.level, "width": w, "height": h, "blur_passes": args.blur,
                        "parallelism": "rows/%d" % world + ("" if world == 1 else " + RCCL all-gather(pre-blur) + gather(strips)")},
             "roofline": {"bound": "hbm", "kernel": "pwn_trace_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": pmc_traffic("pwn_trace_kernel", w, h) if world == 1 else None,
+                         "traffic_unit": "bytes/launch (PMC WRITE_SIZE + 2*FETCH_SIZE, profiles/pmc_latest.csv)",
+                         "algorithmic_bytes_per_launch": TRACE_BYTES_PER_PIXEL * strip_pix,
                          "bytes_per_pixel": TRACE_BYTES_PER_PIXEL, "pixels_per_launch": strip_pix,
                          "avg_launch_ms": round(trace_ms, 4),
                          "note": "VALU/divergence-bound DDA: tables live in LDS, compulsory HBM traffic is the 8 B/pixel written"},

@@ -41,6 +41,8 @@ typedef struct pwn_stats
 	uint64_t portals;       /* portal crossings                 (trace.h:576) */
 	uint64_t sphere_tests;  /* sphere candidates tested         (trace.h:253) */
 	uint64_t exhausted;     /* rays that ran out of maxsteps    (trace.h:677) */
+	uint64_t wave_steps;    /* walk-loop iterations summed over wave64s: steps / (64 *
+	                           wave_steps) = active-lane fraction of the walk loop   */
 	float trace_ms;         /* trace kernel, HIP events                        */
 	float blur_ms;          /* blur kernel(s), HIP events                      */
 	float total_ms;         /* whole pwn_trace_screen_centred call incl. D2H   */
@@ -123,6 +125,8 @@ int pwn_get_stats(pwn_ctx *ctx, pwn_stats *out);
 #define PWN_PROBE_DIV    6  /* in = pairs (a,b), out = a/b */
 #define PWN_PROBE_FTOINT 7  /* in = 4 floats per output word (util.h:48-59) */
 #define PWN_PROBE_RANDFS 8  /* in = seed, out = randfs bits (util.h:13-16) */
+#define PWN_PROBE_SIN_OF_PAIR 9   /* sinf / cosf halves of the joint sincos used for */
+#define PWN_PROBE_COS_OF_PAIR 10  /* the floor normal (trace.h:45-46)                 */
 int pwn_probe(pwn_ctx *ctx, int op, const uint32_t *in, uint32_t *out, int n);
 
 #ifdef __cplusplus

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("PWNHIP_LIB") or os.path.join(_HERE, "libpwnhip.so")
 PWN_OK, PWN_EINVAL, PWN_ENODEV, PWN_ENOMEM, PWN_EIO, PWN_EHIP, PWN_ENOLEVEL, PWN_ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
 PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS = 1, 2
 (PROBE_RCP, PROBE_RSQRT, PROBE_SINF, PROBE_COSF, PROBE_EXPF, PROBE_SQRT, PROBE_DIV,
- PROBE_FTOINT, PROBE_RANDFS) = range(9)
+ PROBE_FTOINT, PROBE_RANDFS, PROBE_SIN_OF_PAIR, PROBE_COS_OF_PAIR) = range(11)
 
 
 class Portal(C.Structure):
@@ -25,7 +25,7 @@ class Sphere(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("portals", C.c_uint64),
-                ("sphere_tests", C.c_uint64), ("exhausted", C.c_uint64),
+                ("sphere_tests", C.c_uint64), ("exhausted", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("total_ms", C.c_float)]
 
 

@@ -208,6 +208,34 @@ __device__ __noinline__ float glibc_sincosf(float y, int which)
 	return __builtin_nanf("");
 }
 
+// sinf(y) and cosf(y) of the same argument (trace.h:45-46: the rippled floor
+// normal): one range reduction, both polynomials evaluated once and handed out
+// by quadrant.  Bit-identical to glibc_sincosf(y,0) / glibc_sincosf(y,1): in
+// sinf_poly(x*s, x*x, p, n) and sinf_poly(x*s, x*x, p, n^1) everything but the
+// choice of polynomial is shared.  x = sin, y = cos.
+__device__ __noinline__ float2 glibc_sincosf_both(float y)
+{
+	double x = (double)y;
+	if(abstop12(y) < abstop12(0x1.921FB6p-1f))
+	{
+		if(abstop12(y) < abstop12(0x1p-12f)) return make_float2(y, 1.0f);
+		double x2 = x * x;
+		return make_float2(sincos_poly(x, x2, 1.0, 0), sincos_poly(x, x2, 1.0, 1));
+	}
+	if(abstop12(y) < abstop12(120.0f))
+	{
+		double r = x * PWN_HPI_INV;
+		int n = ((int)r + 0x800000) >> 24;
+		x = fma(-(double)n, PWN_HPI, x);
+		double s = (n & 3) == 0 || (n & 3) == 3 ? 1.0 : -1.0;
+		double cs = (n & 2) ? -1.0 : 1.0;
+		double xs = x * s, x2 = x * x;
+		float ps = sincos_poly(xs, x2, cs, 0), pc = sincos_poly(xs, x2, cs, 1);
+		return (n & 1) ? make_float2(pc, ps) : make_float2(ps, pc);
+	}
+	return make_float2(glibc_sincosf(y, 0), glibc_sincosf(y, 1));
+}
+
 // ---- glibc 2.35 expf (e_expf.c, N = 32) -------------------------------------
 __device__ __forceinline__ uint64_t exp2f_tab(int i)
 {

@@ -128,6 +128,8 @@ __global__ void pwn_probe_kernel(int op, const uint32_t *in, uint32_t *out, int 
 		case 7: out[i] = col_pack(v4_set(__uint_as_float(in[4 * i]), __uint_as_float(in[4 * i + 1]),
 			__uint_as_float(in[4 * i + 2]), __uint_as_float(in[4 * i + 3]))); break;
 		case 8: { uint32_t s = in[i]; out[i] = __float_as_uint(lcg_fs(s)); break; }
+		case 9: out[i] = __float_as_uint(glibc_sincosf_both(__uint_as_float(in[i])).x); break;
+		case 10: out[i] = __float_as_uint(glibc_sincosf_both(__uint_as_float(in[i])).y); break;
 		default: out[i] = 0; break;
 	}
 }

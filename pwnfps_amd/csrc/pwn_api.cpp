@@ -390,11 +390,12 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	P.has_w = !(cam[3] == 0.0f && cam[7] == 0.0f && cam[11] == 0.0f && cam[15] == 1.0f);
 	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
 	// persistent grid: as many workgroups as are resident at once, each striding over tiles
-	int per_cu = pwn_trace_blocks_per_cu(P.blob_bytes, c->counters_on != 0, P.has_w != 0);
+	const size_t lds_bytes = P.blob_bytes;
+	int per_cu = pwn_trace_blocks_per_cu(lds_bytes, c->counters_on != 0, P.has_w != 0);
 	if(per_cu < 1) per_cu = 1;
 	int grid = c->num_cus * per_cu;
 	if(grid > P.tiles_total) grid = P.tiles_total;
-	HIPCHK(c, pwn_launch_trace(&P, grid, P.blob_bytes, c->counters_on != 0, stream));
+	HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	return PWN_OK;
 }
 
@@ -466,7 +467,7 @@ extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 		unsigned long long v[8];
 		HIPCHK(c, hipMemcpy(v, c->d_counters, sizeof(v), hipMemcpyDeviceToHost));
 		c->stats.rays = v[0]; c->stats.steps = v[1]; c->stats.portals = v[2];
-		c->stats.sphere_tests = v[3]; c->stats.exhausted = v[4];
+		c->stats.sphere_tests = v[3]; c->stats.exhausted = v[4]; c->stats.wave_steps = v[5];
 	}
 	*out = c->stats;
 	return PWN_OK;
@@ -515,7 +516,7 @@ extern "C" int pwn_screen_upscale(pwn_ctx *c, const uint32_t *sbuf, int scale, i
 
 extern "C" int pwn_probe(pwn_ctx *c, int op, const uint32_t *in, uint32_t *out, int n)
 {
-	if(c == NULL || in == NULL || out == NULL || n < 0 || op < 0 || op > PWN_PROBE_RANDFS) return PWN_EINVAL;
+	if(c == NULL || in == NULL || out == NULL || n < 0 || op < 0 || op > PWN_PROBE_COS_OF_PAIR) return PWN_EINVAL;
 	if(n == 0) return PWN_OK;
 	(void)hipSetDevice(c->device);
 	size_t per = (op == PWN_PROBE_DIV) ? 2 : (op == PWN_PROBE_FTOINT ? 4 : 1);

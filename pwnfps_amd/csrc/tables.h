@@ -2,7 +2,9 @@
 // (pwn_api.cpp) and the kernels.  The blob is built once per level / sphere
 // upload, lives in HBM, and is copied verbatim into LDS by every workgroup.
 //
-//   [0      .. 16912)  cellinfo u32 [65][65]     ONE word per cell for the walk loop.
+//   [0      .. 8192)   rcp      u32 [2048]        RCPPS table     (trace.h:231), see dev_math.h
+//   [8192   .. 16384)  rsqrt    u32 [2048]        RSQRTPS table   (util.h:43)
+//   [16384  .. 33296)  cellinfo u32 [65][65]     ONE word per cell for the walk loop.
 //                       Row/column 64 repeat row/column 0 WITHOUT the sphere bit:
 //                       get_cell's per-axis clamp-to-0 (util.h:151-158) becomes
 //                       min(c, 64) and the in-bounds test in front of the sphere
@@ -18,8 +20,6 @@
 //                       bit  15     PWN_C_PORTAL A..Z
 //                       bits 16..30 first entry of this cell's sphere list in binidx
 //                       bit  31     PWN_C_SPH    the cell holds >= 1 sphere
-//   [16912  .. 25104)  rcp      u32 [2048]        RCPPS table     (trace.h:231), see dev_math.h
-//   [25104  .. 33296)  rsqrt    u32 [2048]        RSQRTPS table   (util.h:43)
 //   [33296  .. 33504)  pmap     2 x u32 [26]      portals         (defs.h:87-94)
 //                       word0 = x1 | z1<<8 | x2<<16 | z2<<24   (0xff = -1)
 //                       word1 = rot12 | c1<<8 | c2<<16
@@ -30,9 +30,9 @@
 #include <stdint.h>
 
 #define PWN_GRID_PITCH 65u
-#define PWN_T_CELLINFO 0u
-#define PWN_T_RCP      16912u
-#define PWN_T_RSQ      25104u
+#define PWN_T_RCP      0u
+#define PWN_T_RSQ      8192u
+#define PWN_T_CELLINFO 16384u
 #define PWN_T_PMAP     33296u
 #define PWN_T_BINIDX   33504u
 

@@ -108,7 +108,7 @@ __device__ __forceinline__ float dpp_row_shr1(float v)
 enum { EV_NONE = 0, EV_WALL, EV_SPHERE, EV_EXHAUSTED };
 enum { BASE_CEIL = 0, BASE_FLOOR, BASE_WALL, BASE_MAGENTA };
 
-struct Counters { uint32_t rays, steps, portals, tests, exhausted; };
+struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps; };
 
 // One pixel = trace_ray(0, ...) of screen.h:22-24 with the recursion unrolled.
 template<bool COUNT, bool HAS_W>
@@ -190,7 +190,12 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #pragma unroll 1
 		do
 		{
-			if(COUNT) cnt.steps++;
+			if(COUNT)
+			{
+				cnt.steps++;
+				// once per wave and iteration: the lowest active lane
+				if((__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt.wsteps++;
+			}
 
 			// trace.h:252-296: spheres binned to this cell
 			if((int)cw < 0)
@@ -491,14 +496,19 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		if(depth >= REFLECT_MAX || refl == 0.0f) { vx = colx; vy = coly; vz = colz; vw = colw; break; }
 
 		// trace.h:9-75
+#ifdef PWN_DBG_NOFLOOR
+		if(false)
+#else
 		if(ldir == FYN)
+#endif
 		{
 			pos.y -= 0.001f;
 			const float pi = (float)3.14159265358979323846;
 			float ang = (pi * 2.0f) * (
 				(glibc_sincosf((pi * 0.5f) * pos.x, 0) + glibc_sincosf((pi * 0.5f) * pos.z, 1))
 				+ sec_current);
-			V n; n.x = glibc_sincosf(ang, 0); n.y = 38.0f; n.z = glibc_sincosf(ang, 1); n.w = 0.0f;
+			const float2 sc = glibc_sincosf_both(ang);
+			V n; n.x = sc.x; n.y = 38.0f; n.z = sc.y; n.w = 0.0f;
 			n = vnormalise<HAS_W>(L.rsq, n);
 			float rmul = -2.0f * ((ray.x * n.x + ray.y * n.y) + ray.z * n.z);
 			ray = vnormalise<HAS_W>(L.rsq, vadd<HAS_W>(vscale<HAS_W>(rmul, n), ray));
@@ -516,11 +526,13 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		else { ray.y = -ray.y; pos.y -= 0.001f; }
 
 		// trace.h:77-84: five draws, two discarded
+#ifndef PWN_DBG_NOLCG
 		ray.x += lcg_fs(seed) * REFLECT_BLUR_F;
 		ray.y += lcg_fs(seed) * REFLECT_BLUR_F;
 		lcg_next(seed);
 		ray.z += lcg_fs(seed) * REFLECT_BLUR_F;
 		lcg_next(seed);
+#endif
 
 		if(depth == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; sc0w = colw; }
 		else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; sc1w = colw; }
@@ -593,7 +605,7 @@ pwn_trace_kernel(pwn_trace_params P)
 	const int lx = half * 16 + l16;
 	const int ly = (wave >> 1) * 4 + (lane >> 4);
 
-	Counters cnt = { 0, 0, 0, 0, 0 };
+	Counters cnt = { 0, 0, 0, 0, 0, 0 };
 
 	for(int tile = blockIdx.x; tile < P.tiles_total; tile += gridDim.x)
 	{
@@ -650,8 +662,8 @@ pwn_trace_kernel(pwn_trace_params P)
 	if(COUNT)
 	{
 		// wave reduce, one atomic per wave and counter
-		unsigned long long v[5] = { cnt.rays, cnt.steps, cnt.portals, cnt.tests, cnt.exhausted };
-		for(int i = 0; i < 5; i++)
+		unsigned long long v[6] = { cnt.rays, cnt.steps, cnt.portals, cnt.tests, cnt.exhausted, cnt.wsteps };
+		for(int i = 0; i < 6; i++)
 		{
 			unsigned long long s = v[i];
 			for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);

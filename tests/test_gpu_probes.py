@@ -44,6 +44,9 @@ def test_libm_kat_and_oracle(R, oracle_lib):
     k = np.load(os.path.join(GOLD, "libm_kat.npz"))
     assert (R.probe(_lib.PROBE_SINF, k["x_sincos"]) == k["sinf"].view(np.uint32)).all()
     assert (R.probe(_lib.PROBE_COSF, k["x_sincos"]) == k["cosf"].view(np.uint32)).all()
+    # the joint form used for the floor normal (one reduction, both polynomials)
+    assert (R.probe(_lib.PROBE_SIN_OF_PAIR, k["x_sincos"]) == k["sinf"].view(np.uint32)).all()
+    assert (R.probe(_lib.PROBE_COS_OF_PAIR, k["x_sincos"]) == k["cosf"].view(np.uint32)).all()
     # the fixture was produced by glibc in the default MXCSR mode; the reference
     # executable (and the GPU build) flush results below FLT_MIN to zero
     ge = R.probe(_lib.PROBE_EXPF, k["x_exp"])
@@ -56,7 +59,8 @@ def test_libm_kat_and_oracle(R, oracle_lib):
     rng = np.random.default_rng(2)
     x = np.concatenate([rng.uniform(-130, 130, 60000), rng.standard_normal(20000) * 1e4,
                         10.0 ** rng.uniform(-30, 30, 20000), [0.0, -0.0, 0.785398, 0.7853982, 120.0, 119.99999]]).astype(np.float32)
-    for op, fn in ((_lib.PROBE_SINF, L.pwno_sinf), (_lib.PROBE_COSF, L.pwno_cosf)):
+    for op, fn in ((_lib.PROBE_SINF, L.pwno_sinf), (_lib.PROBE_COSF, L.pwno_cosf),
+                   (_lib.PROBE_SIN_OF_PAIR, L.pwno_sinf), (_lib.PROBE_COS_OF_PAIR, L.pwno_cosf)):
         want = np.array([fn(float(v)) for v in x], np.float32).view(np.uint32)
         assert (R.probe(op, x) == want).all()
     xe = np.concatenate([-rng.uniform(0, 105, 60000), rng.uniform(-1, 1, 5000), [0.0, -87.0, -88.0, -103.9, -104.0, -1e30]]).astype(np.float32)

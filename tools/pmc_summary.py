@@ -12,6 +12,9 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+# optional 2nd argument: a note (frame size, build) written as a leading comment line
+if len(sys.argv) > 2:
+    print("# " + sys.argv[2])
 acc = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)):
     with open(f) as fh:

@@ -40,6 +40,13 @@ if os.environ.get("PWN_HASH"):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle  # checker only
     hsh = oracle.fnv64(sb)
+if os.environ.get("PWN_COUNT"):
+    r.set_counters(True)
+    r.trace_screen_centred(cam, 0.0, want_z=False, sbuf=sb)
+    st = r.stats()
+    print("rays %d steps %d wave_steps %d -> steps/ray %.3f, wave iterations/ray-wave %.2f, walk lane fraction %.3f" % (
+        st["rays"], st["steps"], st["wave_steps"], st["steps"] / st["rays"], st["wave_steps"] / (st["rays"] / 64.0),
+        st["steps"] / (64.0 * st["wave_steps"])))
 print("%s %s %dx%d trace_ms min %.4f med %.4f blur_ms min %.4f fnv %s" % (
     os.path.basename(os.environ.get("PWNHIP_LIB", "libpwnhip.so")), level, w, h,
     min(tr), sorted(tr)[len(tr) // 2], min(bl), hsh))
