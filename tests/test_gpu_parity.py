@@ -313,3 +313,29 @@ def test_full_size_vs_compiled_reference():
     got, gz = r.trace_screen_centred(cam, 7.5)
     assert (got == want).all() and (gz.view(np.uint32) == wz.view(np.uint32)).all()
     r.close()
+
+
+
+def test_edge_scenes_vs_oracle(oracle_lib):
+    """Inputs at the edges of the domain (tests/edge_scenes.py), each against the
+    oracle bit for bit; the oracle itself is pinned on the same scenes against the
+    compiled reference by tests/test_oracle_vs_ref.py::test_edge_scenes."""
+    import edge_scenes
+    for sc in edge_scenes.scenes(oracle_lib.SPHERE_DTYPE):
+        O = oracle_lib.Oracle()
+        r = _renderer(sc.w, sc.h)
+        if sc.text is None:
+            O.load_level(level_path("pwnfps_level"))
+            r.level_load(level_path("pwnfps_level"))
+        else:
+            O.load_level_text(sc.text)
+            r.level_load_text(sc.text)
+        O.set_spheres(sc.spheres)
+        r.set_objects(sc.spheres)
+        blur = 1 if sc.w % 4 == 0 else 0
+        r.set_blur_passes(blur)
+        a, za = r.trace_screen_centred(sc.cam, sc.sec)
+        b, zb = O.render(sc.w, sc.h, sc.cam, sec=sc.sec, blur=blur)
+        assert (a == b).all(), (sc.name, sc.w, sc.h, int((a != b).sum()))
+        assert (za.view(np.uint32) == zb.view(np.uint32)).all(), (sc.name, sc.w, sc.h)
+        r.close()

@@ -84,3 +84,29 @@ def test_upscale_vs_reference(oracle_lib):
     src = rng.integers(0, 2 ** 32, (9, 20), dtype=np.uint32)
     for scale, pitch in ((1, 80), (2, 176), (3, 240), (4, 336)):
         assert (R.upscale(src, scale, pitch) == O.upscale(src, scale, pitch)).all()
+
+
+def test_edge_scenes(oracle_lib, tmp_path):
+    """The oracle on the edge-of-domain scenes that the GPU parity test uses,
+    against the reference's own code."""
+    import edge_scenes
+    R = refharness.RefHarness("tab")
+    for sc in edge_scenes.scenes(oracle_lib.SPHERE_DTYPE):
+        if not sc.ref_safe:
+            continue
+        O = oracle_lib.Oracle()
+        if sc.text is None:
+            path = level_path("pwnfps_level")
+        else:
+            path = str(tmp_path / (sc.name + ".txt"))
+            with open(path, "w", newline="") as f:
+                f.write(sc.text)
+        R.load_level(path)
+        O.load_level(path)
+        R.set_spheres(sc.spheres)
+        O.set_spheres(sc.spheres)
+        blur = 1 if sc.w % 4 == 0 else 0
+        a, za = R.render(sc.w, sc.h, sc.cam, sec=sc.sec, blur=blur)
+        b, zb = O.render(sc.w, sc.h, sc.cam, sec=sc.sec, blur=blur)
+        assert (a == b).all(), (sc.name, int((a != b).sum()))
+        assert (za.view(np.uint32) == zb.view(np.uint32)).all(), sc.name
