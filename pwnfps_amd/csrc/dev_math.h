@@ -33,19 +33,23 @@ __device__ __forceinline__ float v4_dot(v4 a, v4 b)
 //   rsqrt: index = (e odd ? 1024 : 0) + mantissa bits 22..13 (i.e. bits 23..13
 //          of the input as they lie);     result = 2^(190-h+flag) * 1.m12,
 //          h = (e+1)>>1
-// The LDS tables hold the result for e = 0 (rcp) / h = 0 (rsqrt) as a ready
-// fp32 bit pattern, built by pack_blob() from approx_tables.inc:
-//   rcp_tab[i]   = (254 - off_i) << 23 | m12_i << 11
-//   rsqrt_tab[j] = (191 - off_j) << 23 | m12_j << 11
-// so that a positive normal input costs an index, one ds_read_b32 and a
-// subtract in the exponent field.  Everything else takes the general path.
-__device__ __forceinline__ float tab_rcp(const uint32_t *tab, float x)
+// An LDS entry is the 13 bits flag<<12 | m12 (u16, built by pack_blob() from
+// approx_tables.inc); BASE + (entry << 11) is the result for e = 0 / h = 0 as an
+// fp32 bit pattern (BASE = 253<<23 resp. 190<<23), so a positive normal input
+// costs an index, one ds_read_u16, one shift-add and a subtract in the
+// exponent field.  Everything else takes the general path.
+#include "tables.h"
+__device__ __forceinline__ uint32_t rcp_entry(const uint16_t *tab, uint32_t a)
+{
+	return PWN_RCP_BASE + ((uint32_t)tab[(a >> 12) & 2047u] << 11);
+}
+__device__ __forceinline__ float tab_rcp(const uint16_t *tab, float x)
 {
 	uint32_t b = __float_as_uint(x);
 	uint32_t sign = b & 0x80000000u, a = b & 0x7fffffffu;
 	uint32_t r;
 	if(a - 0x00800000u < 0x7e000000u)          // 1 <= e <= 252: result is a normal number
-		r = sign | (tab[(a >> 12) & 2047u] - (a & 0x7f800000u));
+		r = sign | (rcp_entry(tab, a) - (a & 0x7f800000u));
 	else
 	{
 		uint32_t e = a >> 23, m = a & 0x7fffffu;
@@ -54,7 +58,7 @@ __device__ __forceinline__ float tab_rcp(const uint32_t *tab, float x)
 		else
 		{
 			// e = 253, 254: the result is denormal (flushed) unless the entry's exponent allows it
-			uint32_t t = tab[(a >> 12) & 2047u];
+			uint32_t t = rcp_entry(tab, a);
 			int re = (int)(t >> 23) - (int)e;
 			r = re <= 0 ? sign : (sign | (t - (e << 23)));
 		}
@@ -62,18 +66,18 @@ __device__ __forceinline__ float tab_rcp(const uint32_t *tab, float x)
 	return __uint_as_float(r);
 }
 // x >= EPSILON is known (ray components after the clamp of trace.h:220-222)
-__device__ __forceinline__ float tab_rcp_pos(const uint32_t *tab, float x)
+__device__ __forceinline__ float tab_rcp_pos(const uint16_t *tab, float x)
 {
 	uint32_t a = __float_as_uint(x);
-	return __uint_as_float(tab[(a >> 12) & 2047u] - (a & 0x7f800000u));
+	return __uint_as_float(rcp_entry(tab, a) - (a & 0x7f800000u));
 }
 
-__device__ __forceinline__ float tab_rsqrt(const uint32_t *tab, float x)
+__device__ __forceinline__ float tab_rsqrt(const uint16_t *tab, float x)
 {
 	uint32_t b = __float_as_uint(x);
 	uint32_t r;
 	if(b - 0x00800000u < 0x7f000000u)          // positive normal
-		r = tab[(b >> 13) & 2047u] - (((b + 0x00800000u) >> 1) & 0x7f800000u);
+		r = (PWN_RSQ_BASE + ((uint32_t)tab[(b >> 13) & 2047u] << 11)) - (((b + 0x00800000u) >> 1) & 0x7f800000u);
 	else
 	{
 		uint32_t sign = b & 0x80000000u, e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
@@ -85,7 +89,7 @@ __device__ __forceinline__ float tab_rsqrt(const uint32_t *tab, float x)
 	return __uint_as_float(r);
 }
 
-__device__ __forceinline__ v4 v4_normalise(const uint32_t *rsq, v4 a)
+__device__ __forceinline__ v4 v4_normalise(const uint16_t *rsq, v4 a)
 {
 	return v4_scale(tab_rsqrt(rsq, v4_dot(a, a)), a);
 }

@@ -166,8 +166,16 @@ extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stre
 	hipLaunchKernelGGL(pwn_blur_kernel, grid, dim3(256), 0, stream, *P);
 #else
 	const size_t lds = (size_t)BLUR_PITCH * BLUR_LH * sizeof(uint32_t);
-	hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-	if(e != hipSuccess) return e;
+	static bool lds_mark[64];
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	bool &lds_set = lds_mark[dev & 63];
+	if(!lds_set)
+	{
+		hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if(e != hipSuccess) return e;
+		lds_set = true;
+	}
 	const int ntiles = ((P->w + BLUR_TW - 1) / BLUR_TW) * ((P->y1 - P->y0 + BLUR_TH - 1) / BLUR_TH);
 	dim3 grid(((ntiles + 7) / 8) * 8);
 	hipLaunchKernelGGL(pwn_blur_tiled_kernel, grid, dim3(BLUR_THREADS), lds, stream, *P);
@@ -202,15 +210,15 @@ extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int
 
 // --------------------------------------------------------------- probes ----
 // Device-side known-answer access to the arithmetic primitives (pwnhip.h
-// PWN_PROBE_*).  tabs = the rcp+rsqrt part of the blob (2 x 2048 u32).
-__global__ void pwn_probe_kernel(int op, const uint32_t *in, uint32_t *out, int n, const uint32_t *tabs)
+// PWN_PROBE_*).  tabs = the rcp+rsqrt part of the blob (2 x 2048 u16).
+__global__ void pwn_probe_kernel(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs)
 {
-	__shared__ uint32_t t[4096];
+	__shared__ uint16_t t[4096];
 	for(int i = threadIdx.x; i < 4096; i += blockDim.x) t[i] = tabs[i];
 	__syncthreads();
 	int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if(i >= n) return;
-	const uint32_t *rcp = t, *rsq = t + 2048;
+	const uint16_t *rcp = t, *rsq = t + 2048;
 	switch(op)
 	{
 		case 0: out[i] = __float_as_uint(tab_rcp(rcp, __uint_as_float(in[i]))); break;
@@ -229,7 +237,7 @@ __global__ void pwn_probe_kernel(int op, const uint32_t *in, uint32_t *out, int 
 	}
 }
 
-extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint32_t *tabs, hipStream_t stream)
+extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream)
 {
 	hipLaunchKernelGGL(pwn_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, in, out, n, tabs);
 	return hipGetLastError();

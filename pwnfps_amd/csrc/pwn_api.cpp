@@ -30,7 +30,7 @@ extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w)
 extern "C" int pwn_trace_tile_h(void);
 extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
-extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint32_t *tabs, hipStream_t stream);
+extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
 
 // LDS budget for the table blob: leave room so that at least two workgroups
 // fit per CU (160 KiB LDS per CU on gfx950)
@@ -53,6 +53,7 @@ struct pwn_ctx
 	uint8_t *d_blob; size_t d_blob_cap;
 	uint32_t off_sph;
 	bool blob_dirty;
+	size_t occ_lds[4]; int occ_blocks[4];    // cached occupancy query per kernel variant
 
 	uint32_t *d_pre, *d_out;         // pre-blur ("tsbuf") and final ("sbuf") frames
 	float *d_z;
@@ -109,6 +110,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->d_blob = NULL; c->d_blob_cap = 0; c->blob_dirty = true; c->off_sph = 0;
 	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL;
 	c->d_scratch = NULL; c->scratch_cap = 0;
+	for(int i = 0; i < 4; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
 	c->stream = NULL;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));
@@ -181,19 +183,17 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 
 // ---- level / spheres --------------------------------------------------------
 
-// RCPPS / RSQRTPS tables in the form the kernels read (dev_math.h): the result
-// for a zero exponent field as a ready fp32 pattern.  approx_tables.inc entry:
-// bit 12 = exponent offset, bits 11..0 = result mantissa bits 22..11.
-static void expand_tables(uint32_t *rcp, uint32_t *rsq)
+// RCPPS / RSQRTPS tables in the form the kernels read (dev_math.h, tables.h):
+// entry = (1 - exponent offset) << 12 | result mantissa bits 22..11.
+// approx_tables.inc entry: bit 12 = exponent offset, bits 11..0 = that mantissa.
+static void expand_tables(uint16_t *rcp, uint16_t *rsq)
 {
 	for(int i = 0; i < 2048; i++)
 	{
-		uint32_t t = pwn_host_rcp_tab[i];
-		rcp[i] = ((254u - (t >> 12)) << 23) | ((t & 0xfffu) << 11);
+		rcp[i] = (uint16_t)(pwn_host_rcp_tab[i] ^ 0x1000u);
 		// kernel index = input bits 23..13: bit 10 = low exponent bit; the generated
 		// table is indexed by parity of (e - 127), i.e. with that bit flipped
-		uint32_t u = pwn_host_rsqrt_tab[i ^ 0x400];
-		rsq[i] = ((191u - (u >> 12)) << 23) | ((u & 0xfffu) << 11);
+		rsq[i] = (uint16_t)(pwn_host_rsqrt_tab[i ^ 0x400] ^ 0x1000u);
 	}
 }
 
@@ -233,7 +233,7 @@ static int pack_blob(pwn_ctx *c)
 	// never with spheres (the sphere loop runs for in-grid cells only, trace.h:252)
 	for(int z = 0; z < 64; z++) ci[z * PWN_GRID_PITCH + 64] = ci[z * PWN_GRID_PITCH] & ~(PWN_C_SPH | 0x7fff0000u);
 	for(int x = 0; x <= 64; x++) ci[64 * PWN_GRID_PITCH + x] = ci[x] & ~(PWN_C_SPH | 0x7fff0000u);
-	expand_tables((uint32_t *)(b + PWN_T_RCP), (uint32_t *)(b + PWN_T_RSQ));
+	expand_tables((uint16_t *)(b + PWN_T_RCP), (uint16_t *)(b + PWN_T_RSQ));
 	uint32_t *pm = (uint32_t *)(b + PWN_T_PMAP);
 	for(int i = 0; i < 26; i++)
 	{
@@ -391,7 +391,14 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
 	// persistent grid: as many workgroups as are resident at once, each striding over tiles
 	const size_t lds_bytes = P.blob_bytes;
-	int per_cu = pwn_trace_blocks_per_cu(lds_bytes, c->counters_on != 0, P.has_w != 0);
+	// resident workgroups per CU depend on (LDS bytes, kernel variant) only: ask once per combination
+	const int variant = (c->counters_on ? 2 : 0) | (P.has_w ? 1 : 0);
+	if(c->occ_lds[variant] != lds_bytes)
+	{
+		c->occ_blocks[variant] = pwn_trace_blocks_per_cu(lds_bytes, c->counters_on != 0, P.has_w != 0);
+		c->occ_lds[variant] = lds_bytes;
+	}
+	int per_cu = c->occ_blocks[variant];
 	if(per_cu < 1) per_cu = 1;
 	int grid = c->num_cus * per_cu;
 	if(grid > P.tiles_total) grid = P.tiles_total;
@@ -521,14 +528,14 @@ extern "C" int pwn_probe(pwn_ctx *c, int op, const uint32_t *in, uint32_t *out, 
 	(void)hipSetDevice(c->device);
 	size_t per = (op == PWN_PROBE_DIV) ? 2 : (op == PWN_PROBE_FTOINT ? 4 : 1);
 	size_t in_bytes = (size_t)n * per * 4, out_bytes = (size_t)n * 4;
-	int rc = ensure_scratch(c, in_bytes + out_bytes + 16384);
+	int rc = ensure_scratch(c, in_bytes + out_bytes + 8192);
 	if(rc != PWN_OK) return rc;
 	uint8_t *base = (uint8_t *)c->d_scratch;
-	uint32_t *d_tabs = (uint32_t *)base;
-	uint32_t *d_in = (uint32_t *)(base + 16384), *d_out = (uint32_t *)(base + 16384 + in_bytes);
-	std::vector<uint32_t> tabs(4096);
+	uint16_t *d_tabs = (uint16_t *)base;
+	uint32_t *d_in = (uint32_t *)(base + 8192), *d_out = (uint32_t *)(base + 8192 + in_bytes);
+	std::vector<uint16_t> tabs(4096);
 	expand_tables(tabs.data(), tabs.data() + 2048);
-	HIPCHK(c, hipMemcpy(d_tabs, tabs.data(), 16384, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(d_tabs, tabs.data(), 8192, hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, pwn_launch_probe(op, d_in, d_out, n, d_tabs, c->stream));
 	HIPCHK(c, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));

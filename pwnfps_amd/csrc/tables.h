@@ -2,9 +2,9 @@
 // (pwn_api.cpp) and the kernels.  The blob is built once per level / sphere
 // upload, lives in HBM, and is copied verbatim into LDS by every workgroup.
 //
-//   [0      .. 8192)   rcp      u32 [2048]        RCPPS table     (trace.h:231), see dev_math.h
-//   [8192   .. 16384)  rsqrt    u32 [2048]        RSQRTPS table   (util.h:43)
-//   [16384  .. 33296)  cellinfo u32 [65][65]     ONE word per cell for the walk loop.
+//   [0      .. 4096)   rcp      u16 [2048]        RCPPS table     (trace.h:231), see dev_math.h
+//   [4096   .. 8192)   rsqrt    u16 [2048]        RSQRTPS table   (util.h:43)
+//   [8192   .. 25104)  cellinfo u32 [65][65]     ONE word per cell for the walk loop.
 //                       Row/column 64 repeat row/column 0 WITHOUT the sphere bit:
 //                       get_cell's per-axis clamp-to-0 (util.h:151-158) becomes
 //                       min(c, 64) and the in-bounds test in front of the sphere
@@ -20,10 +20,10 @@
 //                       bit  15     PWN_C_PORTAL A..Z
 //                       bits 16..30 first entry of this cell's sphere list in binidx
 //                       bit  31     PWN_C_SPH    the cell holds >= 1 sphere
-//   [33296  .. 33504)  pmap     2 x u32 [26]      portals         (defs.h:87-94)
+//   [25104  .. 25312)  pmap     2 x u32 [26]      portals         (defs.h:87-94)
 //                       word0 = x1 | z1<<8 | x2<<16 | z2<<24   (0xff = -1)
 //                       word1 = rot12 | c1<<8 | c2<<16
-//   [33504  .. +2*nbin pad 16)  binidx u16        per-cell sphere lists (level.h:64-81),
+//   [25312  .. +2*nbin pad 16)  binidx u16        per-cell sphere lists (level.h:64-81),
 //                                                 object order, each list closed by 0xffff
 //   [...    .. +32*nsph)        spheres 8 x f32   r, refl, x, y, z, cb, cg, cr
 #pragma once
@@ -31,10 +31,15 @@
 
 #define PWN_GRID_PITCH 65u
 #define PWN_T_RCP      0u
-#define PWN_T_RSQ      8192u
-#define PWN_T_CELLINFO 16384u
-#define PWN_T_PMAP     33296u
-#define PWN_T_BINIDX   33504u
+#define PWN_T_RSQ      4096u
+#define PWN_T_CELLINFO 8192u
+#define PWN_T_PMAP     25104u
+#define PWN_T_BINIDX   25312u
+
+// table entry -> fp32 pattern of the result for a zero exponent field (dev_math.h):
+// entry = (1 - exponent offset) << 12 | result mantissa bits 22..11
+#define PWN_RCP_BASE   0x7e800000u   /* 253 << 23 */
+#define PWN_RSQ_BASE   0x5f000000u   /* 190 << 23 */
 
 #define PWN_C_ROOM   0x0100u
 #define PWN_C_ROOM2  0x0200u
@@ -80,7 +85,7 @@ struct pwn_trace_params
 	float rayb[4], rdx[4], rdy[4], from[4];   // screen.h:43-57
 	float sec_current;                        // defs.h:23
 	int w, h, y0, y1;
-	int tiles_x, tiles_total;
+	int tiles_x, tiles_total;                 // 32 x TILE_H pixel tiles: per row, in all
 	uint32_t blob_bytes, off_sph;
 	uint32_t *sbuf;                           // full frame, pitch w
 	float *zbuf;                              // full frame, pitch w

@@ -48,7 +48,7 @@ enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
 struct Lds
 {
 	const uint32_t *cellinfo;
-	const uint32_t *rcp, *rsq;
+	const uint16_t *rcp, *rsq;
 	const uint32_t *pmap;
 	const uint16_t *binidx;
 	const float *sph;
@@ -94,7 +94,7 @@ template<bool W> __device__ __forceinline__ Vec<W> vsub(const Vec<W> &a, const V
 	return r;
 }
 // util.h:32-46
-template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const uint32_t *rsq, const Vec<W> &a)
+template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const uint16_t *rsq, const Vec<W> &a)
 {
 	return vscale<W>(tab_rsqrt(rsq, dot3<W>(a, a)), a);
 }
@@ -117,10 +117,14 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	float &dist, bool &have_dist, Counters &cnt)
 {
 	typedef Vec<HAS_W> V;
-	float icx = 1.0f, icy = 1.0f, icz = 1.0f, icw = 1.0f;     // icol (screen.h:24)
+	// icol (screen.h:24).  Its w lane, and the w lane of every surface colour, is
+	// x * 0.0f (COL_* have a = 0, defs.h:17-19; spheres get b,g,r only, script.h:30-32):
+	// +-0 for any finite input, and the sign of a zero never reaches a pixel, so the
+	// w lanes of icol and of the composite stack are not kept.
+	float icx = 1.0f, icy = 1.0f, icz = 1.0f;
 	float st_refl0 = 0.0f, st_refl1 = 0.0f, st_fog0 = 0.0f, st_fog1 = 0.0f;
-	float sc0x = 0.0f, sc0y = 0.0f, sc0z = 0.0f, sc0w = 0.0f;
-	float sc1x = 0.0f, sc1y = 0.0f, sc1z = 0.0f, sc1w = 0.0f;
+	float sc0x = 0.0f, sc0y = 0.0f, sc0z = 0.0f;
+	float sc1x = 0.0f, sc1y = 0.0f, sc1z = 0.0f;
 	int depth = 0;
 	float vx, vy, vz, vw;
 	have_dist = false;
@@ -130,11 +134,14 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	{
 		// ------------------------------------------------ trace.h:186-248
 		float cdist = 0.0f, fog = 0.0f;
-		float aux_dist = -1.0f, aux_refl = 0.25f;
+		// nearest sphere candidate (trace.h:193-199): distance, hit point, which sphere and
+		// its diffuse factor; normal, colour and reflectivity are rebuilt from these when
+		// the hit is committed
+		float aux_dist = -1.0f, aux_diff = 0.0f;
+		uint32_t aux_idx = 0;
 		V aux_pos, aux_norm;
 		aux_pos.x = aux_pos.y = aux_pos.z = aux_pos.w = 0.0f;
 		aux_norm = aux_pos;
-		float acx = 1.0f, acy = 1.0f, acz = 1.0f;
 		if(COUNT) cnt.rays++;
 
 		V pos = from;
@@ -227,13 +234,12 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 								V d;
 								d.x = aux_pos.x - s0.z; d.y = aux_pos.y - s0.w; d.z = aux_pos.z - s1.x;
 								if constexpr(HAS_W) d.w = aux_pos.w - 1.0f; else d.w = 0.0f;
-								aux_norm = vnormalise<HAS_W>(L.rsq, d);
-								float diff = -dot3<HAS_W>(ray, aux_norm);
+								const V nrm = vnormalise<HAS_W>(L.rsq, d);
+								float diff = -dot3<HAS_W>(ray, nrm);
 								if(diff < 0.0f) diff = 0.0f;
 								const float amb = 0.2f;
-								aux_refl = s0.y;
-								diff = amb + (1.0f - amb) * diff;
-								acx = diff * s1.y; acy = diff * s1.z; acz = diff * s1.w;
+								aux_diff = amb + (1.0f - amb) * diff;
+								aux_idx = si;
 							}
 						}
 					}
@@ -464,7 +470,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		}
 		if(depth == 0) { dist = (ev == EV_SPHERE ? aux_dist : cdist); have_dist = true; }
 
-		float colx, coly, colz, colw, refl;
+		float colx, coly, colz, refl;
 		if(ev == EV_WALL)
 		{
 			// trace.h:108-154
@@ -480,20 +486,25 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			const float amb = 0.1f;
 			diffuse = (1.0f - amb) * diffuse + amb;
 			colx = diffuse * (icx * bx); coly = diffuse * (icy * by); colz = diffuse * (icz * bz);
-			colw = diffuse * (icw * 0.0f);
 			refl = (ldir == FYN ? 0.7f : 0.25f);
 		}
 		else
 		{
-			colx = acx; coly = acy; colz = acz;
-			colw = 0.0f;                                   // diff * sph.col.a with a == 0 (script.h:30-32), diff >= 0.2
-			refl = aux_refl;
+			// trace.h:283-291 for the committed sphere
+			const float4 *sp = (const float4 *)(L.sph + 8 * aux_idx);
+			const float4 s0 = sp[0], s1 = sp[1];
+			V d;
+			d.x = aux_pos.x - s0.z; d.y = aux_pos.y - s0.w; d.z = aux_pos.z - s1.x;
+			if constexpr(HAS_W) d.w = aux_pos.w - 1.0f; else d.w = 0.0f;
+			aux_norm = vnormalise<HAS_W>(L.rsq, d);
+			colx = aux_diff * s1.y; coly = aux_diff * s1.z; colz = aux_diff * s1.w;
+			refl = s0.y;
 			ldir = -1;
 			pos = aux_pos;
 		}
 
 		// trace.h:3-7
-		if(depth >= REFLECT_MAX || refl == 0.0f) { vx = colx; vy = coly; vz = colz; vw = colw; break; }
+		if(depth >= REFLECT_MAX || refl == 0.0f) { vx = colx; vy = coly; vz = colz; vw = 0.0f; break; }
 
 		// trace.h:9-75
 #ifdef PWN_DBG_NOFLOOR
@@ -534,10 +545,10 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		lcg_next(seed);
 #endif
 
-		if(depth == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; sc0w = colw; }
-		else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; sc1w = colw; }
+		if(depth == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; }
+		else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; }
 		depth++;
-		icx = colx; icy = coly; icz = colz; icw = colw;
+		icx = colx; icy = coly; icz = colz;
 		from = pos;
 		iray = ray;
 	}
@@ -546,7 +557,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	if(depth >= 2)
 	{
 		const float r1 = st_refl1, q1 = 1.0f - st_refl1;
-		vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw + q1 * sc1w;
+		vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
 		if(st_fog1 != 0.0f)
 		{
 			float f = glibc_expf(-0.6f * st_fog1), g = 1.0f - f;
@@ -556,7 +567,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	if(depth >= 1)
 	{
 		const float r0 = st_refl0, q0 = 1.0f - st_refl0;
-		vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw + q0 * sc0w;
+		vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw;
 		if(st_fog0 != 0.0f)
 		{
 			float f = glibc_expf(-0.6f * st_fog0), g = 1.0f - f;
@@ -583,8 +594,8 @@ pwn_trace_kernel(pwn_trace_params P)
 
 	Lds L;
 	L.cellinfo = (const uint32_t *)(lds_raw + PWN_T_CELLINFO);
-	L.rcp = (const uint32_t *)(lds_raw + PWN_T_RCP);
-	L.rsq = (const uint32_t *)(lds_raw + PWN_T_RSQ);
+	L.rcp = (const uint16_t *)(lds_raw + PWN_T_RCP);
+	L.rsq = (const uint16_t *)(lds_raw + PWN_T_RSQ);
 	L.pmap = (const uint32_t *)(lds_raw + PWN_T_PMAP);
 	L.binidx = (const uint16_t *)(lds_raw + PWN_T_BINIDX);
 	L.sph = (const float *)(lds_raw + P.off_sph);
@@ -607,6 +618,11 @@ pwn_trace_kernel(pwn_trace_params P)
 
 	Counters cnt = { 0, 0, 0, 0, 0, 0 };
 
+	// Persistent workgroups, static split: workgroup b takes tiles b, b + gridDim.x, ...
+	// Measured alternatives that lost: a ticket counter (one atomic per wave and 128
+	// pixels serialises at ~4 ns per atomic: +50 % at 4K) and a pseudo-random
+	// tile permutation (-2 %; it does not shorten the tail of mirror-hall frames,
+	// which is one wave walking 1000 cells, a dependent chain).
 	for(int tile = blockIdx.x; tile < P.tiles_total; tile += gridDim.x)
 	{
 		int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
@@ -675,9 +691,19 @@ pwn_trace_kernel(pwn_trace_params P)
 template<bool COUNT, bool HAS_W>
 static hipError_t launch_variant(const pwn_trace_params *P, int grid, size_t lds_bytes, hipStream_t stream)
 {
-	hipError_t e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W>,
-		hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-	if(e != hipSuccess) return e;
+	// the dynamic-LDS limit is a per-function attribute: raise it only when the blob grew
+	// (high-water mark per device and variant)
+	static size_t lds_mark[64];
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	size_t &lds_set = lds_mark[dev & 63];
+	if(lds_bytes > lds_set)
+	{
+		hipError_t e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W>,
+			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		if(e != hipSuccess) return e;
+		lds_set = lds_bytes;
+	}
 	hipLaunchKernelGGL((pwn_trace_kernel<COUNT, HAS_W>), dim3(grid), dim3(PWN_BLOCK), lds_bytes, stream, *P);
 	return hipGetLastError();
 }
