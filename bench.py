@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--level", default="pwnfps_level")
     ap.add_argument("--blur", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: finish each frame before starting the next")
     args = ap.parse_args()
 
     import torch
@@ -123,11 +124,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libpwnhip.so has no CPU fallback")
+    # test hooks (a 1-GPU box cannot run RCCL with 2 ranks): PWN_BENCH_ONE_DEVICE=1 puts every
+    # rank on device 0 and PWN_BENCH_BACKEND=gloo swaps the transport; the driver sets neither
+    if os.environ.get("PWN_BENCH_ONE_DEVICE"):
+        local = 0
+    backend = os.environ.get("PWN_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     w, h = args.width, args.height
     level_file = os.path.join(GOLD, "levels", args.level + ".txt")
@@ -167,15 +176,26 @@ def main():
             ev[i][1].record()
     be.trace_rows = timed_trace
 
+    # N = 1: frames back to back.  N > 1: frames in flight (dist.py): the RCCL
+    # all-gather / gather of frame i overlap the kernels of frame i+1; all K frames
+    # are complete (flush) before the closing barrier.
+    pipelined = world > 1 and args.blur <= 1 and not args.no_pipeline
     out = None
     for _ in range(args.warmup):
         out = fr.render(cam, sec)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        slot["i"] = i
-        out = fr.render(cam, sec)
-    slot["i"] = -1
+    if pipelined:
+        for i in range(args.steps):
+            slot["i"] = i
+            fr.submit(cam, sec)
+        slot["i"] = -1
+        out = fr.flush()
+    else:
+        for i in range(args.steps):
+            slot["i"] = i
+            out = fr.render(cam, sec)
+        slot["i"] = -1
     barrier()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -249,7 +269,8 @@ def main():
             "config": {"workload": "pwnfps level.txt scene (14 game.lua spheres, spawn pose, sec_current=0), "
                                    "%dx%d, POSTPROC_BLUR=%d, one frame per step" % (w, h, args.blur),
                        "level": args.level, "width": w, "height": h, "blur_passes": args.blur,
-                       "parallelism": "rows/%d" % world + ("" if world == 1 else " + RCCL all-gather(pre-blur) + gather(strips)")},
+                       "parallelism": "rows/%d" % world + ("" if world == 1 else " + RCCL all-gather(pre-blur) + gather(strips)"
+                                                            + (", 2 frames in flight" if pipelined else ""))},
             "roofline": {"bound": "hbm", "kernel": "pwn_trace_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic("pwn_trace_kernel", w, h) if world == 1 else None,

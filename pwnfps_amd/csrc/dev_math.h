@@ -15,6 +15,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// the libm restatements are real functions by default (register pressure, code size)
+#ifdef PWN_INLINE_LIBM
+#define PWN_LIBM_ATTR __forceinline__
+#else
+#define PWN_LIBM_ATTR __noinline__
+#endif
+
 struct v4 { float x, y, z, w; };
 
 __device__ __forceinline__ v4 v4_set(float x, float y, float z, float w) { v4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
@@ -170,7 +177,7 @@ __device__ __forceinline__ uint32_t inv_pio4_word(int i)
 }
 
 // which = 0: sinf, 1: cosf
-__device__ __noinline__ float glibc_sincosf(float y, int which)
+__device__ PWN_LIBM_ATTR float glibc_sincosf(float y, int which)
 {
 	double x = (double)y;
 	int n;
@@ -217,7 +224,7 @@ __device__ __noinline__ float glibc_sincosf(float y, int which)
 // by quadrant.  Bit-identical to glibc_sincosf(y,0) / glibc_sincosf(y,1): in
 // sinf_poly(x*s, x*x, p, n) and sinf_poly(x*s, x*x, p, n^1) everything but the
 // choice of polynomial is shared.  x = sin, y = cos.
-__device__ __noinline__ float2 glibc_sincosf_both(float y)
+__device__ PWN_LIBM_ATTR float2 glibc_sincosf_both(float y)
 {
 	double x = (double)y;
 	if(abstop12(y) < abstop12(0x1.921FB6p-1f))
@@ -255,7 +262,7 @@ __device__ __forceinline__ uint64_t exp2f_tab(int i)
 	return t[i];
 }
 
-__device__ __noinline__ float glibc_expf(float x)
+__device__ PWN_LIBM_ATTR float glibc_expf(float x)
 {
 	const double N = 32.0;
 	const double InvLn2N = 0x1.71547652b82fep+0 * N;

@@ -123,6 +123,80 @@ class RowTiledFrame:
             dist.gather(self._strip(self.z), None, dst=0, group=self.group)
         return None
 
+    # -- frames in flight ------------------------------------------------------
+    # With world > 1 a frame is trace -> all-gather -> blur -> gather, and at 4K the
+    # two collectives take longer than the kernels.  A renderer presents frames in
+    # a stream, so consecutive frames are overlapped: while the collectives of
+    # frame i are on the wire (RCCL's own stream), the kernels of frame i+1 run.
+    # Every buffer exists twice (slot = frame & 1); hazards:
+    #   pre[s]  trace_i writes own strip -> all-gather_i fills the rest -> blur_i reads;
+    #           next writer trace_{i+2} is issued after blur_i on the same stream
+    #   out[s]  blur_i writes own strip -> gather_i reads; next writer blur_{i+2}
+    #           waits for gather_i first
+    #   z[s]    trace_i writes, blur_i reads (same stream)
+    # All ranks issue the collectives in the same order: AG_0, AG_1, G_0, AG_2, G_1, ...
+    def _slots(self):
+        if getattr(self, "_slot", None) is None:
+            mk = lambda t: torch.zeros_like(t)
+            self._slot = [dict(pre=self.pre, out=self.out, z=self.z, ag=None, g=None),
+                          dict(pre=mk(self.pre), out=mk(self.out), z=mk(self.z), ag=None, g=None)]
+            self._n = 0            # frames submitted
+            self._pending = None   # slot index of the frame traced but not yet blurred
+        return self._slot
+
+    def _finish(self, k):
+        """blur + gather of the frame in slot k (its all-gather is in flight)."""
+        sl = self._slot[k]
+        if sl["g"] is not None:            # gather of the frame that used out[k] two submits ago
+            sl["g"].wait()
+            sl["g"] = None
+        cur = sl["pre"]
+        if self.blur_passes:
+            if sl["ag"] is not None:
+                sl["ag"].wait()
+                sl["ag"] = None
+            self.backend.blur_rows(self.y0, self.y1, sl["pre"], sl["z"], sl["out"])
+            cur = sl["out"]
+        if self.world == 1:
+            return cur
+        if self.rank == 0:
+            parts = [self._strip(self.final, r) for r in range(self.world)]
+            sl["g"] = dist.gather(self._strip(cur), parts, dst=0, group=self.group, async_op=True)
+        else:
+            sl["g"] = dist.gather(self._strip(cur), None, dst=0, group=self.group, async_op=True)
+        return self.final
+
+    def submit(self, cam, sec=0.0):
+        """Enqueue one frame (POSTPROC_BLUR 0 or 1).  Returns None; the frame is
+        complete after the next submit() or after flush()."""
+        if self.blur_passes > 1:
+            raise ValueError("frames in flight support blur_passes 0 or 1")
+        slots = self._slots()
+        k = self._n & 1
+        sl = slots[k]
+        cam = np.ascontiguousarray(cam, np.float32).reshape(16)
+        self.backend.trace_rows(cam, float(sec), self.y0, self.y1, sl["pre"], sl["z"])
+        if self.world > 1 and self.blur_passes:
+            sl["ag"] = dist.all_gather_into_tensor(sl["pre"], self._strip(sl["pre"]), group=self.group, async_op=True)
+        if self._pending is not None:
+            self._finish(self._pending)
+        self._pending = k
+        self._n += 1
+
+    def flush(self):
+        """Complete everything in flight.  Returns the last frame on rank 0 (device
+        tensor, rows [0,h) valid; for world == 1 on that one rank), None elsewhere."""
+        slots = self._slots()
+        res = None
+        if self._pending is not None:
+            res = self._finish(self._pending)
+            self._pending = None
+        for sl in slots:
+            if sl["g"] is not None:
+                sl["g"].wait()
+                sl["g"] = None
+        return res if (self.rank == 0) else None
+
     def to_host(self, t):
         """uint32 numpy view of rows [0,h) of a frame tensor."""
         return t[:self.h].cpu().numpy().view(np.uint32)

@@ -63,9 +63,27 @@ def _worker(rank, world, port, w, h, case, blur, q):
         out = fr.render(np.array(case["cam"], np.float32), case["sec"], gather_depth=True)
         if rank == 0:
             import oracle
-            q.put((oracle.fnv64(fr.to_host(out)), oracle.fnv64(fr.final_z[:h].numpy())))
+            res = [oracle.fnv64(fr.to_host(out)), oracle.fnv64(fr.final_z[:h].numpy())]
         else:
             assert out is None
+        # frames in flight: five different frames through the two slots; the last one
+        # and (by flushing in the middle) the third one are checked on rank 0
+        cams = [np.array(case["cam"], np.float32).reshape(4, 4).copy() for _ in range(5)]
+        for i, c in enumerate(cams):
+            c[3, 0] += 0.05 * (i % 3)            # frames 0 and 3 are the golden pose
+        hashes = []
+        for i, c in enumerate(cams):
+            fr.submit(c, case["sec"])
+            if i in (3, 4):
+                o = fr.flush()
+                if rank == 0:
+                    hashes.append(oracle.fnv64(fr.to_host(o)))
+        if rank == 0:
+            # reference for frame 4 (pose index 1): a plain render of the same camera
+            want4 = oracle.fnv64(fr.to_host(fr.render(cams[4], case["sec"])))
+            q.put(tuple(res) + (hashes[0], hashes[1] == want4))
+        else:
+            fr.render(cams[4], case["sec"])
     finally:
         dist.destroy_process_group()
 
@@ -82,9 +100,11 @@ def test_row_tiled_frame_matches_golden(cases, world, blur):
     for p in procs:
         p.join(180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    col, z = q.get(timeout=5)
+    col, z, piped3, piped4_ok = q.get(timeout=5)
     assert col == (case["post"] if blur else case["pre"])
     assert z == case["z"]
+    assert piped3 == (case["post"] if blur else case["pre"])     # frame 3 of the pipeline = the golden pose
+    assert piped4_ok
 
 
 def test_strip_ranges():

@@ -217,6 +217,22 @@ def test_single_rank_row_tiled_frame(oracle_lib, cases):
     out = fr.render(np.array(c["cam"], np.float32), c["sec"])
     torch.cuda.synchronize()
     assert _fnv(oracle_lib, fr.to_host(out)) == c["post"]
+    # frames in flight (the N > 1 bench loop) on the GPU kernels: two slots, six
+    # frames of alternating poses, each checked against a plain render
+    cams = [np.array(c["cam"], np.float32).reshape(4, 4).copy() for _ in range(2)]
+    cams[1][3, 0] += 0.25
+    want = []
+    for cam in cams:
+        o = fr.render(cam, c["sec"])
+        torch.cuda.synchronize()
+        want.append(_fnv(oracle_lib, fr.to_host(o)))
+    assert want[0] == c["post"] and want[1] != want[0]
+    for i in range(6):
+        fr.submit(cams[i & 1], c["sec"])
+        if i in (2, 5):
+            o = fr.flush()
+            torch.cuda.synchronize()
+            assert _fnv(oracle_lib, fr.to_host(o)) == want[i & 1], i
     r.close()
 
 
