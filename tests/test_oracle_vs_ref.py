@@ -110,3 +110,47 @@ def test_edge_scenes(oracle_lib, tmp_path):
         b, zb = O.render(sc.w, sc.h, sc.cam, sec=sc.sec, blur=blur)
         assert (a == b).all(), (sc.name, int((a != b).sum()))
         assert (za.view(np.uint32) == zb.view(np.uint32)).all(), sc.name
+
+
+def test_random_levels_loader_three_way(oracle_lib, tmp_path):
+    """level.txt format (level.h:107-228) on random files: the reference's own
+    level_load, the oracle's and the product's (pwnfps_amd/csrc/level_host.c) parse
+    to the same grid, portal table and spawn.  Letters stay off the grid border,
+    where the reference's find_free_dir_2d reads outside lv->data (util.h:140-149)."""
+    import ctypes as C
+    import os
+    from conftest import ROOT
+    lib = C.CDLL(os.path.join(ROOT, "pwnfps_amd", "libpwnhip.so"))
+    lib.pwn_parse_level.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(31337)
+    R = refharness.RefHarness("tab")
+    plain = list(';;;;;;$$##&&"<>,^....') + ['*']
+    letters = [chr(c) for c in range(ord('A'), ord('Z') + 1)] + [chr(c) for c in range(ord('a'), ord('z') + 1)]
+    for it in range(150):
+        nrows, ncols = int(rng.integers(1, 66)), int(rng.integers(1, 70))
+        eol = ["\n", "\r\n", "\r", "\n\n"][it % 4]
+        rows = []
+        for z in range(nrows):
+            n = int(rng.integers(0, ncols + 1))
+            row = [str(rng.choice(plain)) for _ in range(n)]
+            if 1 <= z < min(nrows, 64) - 1:
+                for x in range(1, min(n, 64) - 1):
+                    if rng.random() < 0.04:
+                        row[x] = str(rng.choice(letters))
+            rows.append("".join(row))
+        text = eol.join(rows) + (eol if it % 3 else "")
+        path = str(tmp_path / ("lv%d.txt" % it))
+        with open(path, "wb") as f:
+            f.write(text.encode("latin-1"))
+        R.load_level(path)
+        d0, p0, s0 = R.get_level()
+        O = oracle_lib.Oracle()
+        O.load_level(path)
+        d1, p1, s1 = O.get_level()
+        cells = np.zeros(4096, np.uint8); pmap = np.zeros((26, 7), np.int32); spawn = np.zeros(2, np.int32)
+        raw = text.encode("latin-1")
+        assert lib.pwn_parse_level(raw, len(raw), cells.ctypes.data, pmap.ctypes.data, spawn.ctypes.data) == 0
+        for name, (d, p, s) in (("oracle", (d1, p1, s1)), ("product", (cells.reshape(64, 64), pmap, spawn))):
+            assert (np.asarray(d) == np.asarray(d0)).all(), (it, name, "grid")
+            assert (np.asarray(p) == np.asarray(p0)).all(), (it, name, "pmap")
+            assert (np.asarray(s) == np.asarray(s0)).all(), (it, name, "spawn")
