@@ -133,13 +133,17 @@ class RowTiledFrame:
     #           next writer trace_{i+2} is issued after blur_i on the same stream
     #   out[s]  blur_i writes own strip -> gather_i reads; next writer blur_{i+2}
     #           waits for gather_i first
+    #           (with the blur off the gather reads pre[s]: trace_{i+2} waits for gather_i)
     #   z[s]    trace_i writes, blur_i reads (same stream)
+    #   final[s] (rank 0) gather_i writes; one per slot, so two gathers never share a target
     # All ranks issue the collectives in the same order: AG_0, AG_1, G_0, AG_2, G_1, ...
     def _slots(self):
         if getattr(self, "_slot", None) is None:
             mk = lambda t: torch.zeros_like(t)
-            self._slot = [dict(pre=self.pre, out=self.out, z=self.z, ag=None, g=None),
-                          dict(pre=mk(self.pre), out=mk(self.out), z=mk(self.z), ag=None, g=None)]
+            fin = self.final
+            self._slot = [dict(pre=self.pre, out=self.out, z=self.z, fin=fin, ag=None, g=None),
+                          dict(pre=mk(self.pre), out=mk(self.out), z=mk(self.z),
+                               fin=(mk(fin) if fin is not None else None), ag=None, g=None)]
             self._n = 0            # frames submitted
             self._pending = None   # slot index of the frame traced but not yet blurred
         return self._slot
@@ -160,11 +164,11 @@ class RowTiledFrame:
         if self.world == 1:
             return cur
         if self.rank == 0:
-            parts = [self._strip(self.final, r) for r in range(self.world)]
+            parts = [self._strip(sl["fin"], r) for r in range(self.world)]
             sl["g"] = dist.gather(self._strip(cur), parts, dst=0, group=self.group, async_op=True)
         else:
             sl["g"] = dist.gather(self._strip(cur), None, dst=0, group=self.group, async_op=True)
-        return self.final
+        return sl["fin"]
 
     def submit(self, cam, sec=0.0):
         """Enqueue one frame (POSTPROC_BLUR 0 or 1).  Returns None; the frame is
@@ -175,6 +179,9 @@ class RowTiledFrame:
         k = self._n & 1
         sl = slots[k]
         cam = np.ascontiguousarray(cam, np.float32).reshape(16)
+        if sl["g"] is not None:            # the gather two frames back read this slot's buffers
+            sl["g"].wait()
+            sl["g"] = None
         self.backend.trace_rows(cam, float(sec), self.y0, self.y1, sl["pre"], sl["z"])
         if self.world > 1 and self.blur_passes:
             sl["ag"] = dist.all_gather_into_tensor(sl["pre"], self._strip(sl["pre"]), group=self.group, async_op=True)
