@@ -388,6 +388,8 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	// main.c:61-64) never put anything but 0 / 1 into the w lanes; the kernel has a
 	// 3-lane specialisation for them that is arithmetically identical
 	P.has_w = !(cam[3] == 0.0f && cam[7] == 0.0f && cam[11] == 0.0f && cam[15] == 1.0f);
+	// test hook (tests/test_gpu_fuzz.py): send every camera through the general variant
+	if(getenv("PWN_DBG_FORCE_HASW")) P.has_w = 1;
 	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
 	// persistent grid: as many workgroups as are resident at once, each striding over tiles
 	const size_t lds_bytes = P.blob_bytes;

@@ -1,0 +1,26 @@
+"""A short run of the randomised parity campaign (tools/fuzz_parity.py: random
+levels, cameras with and without w components, sphere sets, frame sizes, blur
+on/off, counters on) as part of the GPU suite.  The campaign is what found the
+two toolchain problems recorded in pwnfps_amd/csrc/Makefile and dev_math.h; the
+second run sends w-free cameras through the general 4-lane kernel variant, whose
+output must not depend on which variant renders a frame."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,seed,force_w", [(120, 3, False), (80, 4, True)])
+def test_fuzz_campaign(n, seed, force_w):
+    env = dict(os.environ)
+    if force_w:
+        env["PWN_DBG_FORCE_HASW"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), str(n), str(seed)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "%d scenes, 0 mismatches" % n in p.stdout
