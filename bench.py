@@ -181,8 +181,13 @@ def main():
     # are complete (flush) before the closing barrier.
     pipelined = world > 1 and args.blur <= 1 and not args.no_pipeline
     out = None
-    for _ in range(args.warmup):
-        out = fr.render(cam, sec)
+    if pipelined:
+        for _ in range(args.warmup):          # same loop as the timed one: second buffer set, RCCL channels
+            fr.submit(cam, sec)
+        out = fr.flush()
+    else:
+        for _ in range(args.warmup):
+            out = fr.render(cam, sec)
     barrier()
     t0 = time.perf_counter()
     if pipelined:
