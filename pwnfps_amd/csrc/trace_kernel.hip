@@ -4,33 +4,32 @@
 // trace_hit_wall / trace_hit_bounce (trace.h) of the reference.
 //
 // Shape: persistent 256-thread workgroups (4 wave64), exactly as many as are
-// resident at once.  Each workgroup copies the level blob (per-cell word,
-// rcp/rsqrt tables, portals, per-cell sphere lists, spheres: tables.h)
-// HBM -> LDS once, then walks 32x8-pixel tiles of its row strip, one thread
-// per pixel.  The reference's recursion (depth <= REFLECT) is a loop over at
-// most three ray segments; the composites of trace.h:91-101 are applied on
-// unwinding.  Output: BGRA8 colour + fp32 depth, row-major, 4-byte stores.
+// resident at once.  Each workgroup copies the level blob (rcp/rsqrt tables,
+// per-cell word, portals, per-cell sphere lists, spheres: tables.h) HBM -> LDS
+// once, then walks 32x8-pixel tiles of its row strip, one thread per pixel.
+// The reference's recursion (depth <= REFLECT) is a loop over at most three ray
+// segments; the composites of trace.h:91-101 are applied on unwinding.
+// Output: BGRA8 colour + fp32 depth, row-major, 4-byte stores.
 //
 // No MFMA: this is a branchy DDA, not a contraction.  HBM traffic is the two
 // output planes only (8 B / pixel); everything the inner loop reads is in LDS.
-// The kernel is VALU-issue / latency bound, so the code is organised for a
-// small live register set (occupancy) and few scalar branch sequences:
-//   - one walk loop with a single exit (no per-exit struct copies),
-//   - the 1-high and 2-high room cases share one body,
-//   - one LDS word per step gives cell type + sphere count + list offset,
+// The kernel is instruction-issue bound, so the code is
+// organised for few instructions per cell step and few scalar mask sequences:
+//   - one walk loop with one exit; the cell class is a bit test on ONE LDS
+//     word per step (class flags + sphere-list offset, 65x65 clamp-free grid),
+//   - the room body (1-high and 2-high share it) is written with selects,
+//   - the per-tile ray add-chain is built systolically with DPP row shifts,
+//   - rcp/rsqrt table hits cost an index, a ds_read_u16 and a subtract,
 //   - cameras without w components (the usual case) take a 3-lane path that
-//     is arithmetically identical to the 4-lane SSE code (see HAS_W below).
+//     is arithmetically identical to the 4-lane SSE code (see HAS_W below),
+//   - no device function calls (dev_math.h) and no SLP packing (Makefile).
 #include <hip/hip_runtime.h>
 #include "dev_math.h"
 #include "tables.h"
 
 #define EPS 0.0000000000001f      // defs.h:1
 #define REFLECT_BLUR_F 0.03f      // defs.h:5
-#ifdef PWN_DBG_REFLECT            // timing experiments only (changes the pixels)
-#define REFLECT_MAX PWN_DBG_REFLECT
-#else
 #define REFLECT_MAX 2             // defs.h:7
-#endif
 enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
 
 // workgroup = PWN_BLOCK threads = one 32 x (PWN_BLOCK/32) pixel tile
@@ -507,11 +506,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		if(depth >= REFLECT_MAX || refl == 0.0f) { vx = colx; vy = coly; vz = colz; vw = 0.0f; break; }
 
 		// trace.h:9-75
-#ifdef PWN_DBG_NOFLOOR
-		if(false)
-#else
 		if(ldir == FYN)
-#endif
 		{
 			pos.y -= 0.001f;
 			const float pi = (float)3.14159265358979323846;
@@ -537,13 +532,11 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		else { ray.y = -ray.y; pos.y -= 0.001f; }
 
 		// trace.h:77-84: five draws, two discarded
-#ifndef PWN_DBG_NOLCG
 		ray.x += lcg_fs(seed) * REFLECT_BLUR_F;
 		ray.y += lcg_fs(seed) * REFLECT_BLUR_F;
 		lcg_next(seed);
 		ray.z += lcg_fs(seed) * REFLECT_BLUR_F;
 		lcg_next(seed);
-#endif
 
 		if(depth == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; }
 		else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; }
