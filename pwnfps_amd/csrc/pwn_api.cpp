@@ -401,9 +401,29 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 		c->occ_lds[variant] = lds_bytes;
 	}
 	int per_cu = c->occ_blocks[variant];
+	// The API counts LDS as 160 KiB / bytes; a census (tools/ubench/lds_census.hip) shows one
+	// workgroup fewer resident at some sizes (5 x 32 KiB, 3 x 54000 B).  A persistent grid
+	// that is one workgroup per CU too large runs its surplus at the end at a fraction of the
+	// occupancy (+40 % frame time), so stay on the safe side: 2 KiB granules in 152 KiB.
+	{
+		const int lds_fit = (int)(155648u / (((uint32_t)lds_bytes + 2047u) & ~2047u));
+		if(per_cu > lds_fit) per_cu = lds_fit;
+	}
 	if(per_cu < 1) per_cu = 1;
 	int grid = c->num_cus * per_cu;
 	if(grid > P.tiles_total) grid = P.tiles_total;
+	// Workgroup b takes tiles b, b + grid, ...: column (b + k*grid) % tiles_x.  If grid and
+	// tiles_x share a factor a workgroup only ever sees a few tile columns, and a frame whose
+	// expensive rays form a vertical band (a mirror hall) loads a few workgroups with all of
+	// it (8K: 1280 workgroups over 240 columns = 3 columns each: +40 % frame time).  Make the
+	// two coprime; this costs at most a handful of workgroups.
+	while(grid > 1)
+	{
+		int a = grid, b = P.tiles_x;
+		while(b) { int t = a % b; a = b; b = t; }
+		if(a == 1) break;
+		grid--;
+	}
 	HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	return PWN_OK;
 }
