@@ -284,6 +284,13 @@ def main():
                          "bytes_per_pixel": TRACE_BYTES_PER_PIXEL, "pixels_per_launch": strip_pix,
                          "avg_launch_ms": round(trace_ms, 4),
                          "note": "VALU/divergence-bound DDA: tables live in LDS, compulsory HBM traffic is the 8 B/pixel written"},
+            # the second kernel of a frame, the one that really is a memory gather: 12 algorithmic
+            # bytes per pixel (read colour 4 + depth 4, write 4), single-GPU figure from HIP events
+            "blur_roofline": ({"bound": "hbm", "kernel": "pwn_blur_tiled_kernel", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                               "achieved": round(12 * pix / (kernel_ms["blur"] * 1e-3) / 1e9, 3),
+                               "frac": round(12 * pix / (kernel_ms["blur"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                               "bytes_per_pixel": 12, "avg_launch_ms": kernel_ms["blur"]}
+                              if kernel_ms and kernel_ms.get("blur", 0) > 0 else None),
             "frame_bytes_per_pixel": FRAME_BYTES_PER_PIXEL,
             "frame_gbs": round(FRAME_BYTES_PER_PIXEL * pix * args.steps / dt / 1e9, 3),
             "parity_vs_reference_golden": parity,

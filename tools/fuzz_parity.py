@@ -58,6 +58,9 @@ def random_level():
 
 bad = 0
 sizes = [(64, 32), (36, 20), (128, 72), (33, 9), (256, 64), (8, 8), (100, 52), (160, 96)]
+# every 16th scene: a frame larger than one blur tile, so that deep pixels send taps outside
+# the staged halo (post_kernels.hip) and several tiles / XCD bands take part
+big_sizes = [(640, 400), (1024, 136), (388, 260)]
 for it in range(n):
     text = random_level()
     O = oracle.Oracle()
@@ -83,6 +86,8 @@ for it in range(n):
                   rng.uniform(0.0, 1.8), np.clip(z + rng.uniform(-2, 3), 0.7, 62.3), *rng.uniform(0, 1.5, 3))
     sec = float(np.float32(rng.choice([0.0, rng.uniform(0, 60), rng.uniform(0, 4000)])))
     w, h = sizes[it % len(sizes)]
+    if it % 16 == 9:
+        w, h = big_sizes[(it // 16) % len(big_sizes)]
     blur = int(rng.integers(0, 2)) if w % 4 == 0 else 0
     O.set_spheres(sph)
     if REF_MODE:
