@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--blur", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: finish each frame before starting the next")
+    ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
+                    help="N > 1: pre-blur rows each rank receives (dist.py): a bounded halo with an exactness check, or every strip")
     args = ap.parse_args()
 
     import torch
@@ -152,7 +154,7 @@ def main():
     cam = pwnfps_amd.spawn_camera(spawn)            # main.c:61-64
     sec = 0.0
 
-    fr = RowTiledFrame(w, h, HipStripBackend(r), dev, rank=rank, world=world, blur_passes=args.blur)
+    fr = RowTiledFrame(w, h, HipStripBackend(r), dev, rank=rank, world=world, blur_passes=args.blur, exchange=args.exchange)
 
     def barrier():
         torch.cuda.synchronize()
@@ -274,8 +276,12 @@ def main():
             "config": {"workload": "pwnfps level.txt scene (14 game.lua spheres, spawn pose, sec_current=0), "
                                    "%dx%d, POSTPROC_BLUR=%d, one frame per step" % (w, h, args.blur),
                        "level": args.level, "width": w, "height": h, "blur_passes": args.blur,
-                       "parallelism": "rows/%d" % world + ("" if world == 1 else " + RCCL all-gather(pre-blur) + gather(strips)"
-                                                            + (", 2 frames in flight" if pipelined else ""))},
+                       "parallelism": "rows/%d" % world + ("" if world == 1 else
+                                                            (" + RCCL %sgather(strips)" % ("" if not args.blur else
+                                                                                          "halo exchange (%d rows, all-to-all) + " % fr.halo if fr.halo
+                                                                                          else "all-gather(pre-blur) + "))
+                                                            + (", 2 frames in flight" if pipelined else "")),
+                       "halo_fallbacks": fr.halo_misses},
             "roofline": {"bound": "hbm", "kernel": "pwn_trace_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic("pwn_trace_kernel", w, h) if world == 1 else None,

@@ -101,6 +101,15 @@ int pwn_trace_rows_device(pwn_ctx *ctx, const float cam[16], float sec_current,
 	int y0, int y1, void *d_sbuf, void *d_zbuf, void *stream);
 int pwn_blur_rows_device(pwn_ctx *ctx, int y0, int y1, const void *d_pre,
 	const void *d_zbuf, void *d_out, void *stream);
+/*
+ * The same pass when the caller exchanged only a bounded halo instead of the
+ * whole pre-blur frame: rows [avail_y0, avail_y1) of d_pre hold this frame.
+ * A tap outside them (taps reach 0.002*h*|depth-1| rows, screen.h:100-102)
+ * adds to the uint32 at d_miss (device memory, caller clears it); the strip
+ * is then not valid and has to be repeated with the whole frame present.
+ */
+int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre,
+	const void *d_zbuf, void *d_out, int avail_y0, int avail_y1, void *d_miss, void *stream);
 
 /* screen_upscale (screen.h:126-149): replicate every pixel scale x scale into
    a surface of `pitch_bytes` per row (SDL_Surface->pitch / ->pixels).

@@ -46,6 +46,7 @@ ABI = [
     ("pwn_trace_screen_centred", _i, [_vp, _vp, _f, _vp, _vp]),
     ("pwn_trace_rows_device", _i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
     ("pwn_blur_rows_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    ("pwn_blur_rows_device_bounded", _i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     ("pwn_screen_upscale", _i, [_vp, _vp, _i, _i, _vp]),
     ("pwn_upscale_device", _i, [_vp, _vp, _i, _i, _vp, _vp]),
     ("pwn_get_stats", _i, [_vp, C.POINTER(Stats)]),

@@ -20,6 +20,11 @@ struct pwn_blur_params
 	const float *zbuf;             // full frame depth
 	uint32_t *out;                 // full frame
 	const uint2 *skip;             // groups x (A_g, C_g)
+	// row tiling with a bounded exchange: only rows [avail_y0, avail_y1) of `pre` hold this
+	// frame; a tap that lands outside them makes the kernel add to *miss (the caller then
+	// repeats the strip with the whole frame present).  miss == NULL: every row is valid.
+	int avail_y0, avail_y1;
+	uint32_t *miss;
 };
 
 __device__ __forceinline__ uint32_t avg_u8x4(uint32_t a, uint32_t b)
@@ -91,6 +96,7 @@ pwn_blur_kernel(pwn_blur_params P)
 #define BLUR_PITCH (BLUR_LW + 4)                   // words; +4 keeps rows 16-B aligned and off one bank
 #define BLUR_THREADS (BLUR_TW / 4 * BLUR_TH)       // one thread per 4-pixel group
 
+template<bool CHECK>
 __global__ void __launch_bounds__(BLUR_THREADS)
 pwn_blur_tiled_kernel(pwn_blur_params P)
 {
@@ -132,6 +138,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	const float4 zv = *(const float4 *)(P.zbuf + row + cx);
 	const float z[4] = { zv.x - 1.0f, zv.y - 1.0f, zv.z - 1.0f, zv.w - 1.0f };
 	uint32_t tap[4][4];
+	bool missed = false;
 #pragma unroll
 	for(int i = 0; i < 4; i++)
 	{
@@ -145,6 +152,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 			int y = (fy >= -2147483648.0f && fy < 2147483648.0f) ? (int)fy : INT32_MIN;
 			x = max(x, 0); y = max(y, 0);
 			x = min(x, P.w - 1); y = min(y, P.h - 1);
+			if(CHECK) missed |= (unsigned)(y - P.avail_y0) >= (unsigned)(P.avail_y1 - P.avail_y0);
 			const unsigned tx = (unsigned)(x - lx0), ty = (unsigned)(y - ly0);
 			if(tx < (unsigned)BLUR_LW && ty < (unsigned)BLUR_LH) tap[i][j] = tile[ty * BLUR_PITCH + tx];
 			else tap[i][j] = P.pre[(size_t)y * (size_t)P.w + (size_t)x];
@@ -156,6 +164,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	o.z = avg_u8x4(avg_u8x4(tap[0][2], tap[1][2]), avg_u8x4(tap[2][2], tap[3][2]));
 	o.w = avg_u8x4(avg_u8x4(tap[0][3], tap[1][3]), avg_u8x4(tap[2][3], tap[3][3]));
 	*(uint4 *)(P.out + row + cx) = o;
+	if(CHECK) { if(missed) atomicAdd(P.miss, 1u); }
 }
 
 extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream)
@@ -172,13 +181,15 @@ extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stre
 	bool &lds_set = lds_mark[dev & 63];
 	if(!lds_set)
 	{
-		hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if(e != hipSuccess) return e;
 		lds_set = true;
 	}
 	const int ntiles = ((P->w + BLUR_TW - 1) / BLUR_TW) * ((P->y1 - P->y0 + BLUR_TH - 1) / BLUR_TH);
 	dim3 grid(((ntiles + 7) / 8) * 8);
-	hipLaunchKernelGGL(pwn_blur_tiled_kernel, grid, dim3(BLUR_THREADS), lds, stream, *P);
+	if(P->miss != NULL) hipLaunchKernelGGL(pwn_blur_tiled_kernel<true>, grid, dim3(BLUR_THREADS), lds, stream, *P);
+	else hipLaunchKernelGGL(pwn_blur_tiled_kernel<false>, grid, dim3(BLUR_THREADS), lds, stream, *P);
 #endif
 	return hipGetLastError();
 }

@@ -23,6 +23,8 @@ struct pwn_blur_params
 	const float *zbuf;
 	uint32_t *out;
 	const uint2 *skip;
+	int avail_y0, avail_y1;
+	uint32_t *miss;
 };
 
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
@@ -428,13 +430,15 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	return PWN_OK;
 }
 
-static int launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream)
+static int launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream,
+	int avail_y0 = 0, int avail_y1 = 0, uint32_t *d_miss = NULL)
 {
 	if((c->w & 3) != 0) return PWN_EINVAL; // screen.h:88,117: aligned 16-B store per group
 	pwn_blur_params B;
 	B.w = c->w; B.h = c->h; B.y0 = y0; B.y1 = y1;
 	B.groups = c->w / 4;
 	B.pre = d_pre; B.zbuf = d_z; B.out = d_out; B.skip = c->d_skip;
+	B.avail_y0 = avail_y0; B.avail_y1 = avail_y1; B.miss = d_miss;
 	HIPCHK(c, pwn_launch_blur(&B, stream));
 	return PWN_OK;
 }
@@ -452,6 +456,16 @@ extern "C" int pwn_blur_rows_device(pwn_ctx *c, int y0, int y1, const void *d_pr
 	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || y0 < 0 || y1 > c->h || y0 > y1 || d_pre == d_out) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	return launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream);
+}
+
+extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const void *d_pre, const void *d_zbuf, void *d_out,
+	int avail_y0, int avail_y1, void *d_miss, void *stream)
+{
+	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || d_miss == NULL || y0 < 0 || y1 > c->h || y0 > y1 ||
+	   d_pre == d_out || avail_y0 > avail_y1) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	return launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream,
+		avail_y0, avail_y1, (uint32_t *)d_miss);
 }
 
 extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float sec, uint32_t *sbuf, float *zbuf)

@@ -11,12 +11,21 @@ its taps reach +-0.002*h*(depth-1) rows (screen.h:86,100-102), unbounded in
 depth, so every rank needs the whole pre-blur colour frame.  Per frame:
 
     1. trace own strip          -> pre[strip], z[strip]            (HIP kernel)
-    2. all-gather pre strips    -> pre[all rows]   4 B/pixel       (RCCL, in place)
+    2. exchange pre-blur rows                                      (RCCL)
+         "halo" (default): H rows with each neighbour strip, one all-to-all
+             with zero-length parts for all other ranks; the blur kernel
+             counts taps that land outside [y0-H, y1+H) and, if any rank saw
+             one, the frame is repeated with the whole frame gathered
+         "allgather": every strip to everyone, 4 B/pixel, in place
     3. blur own strip           -> out[strip]                      (HIP kernel)
     4. gather out strips to rank 0                                 (RCCL)
 
-With the blur disabled steps 2-3 vanish.  The collectives are the only data
-exchanged; level and sphere tables are uploaded by every rank itself (13 KB).
+With the blur disabled steps 2-3 vanish.  Why the halo: xGMI is point to point,
+so with 2 GPUs the all-gather and the gather share ONE link and move 2 x 16.6 MB
+per 4K frame - more time than tracing the frame on one GPU; with 8, rank 0 takes
+in 58 MB per frame.  At 4K the taps of level.txt reach 32 rows; H covers depth 24
+(104 rows).  The collectives are the only data exchanged; level and sphere tables
+are uploaded by every rank itself (13 KB).
 
 The strip work is delegated to a backend with trace_rows()/blur_rows() on
 torch tensors: HipStripBackend (the product: libpwnhip.so on this rank's GPU)
@@ -60,13 +69,19 @@ class HipStripBackend:
     def blur_rows(self, y0, y1, pre, z, out):
         self.r.blur_rows_device(y0, y1, pre.data_ptr(), z.data_ptr(), out.data_ptr(), self._stream())
 
+    def blur_rows_bounded(self, y0, y1, pre, z, out, avail_y0, avail_y1, miss):
+        """miss: int32 device tensor (1 element) the kernel adds to for taps outside [avail_y0, avail_y1)."""
+        self.r.blur_rows_device_bounded(y0, y1, pre.data_ptr(), z.data_ptr(), out.data_ptr(), avail_y0, avail_y1,
+                                        miss.data_ptr(), self._stream())
+
 
 class RowTiledFrame:
     """Frame buffers + choreography for one rank.  Buffers are padded to
     world * rows_per rows so that all strips have equal size for the
     collectives; rows >= h are never written by the kernels."""
 
-    def __init__(self, w, h, backend, device, rank=None, world=None, blur_passes=1, group=None):
+    def __init__(self, w, h, backend, device, rank=None, world=None, blur_passes=1, group=None,
+                 exchange="halo", halo_depth=24.0):
         self.w, self.h = int(w), int(h)
         self.group = group
         if world is None:
@@ -88,6 +103,58 @@ class RowTiledFrame:
         self.z = torch.zeros((self.hpad, self.w), dtype=torch.float32, **kw)
         self.final = torch.zeros((self.hpad, self.w), dtype=torch.int32, **kw) if rank == 0 else None
         self.final_z = None
+        # bounded exchange: H rows per neighbour, possible when every strip has at least H rows
+        self.halo = 0
+        self.halo_misses = 0       # frames (render) / flushes (submit) that had to fall back to the all-gather
+        if exchange == "halo" and world > 1 and self.blur_passes == 1:
+            H = int(np.ceil(0.002 * self.h * float(halo_depth))) + 1
+            shortest = min(strip_range(self.h, world, r)[1] - strip_range(self.h, world, r)[0] for r in range(world))
+            if 0 < H <= shortest:
+                self.halo = H
+        elif exchange not in ("halo", "allgather"):
+            raise ValueError("exchange must be 'halo' or 'allgather'")
+        if self.halo:
+            H = self.halo
+            up, dn = rank > 0, rank < world - 1
+            self._peers = (up, dn)
+            self._in_split = [H if (r == rank - 1 or r == rank + 1) else 0 for r in range(world)]
+            self._nrows = H * (int(up) + int(dn))
+            self.avail = (self.y0 - H if up else 0, self.y1 + H if dn else self.h)
+            self._hx = [self._halo_bufs(kw) for _ in range(2)]
+
+    def _halo_bufs(self, kw):
+        return dict(send=torch.zeros((max(self._nrows, 1), self.w), dtype=torch.int32, **kw),
+                    recv=torch.zeros((max(self._nrows, 1), self.w), dtype=torch.int32, **kw),
+                    miss=torch.zeros(1, dtype=torch.int32, **kw))
+
+    def _halo_start(self, pre, hx, async_op):
+        """Send this strip's border rows to the neighbours (ascending rank order: the upper
+        neighbour gets my top rows, the lower one my bottom rows); returns the work handle."""
+        H, (up, dn) = self.halo, self._peers
+        k = 0
+        if up:
+            hx["send"][0:H].copy_(pre[self.y0:self.y0 + H]); k = H
+        if dn:
+            hx["send"][k:k + H].copy_(pre[self.y1 - H:self.y1])
+        n = self._nrows
+        return dist.all_to_all_single(hx["recv"][:n], hx["send"][:n], output_split_sizes=self._in_split,
+                                      input_split_sizes=self._in_split, group=self.group, async_op=async_op)
+
+    def _halo_finish(self, pre, hx):
+        """Place the received rows: the upper neighbour's bottom rows above my strip, the
+        lower neighbour's top rows below it."""
+        H, (up, dn) = self.halo, self._peers
+        k = 0
+        if up:
+            pre[self.y0 - H:self.y0].copy_(hx["recv"][0:H]); k = H
+        if dn:
+            pre[self.y1:self.y1 + H].copy_(hx["recv"][k:k + H])
+
+    def _any_miss(self, miss):
+        """Collective: did any rank count a tap outside its halo?  (host sync)"""
+        m = miss.clone()
+        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
+        return int(m.item()) != 0
 
     def _strip(self, t, rank=None):
         rank = self.rank if rank is None else rank
@@ -100,7 +167,19 @@ class RowTiledFrame:
         cam = np.ascontiguousarray(cam, np.float32).reshape(16)
         b.trace_rows(cam, float(sec), self.y0, self.y1, self.pre, self.z)
         cur, other = self.pre, self.out
-        for _ in range(self.blur_passes):
+        done = False
+        if self.halo:
+            hx = self._hx[0]
+            hx["miss"].zero_()
+            self._halo_start(cur, hx, False)
+            self._halo_finish(cur, hx)
+            b.blur_rows_bounded(self.y0, self.y1, cur, self.z, other, self.avail[0], self.avail[1], hx["miss"])
+            if self._any_miss(hx["miss"]):
+                self.halo_misses += 1          # some tap left the halo: repeat with the whole frame
+            else:
+                cur, other = other, cur
+                done = True
+        for _ in range(0 if done else self.blur_passes):
             if self.world > 1:
                 # in place: this rank's strip is already at its slot in `cur`
                 dist.all_gather_into_tensor(cur, self._strip(cur), group=self.group)
@@ -141,9 +220,14 @@ class RowTiledFrame:
         if getattr(self, "_slot", None) is None:
             mk = lambda t: torch.zeros_like(t)
             fin = self.final
-            self._slot = [dict(pre=self.pre, out=self.out, z=self.z, fin=fin, ag=None, g=None),
+            self._slot = [dict(pre=self.pre, out=self.out, z=self.z, fin=fin, ag=None, g=None, hx=None),
                           dict(pre=mk(self.pre), out=mk(self.out), z=mk(self.z),
-                               fin=(mk(fin) if fin is not None else None), ag=None, g=None)]
+                               fin=(mk(fin) if fin is not None else None), ag=None, g=None, hx=None)]
+            if self.halo:
+                for i in (0, 1):
+                    self._slot[i]["hx"] = self._hx[i]
+                self._miss_run = torch.zeros(1, dtype=torch.int32, device=self.pre.device)
+            self._last = None      # (cam, sec) of the newest frame, for the fallback in flush()
             self._n = 0            # frames submitted
             self._pending = None   # slot index of the frame traced but not yet blurred
         return self._slot
@@ -159,7 +243,12 @@ class RowTiledFrame:
             if sl["ag"] is not None:
                 sl["ag"].wait()
                 sl["ag"] = None
-            self.backend.blur_rows(self.y0, self.y1, sl["pre"], sl["z"], sl["out"])
+            if self.halo:
+                self._halo_finish(sl["pre"], sl["hx"])
+                self.backend.blur_rows_bounded(self.y0, self.y1, sl["pre"], sl["z"], sl["out"],
+                                               self.avail[0], self.avail[1], self._miss_run)
+            else:
+                self.backend.blur_rows(self.y0, self.y1, sl["pre"], sl["z"], sl["out"])
             cur = sl["out"]
         if self.world == 1:
             return cur
@@ -183,7 +272,10 @@ class RowTiledFrame:
             sl["g"].wait()
             sl["g"] = None
         self.backend.trace_rows(cam, float(sec), self.y0, self.y1, sl["pre"], sl["z"])
-        if self.world > 1 and self.blur_passes:
+        self._last = (cam.copy(), float(sec))
+        if self.halo:
+            sl["ag"] = self._halo_start(sl["pre"], sl["hx"], True)
+        elif self.world > 1 and self.blur_passes:
             sl["ag"] = dist.all_gather_into_tensor(sl["pre"], self._strip(sl["pre"]), group=self.group, async_op=True)
         if self._pending is not None:
             self._finish(self._pending)
@@ -202,6 +294,18 @@ class RowTiledFrame:
             if sl["g"] is not None:
                 sl["g"].wait()
                 sl["g"] = None
+        if self.halo and self._last is not None:
+            # taps outside the halo anywhere since the last flush?  Then the frames in flight were
+            # not exact; the one handed back is rendered again with the whole frame gathered.
+            miss = self._any_miss(self._miss_run)
+            self._miss_run.zero_()
+            if miss:
+                self.halo_misses += 1
+                H, self.halo = self.halo, 0
+                try:
+                    res = self.render(*self._last)
+                finally:
+                    self.halo = H
         return res if (self.rank == 0) else None
 
     def to_host(self, t):

@@ -122,6 +122,13 @@ class Renderer:
         self._chk(lib.pwn_blur_rows_device(self._ctx, int(y0), int(y1), C.c_void_p(d_pre), C.c_void_p(d_zbuf),
                                            C.c_void_p(d_out), C.c_void_p(stream)), "pwn_blur_rows_device")
 
+    def blur_rows_device_bounded(self, y0, y1, d_pre, d_zbuf, d_out, avail_y0, avail_y1, d_miss, stream=0):
+        """blur_rows_device when only rows [avail_y0, avail_y1) of d_pre are this frame's;
+        taps outside add to the uint32 at d_miss."""
+        self._chk(lib.pwn_blur_rows_device_bounded(self._ctx, int(y0), int(y1), C.c_void_p(d_pre), C.c_void_p(d_zbuf),
+                                                   C.c_void_p(d_out), int(avail_y0), int(avail_y1), C.c_void_p(d_miss),
+                                                   C.c_void_p(stream)), "pwn_blur_rows_device_bounded")
+
     # -- sink (screen.h:126-149) ----------------------------------------------
     def screen_upscale(self, sbuf, scale, pitch_bytes=None, pixels=None):
         scale = int(scale)

@@ -45,8 +45,23 @@ class OracleStripBackend:
     def blur_rows(self, y0, y1, pre, z, out):
         self.o.L.pwno_blur_rows(self.w, self.h, y0, y1, 1, pre.data_ptr(), z.data_ptr(), out.data_ptr())
 
+    def blur_rows_bounded(self, y0, y1, pre, z, out, avail_y0, avail_y1, miss):
+        """The contract of pwn_blur_rows_device_bounded with the oracle: rows outside
+        [avail_y0, avail_y1) are NOT this frame's - overwrite them with garbage so that a
+        wrong halo shows in the pixels - and report (conservatively, from the depth) whether
+        a tap can have left the available rows."""
+        p = pre.numpy()
+        p[:avail_y0] = 0x5EADBEEF
+        p[avail_y1:] = 0x5EADBEEF
+        zz = z.numpy()[y0:y1, :self.w]
+        reach = int(np.floor(np.float32(0.002 * self.h) * np.abs(zz - 1.0).max())) + 1 if y1 > y0 else 0
+        lo, hi = max(y0 - reach, 0), min(y1 - 1 + reach, self.h - 1)
+        if lo < avail_y0 or hi >= avail_y1:
+            miss += 1
+        self.o.L.pwno_blur_rows(self.w, self.h, y0, y1, 1, pre.data_ptr(), z.data_ptr(), out.data_ptr())
 
-def _worker(rank, world, port, w, h, case, blur, q):
+
+def _worker(rank, world, port, w, h, case, blur, q, exchange="halo", halo_depth=24.0):
     import sys
     sys.path.insert(0, HERE)
     sys.path.insert(0, ROOT)
@@ -56,7 +71,8 @@ def _worker(rank, world, port, w, h, case, blur, q):
     try:
         from pwnfps_amd.dist import RowTiledFrame, strip_range
         be = OracleStripBackend(w, h, level_path(case["level"]), load_spheres(case["spheres"]))
-        fr = RowTiledFrame(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur)
+        fr = RowTiledFrame(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur,
+                           exchange=exchange, halo_depth=halo_depth)
         assert (fr.y0, fr.y1) == strip_range(h, world, rank)
         out = fr.render(np.array(case["cam"], np.float32), case["sec"], gather_depth=True)
         # second frame with the same inputs must be identical (buffers are reused)
@@ -81,26 +97,36 @@ def _worker(rank, world, port, w, h, case, blur, q):
         if rank == 0:
             # reference for frame 4 (pose index 1): a plain render of the same camera
             want4 = oracle.fnv64(fr.to_host(fr.render(cams[4], case["sec"])))
-            q.put(tuple(res) + (hashes[0], hashes[1] == want4))
+            q.put(tuple(res) + (hashes[0], hashes[1] == want4, fr.halo, fr.halo_misses))
         else:
             fr.render(cams[4], case["sec"])
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,blur", [(2, 1), (2, 0), (3, 1)])
-def test_row_tiled_frame_matches_golden(cases, world, blur):
+# exchange / halo depth: the default halo (depth 24: 13 rows at h = 240, never missed by this
+# scene), a halo of 1 row that IS missed (every frame falls back to the all-gather), and the
+# plain all-gather
+@pytest.mark.parametrize("world,blur,exchange,depth", [(2, 1, "halo", 24.0), (2, 0, "halo", 24.0), (3, 1, "halo", 24.0),
+                                                       (2, 1, "halo", 0.0), (3, 1, "halo", 0.0), (2, 1, "allgather", 24.0)])
+def test_row_tiled_frame_matches_golden(cases, world, blur, exchange, depth):
     case = next(c for c in cases if c["name"] == "level_pose1_320x240")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case["w"], case["h"], case, blur, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case["w"], case["h"], case, blur, q, exchange, depth))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
         p.join(180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    col, z, piped3, piped4_ok = q.get(timeout=5)
+    col, z, piped3, piped4_ok, halo, misses = q.get(timeout=5)
+    if exchange == "halo" and blur == 1:
+        assert halo == int(np.ceil(0.002 * case["h"] * depth)) + 1
+        assert (misses > 0) == (depth < 1.0), (halo, misses)     # the 1-row halo must have been caught
+    else:
+        assert halo == 0 and misses == 0
     assert col == (case["post"] if blur else case["pre"])
     assert z == case["z"]
     assert piped3 == (case["post"] if blur else case["pre"])     # frame 3 of the pipeline = the golden pose

@@ -355,3 +355,44 @@ def test_edge_scenes_vs_oracle(oracle_lib):
         assert (a == b).all(), (sc.name, sc.w, sc.h, int((a != b).sum()))
         assert (za.view(np.uint32) == zb.view(np.uint32)).all(), (sc.name, sc.w, sc.h)
         r.close()
+
+
+def test_bounded_blur_reports_taps_outside_the_available_rows(oracle_lib, cases):
+    """pwn_blur_rows_device_bounded: with enough rows available the strip equals the plain
+    strip and the counter stays 0; with too few it counts.  (The multi-GPU halo exchange
+    relies on exactly this to stay bit-exact.)"""
+    import torch
+    c = next(x for x in cases if x["name"] == "level_pose1_1280x720")
+    w, h = c["w"], c["h"]
+    r = _renderer(w, h)
+    r.level_load(level_path(c["level"]))
+    r.set_objects(load_spheres(c["spheres"]))
+    cam = np.array(c["cam"], np.float32)
+    dev = torch.device("cuda:0")
+    pre = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    z = torch.zeros((h, w), dtype=torch.float32, device=dev)
+    ref = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    out = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    miss = torch.zeros(1, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    r.trace_rows_device(cam, c["sec"], 0, h, pre.data_ptr(), z.data_ptr(), s)
+    r.blur_rows_device(0, h, pre.data_ptr(), z.data_ptr(), ref.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert _fnv(oracle_lib, ref.cpu().numpy()) == c["post"]
+    zmax = float((z[240:480] - 1.0).abs().max())
+    need = int(np.floor(np.float32(0.002 * h) * zmax)) + 1
+    # (a) a halo that covers the deepest pixel of the strip: exact, no miss, even with garbage outside it
+    lo, hi = max(240 - need, 0), min(480 + need, h)
+    poisoned = pre.clone()
+    poisoned[:lo] = 0x5EADBEEF
+    poisoned[hi:] = 0x5EADBEEF
+    r.blur_rows_device_bounded(240, 480, poisoned.data_ptr(), z.data_ptr(), out.data_ptr(), lo, hi, miss.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert int(miss.item()) == 0
+    assert (out[240:480] == ref[240:480]).all()
+    # (b) only the strip itself: this scene's taps do leave it
+    assert need > 1
+    r.blur_rows_device_bounded(240, 480, pre.data_ptr(), z.data_ptr(), out.data_ptr(), 240, 480, miss.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert int(miss.item()) > 0
+    r.close()
