@@ -73,7 +73,15 @@ def cpu_baseline(w, h, cam, spheres, level_file, target_s=10.0):
                 t0 = time.perf_counter()
                 R.render(w, h, cam, threads=threads, want_z=False)
                 best = min(best, time.perf_counter() - t0)
+            # one thread as well: two frames at about 3 Mpixels/s
+            t0 = time.perf_counter()
+            R.render(w, h, cam, threads=1, want_z=False)
+            one = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            R.render(w, h, cam, threads=1, want_z=False)
+            one = min(one, time.perf_counter() - t0)
             return {"value": round(w * h / best / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "kind": "reference",
+                    "value_1_thread": round(w * h / one / 1e6, 3),
                     "sample": "%d full %dx%d frames (trace+blur) of the same scene, best of %d, reference "
                               "sources compiled with its own flags (gcc -O3 -fopenmp -ffast-math -funroll-loops), "
                               "OpenMP over 32-row chunks as screen.h:63" % (reps + 1, w, h, reps + 1)}
