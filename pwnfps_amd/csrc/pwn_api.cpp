@@ -412,6 +412,7 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 		if(per_cu > lds_fit) per_cu = lds_fit;
 	}
 	if(per_cu < 1) per_cu = 1;
+	if(const char *cap = getenv("PWN_DBG_BLOCKS_PER_CU")) { if(atoi(cap) > 0) per_cu = atoi(cap); }   // experiments
 	int grid = c->num_cus * per_cu;
 	if(grid > P.tiles_total) grid = P.tiles_total;
 	// Workgroup b takes tiles b, b + grid, ...: column (b + k*grid) % tiles_x.  If grid and
