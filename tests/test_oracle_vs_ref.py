@@ -154,3 +154,17 @@ def test_random_levels_loader_three_way(oracle_lib, tmp_path):
             assert (np.asarray(d) == np.asarray(d0)).all(), (it, name, "grid")
             assert (np.asarray(p) == np.asarray(p0)).all(), (it, name, "pmap")
             assert (np.asarray(s) == np.asarray(s0)).all(), (it, name, "spawn")
+
+
+def test_fuzz_scenes_oracle_vs_reference():
+    """The scenes of the GPU fuzz campaign (tools/fuzz_parity.py, same generator and seed as
+    tests/test_gpu_fuzz.py) with the compiled reference in place of the GPU: the oracle is
+    pinned on exactly the inputs it is later the judge of."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "120", "3", "--ref"],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    assert "120 scenes, 0 mismatches" in p.stdout
