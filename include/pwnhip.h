@@ -6,6 +6,11 @@
  * (0 = ok, negative = PWN_E*).  Nothing here aborts or asserts.
  * Each entry cites the reference interface it replaces (paths relative to
  * the reference tree).  INTEGRATION.md shows the host-side change.
+ *
+ * Like the reference's render path (globals, one main thread: main.c:26-34) a
+ * context is not re-entrant: one thread at a time per context, and the strip
+ * forms of one context must be ordered with respect to each other by their
+ * streams.  Different contexts (one per GPU, one process per GPU) are independent.
  */
 #ifndef PWNHIP_H
 #define PWNHIP_H
