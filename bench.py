@@ -143,10 +143,12 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
+        tmo = datetime.timedelta(seconds=180)       # a stuck collective should fail the run, not hang it
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
 
     w, h = args.width, args.height
     level_file = os.path.join(GOLD, "levels", args.level + ".txt")
