@@ -133,6 +133,26 @@ def test_row_tiled_frame_matches_golden(cases, world, blur, exchange, depth):
     assert piped4_ok
 
 
+def test_eight_ranks_uneven_last_strip(cases):
+    """World size 8 at 1280x720: strips of 96 rows, the last one 48; the 36-row halo fits the
+    shortest strip, so the bounded exchange runs with the geometry of the 8-GPU bench."""
+    case = next(c for c in cases if c["name"] == "level_pose1_1280x720")
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case["w"], case["h"], case, 1, q, "halo", 24.0))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    col, z, piped3, piped4_ok, halo, misses = q.get(timeout=5)
+    assert halo == 36 and misses == 0
+    assert col == case["post"] and z == case["z"] and piped3 == case["post"] and piped4_ok
+
+
 def test_strip_ranges():
     from pwnfps_amd.dist import strip_range, strip_rows
     for h in (200, 240, 720, 1080, 2160, 4320, 7, 8, 9):
