@@ -7,7 +7,7 @@
 A step = one frame of the workload BASELINE.json quotes the metric on: the
 reference's level.txt scene (its 14 game.lua spheres, camera at the spawn
 pose, sec_current = 0) at 3840x2160 with the post-process blur on, i.e. one
-trace_screen_centred() (screen.h:31-124).  With N > 1 the frame is row-tiled:
+level_prepare_render() + trace_screen_centred() (main.c:95,107; screen.h:31-124).  With N > 1 the frame is row-tiled:
 rank r traces rows [r*H/N, (r+1)*H/N), the pre-blur strips are all-gathered
 (RCCL), each rank blurs its strip, and the strips are gathered on rank 0
 (pwnfps_amd/dist.py).  Level/sphere tables and all frame buffers are resident
@@ -202,15 +202,19 @@ def main():
             out = fr.render(cam, sec)
     barrier()
     t0 = time.perf_counter()
+    # every step re-bins and re-uploads the spheres first, like the reference's frame loop does
+    # (level_prepare_render, main.c:95), although this benchmark's spheres do not move
     if pipelined:
         for i in range(args.steps):
             slot["i"] = i
+            r.set_objects(spheres)
             fr.submit(cam, sec)
         slot["i"] = -1
         out = fr.flush()
     else:
         for i in range(args.steps):
             slot["i"] = i
+            r.set_objects(spheres)
             out = fr.render(cam, sec)
         slot["i"] = -1
     barrier()

@@ -56,6 +56,7 @@ struct pwn_ctx
 	uint32_t off_sph;
 	bool blob_dirty;
 	size_t occ_lds[4]; int occ_blocks[4];    // cached occupancy query per kernel variant
+	hipEvent_t ev_tables; bool tables_in_use;   // recorded behind the last trace launch (it reads d_blob)
 
 	uint32_t *d_pre, *d_out;         // pre-blur ("tsbuf") and final ("sbuf") frames
 	float *d_z;
@@ -113,6 +114,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL;
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 4; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
+	c->ev_tables = NULL; c->tables_in_use = false;
 	c->stream = NULL;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));
@@ -141,6 +143,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		   hipMemset(c->d_out, 0, n * 4) != hipSuccess) { rc = PWN_EHIP; break; }
 		if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
 		for(int i = 0; i < 4; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { rc = PWN_EHIP; break; }
+		if(rc == PWN_OK && hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming) != hipSuccess) rc = PWN_EHIP;
 		if(rc != PWN_OK) break;
 
 		// blur LCG skip-ahead: entry g maps the row seed to the seed in front
@@ -166,6 +169,7 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 	(void)hipSetDevice(c->device);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
 	for(int i = 0; i < 4; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	if(c->ev_tables) (void)hipEventDestroy(c->ev_tables);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	(void)hipFree(c->d_blob); (void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z);
 	(void)hipFree(c->d_skip); (void)hipFree(c->d_counters); (void)hipFree(c->d_scratch);
@@ -252,7 +256,9 @@ static int pack_blob(pwn_ctx *c)
 		HIPCHK(c, hipMalloc((void **)&c->d_blob, total));
 		c->d_blob_cap = total;
 	}
-	// stream-ordered so that a frame in flight keeps its tables
+	// a trace launch still in flight (strip forms run on the caller's stream) reads these tables:
+	// let it finish before they change (level_prepare_render runs between frames, main.c:95)
+	if(c->tables_in_use) { HIPCHK(c, hipEventSynchronize(c->ev_tables)); c->tables_in_use = false; }
 	HIPCHK(c, hipMemcpyAsync(c->d_blob, b, total, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, hipStreamSynchronize(c->stream));
 	c->blob_dirty = false;
@@ -428,6 +434,8 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 		grid--;
 	}
 	HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
+	HIPCHK(c, hipEventRecord(c->ev_tables, stream));
+	c->tables_in_use = true;
 	return PWN_OK;
 }
 
