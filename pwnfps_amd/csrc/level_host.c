@@ -119,6 +119,13 @@ int pwn_parse_level(const char *text, int len, uint8_t *cells, pwn_portal *pmap,
  * Returns the number of entries, or -1 if idx_cap is too small (call with
  * idx = NULL to size).
  */
+/* (int)f as the reference's x86 build computes it (cvttss2si: INT_MIN for NaN and anything
+   outside int), without the undefined behaviour of the C cast */
+static int trunc_to_int(float f)
+{
+	return (f >= -2147483648.0f && f < 2147483648.0f) ? (int)f : INT32_MIN;
+}
+
 int pwn_bin_spheres(const pwn_sphere *s, int n, int32_t *off, int32_t *idx, int idx_cap)
 {
 	int32_t *fill = calloc(4096, sizeof(int32_t));
@@ -129,8 +136,8 @@ int pwn_bin_spheres(const pwn_sphere *s, int n, int32_t *off, int32_t *idx, int 
 		for(int i = 0; i < n; i++)
 		{
 			/* float subtraction/addition, then truncation toward zero (level.h:27-31) */
-			int x1 = (int)(s[i].x - s[i].r), z1 = (int)(s[i].z - s[i].r);
-			int x2 = (int)(s[i].x + s[i].r), z2 = (int)(s[i].z + s[i].r);
+			int x1 = trunc_to_int(s[i].x - s[i].r), z1 = trunc_to_int(s[i].z - s[i].r);
+			int x2 = trunc_to_int(s[i].x + s[i].r), z2 = trunc_to_int(s[i].z + s[i].r);
 			if(x1 < 0) x1 = 0;
 			if(z1 < 0) z1 = 0;
 			if(x2 > 63) x2 = 63;
