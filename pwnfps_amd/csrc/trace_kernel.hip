@@ -105,7 +105,9 @@ __device__ __forceinline__ float dpp_row_shr1(float v)
 }
 
 enum { EV_NONE = 0, EV_WALL, EV_SPHERE, EV_EXHAUSTED };
-enum { BASE_CEIL = 0, BASE_FLOOR, BASE_WALL, BASE_MAGENTA };
+// BASE_ROOM_Y: the ray left a room through its floor / ceiling (trace.h:323-329,373-379);
+// the face and the colour follow from the ray's y sign after the walk
+enum { BASE_CEIL = 0, BASE_FLOOR, BASE_WALL, BASE_MAGENTA, BASE_ROOM_Y };
 
 struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps; };
 
@@ -136,7 +138,10 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		// nearest sphere candidate (trace.h:193-199): distance, hit point, which sphere and
 		// its diffuse factor; normal, colour and reflectivity are rebuilt from these when
 		// the hit is committed
-		float aux_dist = -1.0f, aux_diff = 0.0f;
+		// aux_dist: the reference's "none yet" value -1 (trace.h:200) is kept as +inf here, so that
+		// "a candidate exists and lies behind us" is one comparison; a candidate whose distance is
+		// exactly -1.0f counts as none there and is stored as +inf here too
+		float aux_dist = __builtin_inff(), aux_diff = 0.0f;
 		uint32_t aux_idx = 0;
 		V aux_pos, aux_norm;
 		aux_pos.x = aux_pos.y = aux_pos.z = aux_pos.w = 0.0f;
@@ -179,13 +184,14 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		// (trace.h:345-349,381-385); iay_dn is the amount added when stepping DOWN into it
 		const float iay_dn = gyp ? iay : -iay;
 		const int ldy = gyp ? FYP : FYN;
+		const uint32_t iay_up_bits = gyp ? __float_as_uint(iay) : 0u;   // +iay when looking up, else +0
 		int ldx = (gx < 0 ? FXN : FXP), ldz = (gz < 0 ? FZN : FZP);
 
 		uint32_t cw = cellword_at(L, cx, cz);
 		int ldir = FYN;
-		int ev = EV_NONE, base = BASE_WALL;
+		int ev = EV_NONE, base = BASE_ROOM_Y;
 
-#define AUX_HIT() (aux_dist != -1.0f && cdist > aux_dist)
+#define AUX_HIT() (cdist > aux_dist)
 
 		// ------------------------------------------------ trace.h:250-675
 		// One cell per iteration, one loop exit at the bottom.  The cell class is a
@@ -226,9 +232,10 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 						{
 							float sd2 = 1.0f - calc / rad2;
 							float sdist = sqrtf(d2) - sqrtf(sd2);
-							if(aux_dist == -1.0f || sdist + cdist < aux_dist)
+							if(sdist + cdist < aux_dist)
 							{
 								aux_dist = sdist + cdist;
+								if(aux_dist == -1.0f) aux_dist = __builtin_inff();
 								aux_pos = vadd<HAS_W>(pos, vscale<HAS_W>(sdist, ray));
 								V d;
 								d.x = aux_pos.x - s0.z; d.y = aux_pos.y - s0.w; d.z = aux_pos.z - s1.x;
@@ -250,7 +257,8 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 				// trace.h:302-352 (1-high) and 354-441 (2-high) share this body
 				const bool room2 = (cw & PWN_C_ROOM2) != 0u;
 				// 2-high: the ceiling is one unit further when looking up (trace.h:357,392)
-				const float up2 = (room2 && gyp) ? iay : 0.0f;
+				// = (room2 && gyp) ? iay : 0: the ROOM2 bit stretched to a mask (one v_bfe_i32)
+				const float up2 = __uint_as_float(iay_up_bits & (uint32_t)(((int32_t)(cw << 22)) >> 31));
 				wy += up2;
 				const float cdist0 = cdist;
 				// trace.h:156-184, then 331-340 on the same comparisons
@@ -269,9 +277,8 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 					const float fn = (fog - cdist0) + cdist;
 					fog = hit ? (aux_dist > cdist0 ? fh : fog) : fn;
 				}
-				ldir = ymin ? ldy : (xlt ? ldx : ldz);
+				ldir = xlt ? ldx : ldz;                      // a y exit is patched in after the walk
 				ev = hit ? EV_SPHERE : (ymin ? EV_WALL : 0);
-				base = gyp ? BASE_CEIL : BASE_FLOOR;
 				wy = (wy - txz) - up2;
 				wz = xlt ? wz - txz : iaz;
 				wx = xlt ? iax : wx - txz;
@@ -467,6 +474,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			vx = ray.x; vy = ray.y; vz = ray.z; vw = HAS_W ? ray.w : 0.0f;
 			break;
 		}
+		if(ev == EV_WALL && base == BASE_ROOM_Y) { ldir = ldy; base = (gyp ? BASE_CEIL : BASE_FLOOR); }
 		if(depth == 0) { dist = (ev == EV_SPHERE ? aux_dist : cdist); have_dist = true; }
 
 		float colx, coly, colz, refl;
