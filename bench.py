@@ -52,6 +52,28 @@ def pmc_traffic(kernel, w, h):
         return None
 
 
+def pmc_issue_rate(kernel, w, h):
+    """What actually bounds the trace kernel: wave-instructions issued per
+    cycle and SIMD, from the same committed PMC summary, next to the rate a SIMD sustains
+    on this chip (tools/ubench/valu_rate.hip: one simple VALU instruction per 1.65 cycles at
+    4+ waves, 1.76 for a VALU/SALU mix)."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.csv")
+    try:
+        meta = [l for l in open(path) if l.startswith("#")]
+        if not any("%dx%d" % (w, h) in m for m in meta):
+            return None
+        rows = [l.rstrip("\n").rsplit(",", 3) for l in open(path)]
+        v = {r[1]: float(r[3]) for r in rows if len(r) == 4 and kernel in r[0] and "<true" not in r[0]}
+        insts = v["SQ_INSTS_VALU"] + v["SQ_INSTS_SALU"] + v["SQ_INSTS_BRANCH"] + v["SQ_INSTS_LDS"]
+        cycles = v["GRBM_GUI_ACTIVE"] / 8.0                 # the counter sums the 8 XCDs
+        return {"wave_instructions_per_launch": int(insts), "cycles": int(cycles), "simds": 1024,
+                "issued_per_cycle_per_simd": round(insts / 1024.0 / cycles, 3), "sustainable_per_cycle_per_simd": 0.57,
+                "active_lanes_per_valu_instruction": round(v["SQ_THREAD_CYCLES_VALU"] / v["SQ_ACTIVE_INST_VALU"], 1)
+                if "SQ_ACTIVE_INST_VALU" in v else None}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 def cpu_baseline(w, h, cam, spheres, level_file, target_s=10.0):
     """The reference's own code (oracle/_ref, built from /root/reference with the
     reference's flags) timed on this host's cores; falls back to the port."""
@@ -301,6 +323,7 @@ def main():
                          "traffic": pmc_traffic("pwn_trace_kernel", w, h) if world == 1 else None,
                          "traffic_unit": "bytes/launch (PMC WRITE_SIZE + 2*FETCH_SIZE, profiles/pmc_latest.csv)",
                          "algorithmic_bytes_per_launch": TRACE_BYTES_PER_PIXEL * strip_pix,
+                         "instruction_issue": pmc_issue_rate("pwn_trace_kernel", w, h) if world == 1 else None,
                          "bytes_per_pixel": TRACE_BYTES_PER_PIXEL, "pixels_per_launch": strip_pix,
                          "avg_launch_ms": round(trace_ms, 4),
                          "note": "VALU/divergence-bound DDA: tables live in LDS, compulsory HBM traffic is the 8 B/pixel written"},
