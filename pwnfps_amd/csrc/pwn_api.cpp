@@ -30,6 +30,7 @@ struct pwn_blur_params
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
 extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w);
 extern "C" int pwn_trace_tile_h(void);
+extern "C" unsigned pwn_trace_lds_extra(void);
 extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
 extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
@@ -400,7 +401,7 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	if(getenv("PWN_DBG_FORCE_HASW")) P.has_w = 1;
 	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
 	// persistent grid: as many workgroups as are resident at once, each striding over tiles
-	const size_t lds_bytes = P.blob_bytes;
+	const size_t lds_bytes = ((P.blob_bytes + 15u) & ~15u) + pwn_trace_lds_extra();
 	// resident workgroups per CU depend on (LDS bytes, kernel variant) only: ask once per combination
 	const int variant = (c->counters_on ? 2 : 0) | (P.has_w ? 1 : 0);
 	if(c->occ_lds[variant] != lds_bytes)

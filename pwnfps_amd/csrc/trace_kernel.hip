@@ -115,7 +115,7 @@ struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps; };
 template<bool COUNT, bool HAS_W>
 __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uint32_t seed,
 	Vec<HAS_W> from, Vec<HAS_W> iray, float &out_x, float &out_y, float &out_z, float &out_w,
-	float &dist, bool &have_dist, Counters &cnt)
+	float &dist, bool &have_dist, Counters &cnt, float *stk)
 {
 	typedef Vec<HAS_W> V;
 	// icol (screen.h:24).  Its w lane, and the w lane of every surface colour, is
@@ -123,9 +123,15 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	// +-0 for any finite input, and the sign of a zero never reaches a pixel, so the
 	// w lanes of icol and of the composite stack are not kept.
 	float icx = 1.0f, icy = 1.0f, icz = 1.0f;
+#ifdef PWN_LDS_STACK
+	// the composite stack (reflectivity, fog, colour of the two bounced-off surfaces) lives in
+	// LDS, one float per thread and slot (stride PWN_BLOCK: conflict-free), not in registers
+#define STK(level, k) stk[((level) * 5 + (k)) * PWN_BLOCK]
+#else
 	float st_refl0 = 0.0f, st_refl1 = 0.0f, st_fog0 = 0.0f, st_fog1 = 0.0f;
 	float sc0x = 0.0f, sc0y = 0.0f, sc0z = 0.0f;
 	float sc1x = 0.0f, sc1y = 0.0f, sc1z = 0.0f;
+#endif
 	int depth = 0;
 	float vx, vy, vz, vw;
 	have_dist = false;
@@ -546,8 +552,12 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		ray.z += lcg_fs(seed) * REFLECT_BLUR_F;
 		lcg_next(seed);
 
+#ifdef PWN_LDS_STACK
+		STK(depth, 0) = refl; STK(depth, 1) = fog; STK(depth, 2) = colx; STK(depth, 3) = coly; STK(depth, 4) = colz;
+#else
 		if(depth == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; }
 		else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; }
+#endif
 		depth++;
 		icx = colx; icy = coly; icz = colz;
 		from = pos;
@@ -557,6 +567,9 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	// trace.h:91-101, innermost first
 	if(depth >= 2)
 	{
+#ifdef PWN_LDS_STACK
+		const float st_refl1 = STK(1, 0), st_fog1 = STK(1, 1), sc1x = STK(1, 2), sc1y = STK(1, 3), sc1z = STK(1, 4);
+#endif
 		const float r1 = st_refl1, q1 = 1.0f - st_refl1;
 		vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
 		if(st_fog1 != 0.0f)
@@ -567,6 +580,9 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	}
 	if(depth >= 1)
 	{
+#ifdef PWN_LDS_STACK
+		const float st_refl0 = STK(0, 0), st_fog0 = STK(0, 1), sc0x = STK(0, 2), sc0y = STK(0, 3), sc0z = STK(0, 4);
+#endif
 		const float r0 = st_refl0, q0 = 1.0f - st_refl0;
 		vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw;
 		if(st_fog0 != 0.0f)
@@ -669,7 +685,8 @@ pwn_trace_kernel(pwn_trace_params P)
 
 			float dist = 0.0f, ox, oy, oz, ow;
 			bool have_dist;
-			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, dist, have_dist, cnt);
+			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, dist, have_dist, cnt,
+				(float *)(lds_raw + ((P.blob_bytes + 15u) & ~15u)) + threadIdx.x);
 			size_t o = (size_t)y * (size_t)P.w + (size_t)x;
 			P.sbuf[o] = ftoint_lane(ox) | (ftoint_lane(oy) << 8) | (ftoint_lane(oz) << 16) | (ftoint_lane(ow) << 24);
 			if(have_dist) P.zbuf[o] = dist;
@@ -717,6 +734,15 @@ extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size
 
 // resident 256-thread workgroups per CU for this variant and LDS size
 extern "C" int pwn_trace_tile_h(void) { return TILE_H; }
+// LDS a workgroup needs beyond the table blob
+extern "C" unsigned pwn_trace_lds_extra(void)
+{
+#ifdef PWN_LDS_STACK
+	return 10u * 4u * PWN_BLOCK;
+#else
+	return 0u;
+#endif
+}
 
 extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w)
 {

@@ -15,7 +15,7 @@
 	OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)
 
 #define KERNEL(NAME, ASMSTR) \
-__global__ void __launch_bounds__(1024) NAME(unsigned long long *out, float seed) \
+__global__ void __launch_bounds__(256) NAME(unsigned long long *out, float seed) \
 { \
 	float a = seed + threadIdx.x, b = seed * 3.0f; \
 	float r[16]; \
@@ -88,10 +88,12 @@ KERNEL(k_mix_vs,    "v_add_f32 %0, %16, %17\ns_add_u32 s4, s4, 1\nv_add_f32 %1, 
 template<int OPS> static void run(const char *name, void (*k)(unsigned long long *, float), unsigned long long *d, int ncu)
 {
 	printf("%-12s", name);
-	for(int wps = 1; wps <= 8; wps *= 2)
+	const int wlist[] = { 1, 2, 4, 5, 6, 8 };
+	for(int wps : wlist)
 	{
-		int threads = 64 * 4 * (wps > 4 ? 4 : wps);     // 4 SIMDs x wps waves (two blocks per CU at 8)
-		int nblk = ncu * (wps > 4 ? 2 : 1);
+		// wps workgroups of 256 threads per CU: one wave of each on every SIMD
+		int threads = 256;
+		int nblk = ncu * wps;
 		int nw = ncu * 4 * wps;
 		hipMemset(d, 0, 8 * (nw + 1));
 		hipLaunchKernelGGL(k, dim3(nblk), dim3(threads), 0, 0, d, 1.0f);
@@ -101,8 +103,7 @@ template<int OPS> static void run(const char *name, void (*k)(unsigned long long
 		hipMemcpy(h.data(), d, 8 * (nw + 1), hipMemcpyDeviceToHost);
 		double s = 0, q = 0; for(int i = 1; i <= nw; i++) { s += (double)(h[i] >> 24); q += (double)(h[i] & 0xffffff); }
 		double per = s / nw / ((double)ITER * OPS * wps);
-		double ns = q / nw * 10.0;   // s_memrealtime: 100 MHz
-		printf("  w%d: %5.2f tick %5.3f ns (%.2f GHz)", wps, per, ns / ((double)ITER * OPS * wps), s / nw / ns);
+		printf("  w%d: %5.2f", wps, per);
 	}
 	printf("   cycles per wave-instruction per SIMD\n");
 }
