@@ -30,6 +30,7 @@ struct pwn_blur_params
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
 extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w);
 extern "C" int pwn_trace_tile_h(void);
+extern "C" int pwn_trace_tile_w(void);
 extern "C" unsigned pwn_trace_lds_extra(void);
 extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
@@ -385,7 +386,8 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	frame_setup(c->w, c->h, cam, &P);
 	P.sec_current = sec;
 	P.w = c->w; P.h = c->h; P.y0 = y0; P.y1 = y1;
-	P.tiles_x = (c->w + 31) / 32;
+	const int tw = pwn_trace_tile_w();
+	P.tiles_x = (c->w + tw - 1) / tw;
 	const int th = pwn_trace_tile_h();
 	P.tiles_total = P.tiles_x * ((y1 - y0 + th - 1) / th);
 	P.blob_bytes = (uint32_t)c->blob.size();

@@ -36,8 +36,8 @@ enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
 #ifndef PWN_BLOCK
 #define PWN_BLOCK 256
 #endif
-#define TILE_W 32
-#define TILE_H (PWN_BLOCK / 32)
+#define TILE_W (PWN_BLOCK / 8)    // a workgroup covers TILE_W x 8 pixels = PWN_BLOCK/256 sub-tiles of 32 x 8
+#define TILE_H 8
 
 // min waves per SIMD the register allocator must leave room for (Makefile MINW)
 #ifndef PWN_MIN_WAVES
@@ -115,14 +115,16 @@ struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps; };
 template<bool COUNT, bool HAS_W>
 __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uint32_t seed,
 	Vec<HAS_W> from, Vec<HAS_W> iray, float &out_x, float &out_y, float &out_z, float &out_w,
-	float &dist, bool &have_dist, Counters &cnt, float *stk)
+	float *zpix, Counters &cnt, float *stk)
 {
 	typedef Vec<HAS_W> V;
 	// icol (screen.h:24).  Its w lane, and the w lane of every surface colour, is
 	// x * 0.0f (COL_* have a = 0, defs.h:17-19; spheres get b,g,r only, script.h:30-32):
 	// +-0 for any finite input, and the sign of a zero never reaches a pixel, so the
 	// w lanes of icol and of the composite stack are not kept.
+#ifndef PWN_LDS_STACK
 	float icx = 1.0f, icy = 1.0f, icz = 1.0f;
+#endif
 #ifdef PWN_LDS_STACK
 	// the composite stack (reflectivity, fog, colour of the two bounced-off surfaces) lives in
 	// LDS, one float per thread and slot (stride PWN_BLOCK: conflict-free), not in registers
@@ -134,7 +136,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #endif
 	int depth = 0;
 	float vx, vy, vz, vw;
-	have_dist = false;
 
 #pragma unroll 1
 	for(;;)
@@ -481,7 +482,9 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			break;
 		}
 		if(ev == EV_WALL && base == BASE_ROOM_Y) { ldir = ldy; base = (gyp ? BASE_CEIL : BASE_FLOOR); }
-		if(depth == 0) { dist = (ev == EV_SPHERE ? aux_dist : cdist); have_dist = true; }
+		// zbuf = the PRIMARY ray's hit distance (trace.h:102-105); a primary ray that ran out of steps
+		// leaves the old depth in place (trace.h:677)
+		if(depth == 0) *zpix = (ev == EV_SPHERE ? aux_dist : cdist);
 
 		float colx, coly, colz, refl;
 		if(ev == EV_WALL)
@@ -498,6 +501,11 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			if(diffuse < 0.0f) diffuse = 0.0f;
 			const float amb = 0.1f;
 			diffuse = (1.0f - amb) * diffuse + amb;
+#ifdef PWN_LDS_STACK
+			// icol of a bounced ray = the colour of the surface it left (trace.h:90): the stack entry below
+			float icx = 1.0f, icy = 1.0f, icz = 1.0f;
+			if(depth > 0) { icx = STK(depth - 1, 2); icy = STK(depth - 1, 3); icz = STK(depth - 1, 4); }
+#endif
 			colx = diffuse * (icx * bx); coly = diffuse * (icy * by); colz = diffuse * (icz * bz);
 			refl = (ldir == FYN ? 0.7f : 0.25f);
 		}
@@ -559,7 +567,9 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; }
 #endif
 		depth++;
+#ifndef PWN_LDS_STACK
 		icx = colx; icy = coly; icz = colz;
+#endif
 		from = pos;
 		iray = ray;
 	}
@@ -630,8 +640,9 @@ pwn_trace_kernel(pwn_trace_params P)
 	// left / right half of rows 4k .. 4k+3
 	const int half = wave & 1;
 	const int l16 = lane & 15;
-	const int lx = half * 16 + l16;
-	const int ly = (wave >> 1) * 4 + (lane >> 4);
+	const int sub = wave >> 2;                           // which 32 x 8 sub-tile of the workgroup's tile
+	const int lx = sub * 32 + half * 16 + l16;
+	const int ly = ((wave >> 1) & 1) * 4 + (lane >> 4);
 
 	Counters cnt = { 0, 0, 0, 0, 0, 0 };
 
@@ -643,8 +654,8 @@ pwn_trace_kernel(pwn_trace_params P)
 	for(int tile = blockIdx.x; tile < P.tiles_total; tile += gridDim.x)
 	{
 		int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-		int cx0 = tx * TILE_W;
-		int x = cx0 + lx, y = P.y0 + ty * TILE_H + ly;
+		int cx0 = tx * TILE_W + sub * 32;                 // the 32-pixel tile of screen.h:6-7 this wave is in
+		int x = tx * TILE_W + lx, y = P.y0 + ty * TILE_H + ly;
 
 		// screen.h:12-18, in the order the reference build evaluates it:
 		// rayl = (cx*rdx + rayb) + y*rdy, then one "+= rdx" per pixel of the
@@ -683,13 +694,11 @@ pwn_trace_kernel(pwn_trace_params P)
 			seed *= seed * seed;
 			seed *= seed * seed;
 
-			float dist = 0.0f, ox, oy, oz, ow;
-			bool have_dist;
-			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, dist, have_dist, cnt,
+			float ox, oy, oz, ow;
+			const size_t o = (size_t)y * (size_t)P.w + (size_t)x;
+			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt,
 				(float *)(lds_raw + ((P.blob_bytes + 15u) & ~15u)) + threadIdx.x);
-			size_t o = (size_t)y * (size_t)P.w + (size_t)x;
 			P.sbuf[o] = ftoint_lane(ox) | (ftoint_lane(oy) << 8) | (ftoint_lane(oz) << 16) | (ftoint_lane(ow) << 24);
-			if(have_dist) P.zbuf[o] = dist;
 		}
 	}
 
@@ -734,6 +743,7 @@ extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size
 
 // resident 256-thread workgroups per CU for this variant and LDS size
 extern "C" int pwn_trace_tile_h(void) { return TILE_H; }
+extern "C" int pwn_trace_tile_w(void) { return TILE_W; }
 // LDS a workgroup needs beyond the table blob
 extern "C" unsigned pwn_trace_lds_extra(void)
 {
