@@ -436,3 +436,19 @@ def test_sphere_uploads_between_launches_in_flight(oracle_lib):
         assert (pres[i].cpu().numpy().view(np.uint32) == b).all(), i
         assert (zs[i].cpu().numpy().view(np.uint32) == zb.view(np.uint32)).all(), i
     r.close()
+
+
+def test_two_contexts_interleaved(oracle_lib, cases):
+    """Two live contexts of different sizes and levels, frames interleaved: nothing is shared
+    between contexts but the per-device launch attributes."""
+    a = next(x for x in cases if x["name"] == "level_pose1_320x240")
+    b = next(x for x in cases if x["name"] == "synth64_cam1_1920x1080")
+    ra, rb = _renderer(a["w"], a["h"]), _renderer(b["w"], b["h"])
+    ra.level_load(level_path(a["level"])); ra.set_objects(load_spheres(a["spheres"]))
+    rb.level_load(level_path(b["level"])); rb.set_objects(load_spheres(b["spheres"]))
+    for _ in range(3):
+        fa, _ = ra.trace_screen_centred(np.array(a["cam"], np.float32), a["sec"])
+        fb, _ = rb.trace_screen_centred(np.array(b["cam"], np.float32), b["sec"])
+        assert _fnv(oracle_lib, fa) == a["post"]
+        assert _fnv(oracle_lib, fb) == b["post"]
+    ra.close(); rb.close()
