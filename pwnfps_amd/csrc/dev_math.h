@@ -17,12 +17,13 @@
 
 // The libm restatements are always inlined.  As real (noinline) device functions
 // they were correct in isolation, but the 4-lane trace variants then rendered wrong
-// pixels in lanes 0/1 of some waves on ~10 % of random scenes, and whether they did
-// depended on the LAYOUT of the code object (appending an unrelated kernel made it
-// go away; -O1 too): hipcc 7.2 keeps SGPR spills such as a non-leaf callee's return
-// address in VGPR lanes via v_writelane, and a value the caller kept live across
-// the call was overwritten.  With no calls there is nothing to get wrong (and no
-// scratch); tools/fuzz_parity.py is the regression check.
+// pixels on ~10 % of random scenes, and whether they did depended on the LAYOUT of
+// the code object (identical kernel code; appending an unrelated kernel made it go
+// away; -O1 too).  The root cause was not isolated - the observations fit a callee
+// clobbering a register in which the caller keeps a value (hipcc 7.2 keeps SGPR
+// spills such as a non-leaf callee's return address in VGPR lanes via v_writelane).
+// With no calls there is nothing of that kind to get wrong (and no scratch);
+// tools/fuzz_parity.py is the regression check.
 #define PWN_LIBM_ATTR __forceinline__
 
 struct v4 { float x, y, z, w; };
