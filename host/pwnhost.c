@@ -5,14 +5,19 @@
  * include/pwnhip.h: no HIP, no C++ and no Python on this side of the ABI.
  *
  * SDL and Lua are not in this image, so "present" writes the upscaled
- * surface as a binary PPM (the role of SDL_Flip, main.c:109) and the
- * objects come from a text file instead of game.lua's obj_set calls
- * (script.h:10-40): one sphere per line,
+ * surface as a binary PPM (the role of SDL_Flip, main.c:109).  The objects
+ * come either from a text file of obj_set "sphere" arguments in obj_set's
+ * own order (script.h:10-40), one sphere per line,
  *     r refl x y z  b g r
- * which are obj_set's "sphere" arguments in its own order.
+ * or (-g) from the shipped game script restated in C (game_script.c), which
+ * is ticked once per frame like main.c:127-140 does.
  *
- *   pwnhost level.txt [-s spheres.txt] [-w W] [-h H] [-x SCALE] [-n FRAMES]
- *           [-a TURN_PER_FRAME] [-p PITCH] [-b BLUR_PASSES] [-o out.ppm] [-d DEVICE]
+ *   pwnhost level.txt [-s spheres.txt | -g game_objects.txt] [-w W] [-h H]
+ *           [-x SCALE] [-n FRAMES] [-t SECONDS_PER_FRAME] [-a TURN_PER_FRAME]
+ *           [-p PITCH] [-b BLUR_PASSES] [-o out.ppm] [-d DEVICE] [-v 1]
+ *
+ * -t fixes the clock step (the reference uses wall time, main.c:112-114), which
+ * makes a run reproducible; -v 1 prints every frame's hash.
  *
  * Build: make -C host      (gcc only; links libpwnhip.so by path)
  */
@@ -24,6 +29,7 @@
 #include <time.h>
 
 #include "pwnhip.h"
+#include "game_script.h"
 
 /* the globals a reference host owns (main.c:26-34) */
 static int rwidth = 320, rheight = 200, rscale = 3;
@@ -111,9 +117,9 @@ static uint64_t fnv64(const uint32_t *p, size_t n)
 
 int main(int argc, char **argv)
 {
-	const char *level = NULL, *sphfile = NULL, *out = NULL;
-	int frames = 1, device = 0, blur = 1, pitch = 0;
-	float turn = 0.0f;
+	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL;
+	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0;
+	float turn = 0.0f, fixed_dt = -1.0f;
 	for(int i = 1; i < argc; i++)
 	{
 		if(argv[i][0] != '-') { level = argv[i]; continue; }
@@ -121,6 +127,9 @@ int main(int argc, char **argv)
 		switch(argv[i][1])
 		{
 			case 's': sphfile = argv[++i]; break;
+			case 'g': gamefile = argv[++i]; break;
+			case 't': fixed_dt = (float)atof(argv[++i]); break;
+			case 'v': verbose = atoi(argv[++i]); break;
 			case 'w': rwidth = atoi(argv[++i]); break;
 			case 'h': rheight = atoi(argv[++i]); break;
 			case 'x': rscale = atoi(argv[++i]); break;
@@ -135,8 +144,8 @@ int main(int argc, char **argv)
 	}
 	if(level == NULL)
 	{
-		fprintf(stderr, "usage: pwnhost level.txt [-s spheres.txt] [-w W] [-h H] [-x SCALE] [-n FRAMES] "
-			"[-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE]\n");
+		fprintf(stderr, "usage: pwnhost level.txt [-s spheres.txt | -g game_objects.txt] [-w W] [-h H] [-x SCALE] "
+			"[-n FRAMES] [-t SEC_PER_FRAME] [-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE] [-v 1]\n");
 		return 2;
 	}
 	if(rscale < 1) rscale = 1;
@@ -163,6 +172,15 @@ int main(int argc, char **argv)
 	pwn_sphere *sph = NULL;
 	int nsph = 0;
 	if(sphfile != NULL && (nsph = load_spheres(sphfile, &sph)) < 0) { fprintf(stderr, "cannot read %s\n", sphfile); pwn_destroy(ctx); return 1; }
+	game_script game;
+	if(gamefile != NULL)                                                         /* script_newvm, main.c:56 */
+	{
+		rc = game_script_init(&game, ctx, gamefile);
+		if(rc == -100) { fprintf(stderr, "cannot read %s\n", gamefile); pwn_destroy(ctx); return 1; }
+		CHK(rc);
+	}
+	else
+		CHK(pwn_upload_spheres(ctx, sph, nsph));
 
 	float ang = 0.0f;
 	double t_first = 0.0, t_rest = 0.0;
@@ -174,13 +192,18 @@ int main(int argc, char **argv)
 		cam[12] = 0.5f + (float)spawn[0]; cam[13] = 0.5f; cam[14] = 0.5f + (float)spawn[1];
 
 		double t0 = now_s();
-		CHK(pwn_upload_spheres(ctx, sph, nsph));                                /* level_prepare_render, main.c:95 */
+		CHK(pwn_prepare_render(ctx));                                           /* level_prepare_render, main.c:95 */
 		CHK(pwn_trace_screen_centred(ctx, cam, sec_current, sbuf, zbuf));       /* main.c:107 */
 		CHK(pwn_screen_upscale(ctx, NULL, rscale, surface.pitch, surface.pixels)); /* main.c:108 */
 		double dt = now_s() - t0;
 		if(f == 0) t_first = dt; else t_rest += dt;
 
-		sec_current += (float)dt;                                                /* main.c:112-114 */
+		if(verbose)
+			printf("frame %d sec %.9g fnv64 %016llx\n", f, (double)sec_current, (unsigned long long)fnv64(sbuf, npix));
+		float tdiff = fixed_dt >= 0.0f ? fixed_dt : (float)dt;
+		sec_current += tdiff;                                                    /* main.c:112-114 */
+		if(gamefile != NULL)
+			CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)tdiff));   /* main.c:127-140 */
 		ang += turn;
 	}
 

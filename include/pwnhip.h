@@ -83,6 +83,35 @@ int pwn_upload_spheres(pwn_ctx *ctx, const pwn_sphere *spheres, int n);
 int pwn_get_bins(pwn_ctx *ctx, uint16_t counts[4096], int32_t *idx, int cap);
 
 /*
+ * The object table behind those lists, driven the way game.lua drives the
+ * reference (script.h:1-64): lv->objs[OBJ_MAX] (defs.h:4,98-99).
+ *   pwn_obj_new        level_obj_new (level.h:41-62): first freed slot, else
+ *                      append; returns the object's index, PWN_ENOMEM when all
+ *                      PWN_OBJ_MAX slots are taken (the reference returns NULL)
+ *   pwn_obj_set_sphere obj_set(o, "sphere", r, refl, x, y, z, b, g, r)
+ *                      (script.h:10-40); Lua numbers are doubles and are
+ *                      narrowed to float on store, as there
+ *   pwn_obj_free       obj_free (script.h:42-51): the slot becomes reusable
+ *   pwn_level_get      level_get(cx, cz) (script.h:53-64): the cell character
+ *                      under get_cell's clamp (util.h:151-158)
+ *   pwn_prepare_render level_prepare_render (level.h:64-81): bin every object
+ *                      that is not free, in table order, and upload; an object
+ *                      that was created but never set is PWN_EINVAL (the
+ *                      reference aborts, level.h:34-37)
+ *   pwn_get_objects    the live spheres in table order (at most cap); returns
+ *                      their number
+ * pwn_upload_spheres replaces the whole table by n set spheres.
+ */
+#define PWN_OBJ_MAX 10000
+int pwn_obj_new(pwn_ctx *ctx);
+int pwn_obj_set_sphere(pwn_ctx *ctx, int obj, double r, double refl, double x, double y, double z,
+	double cb, double cg, double cr);
+int pwn_obj_free(pwn_ctx *ctx, int obj);
+int pwn_level_get(pwn_ctx *ctx, int cx, int cz);
+int pwn_prepare_render(pwn_ctx *ctx);
+int pwn_get_objects(pwn_ctx *ctx, pwn_sphere *out, int cap);
+
+/*
  * trace_screen_centred(lv, 0, 0, rwidth, rheight, &cam) (screen.h:31-124,
  * called at main.c:107) with sec_current (defs.h:23) passed explicitly.
  * cam = mat4 rows x,y,z,w (defs.h:46-52).  Blocking.  Fills the caller's

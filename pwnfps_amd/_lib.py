@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("PWNHIP_LIB") or os.path.join(_HERE, "libpwnhip.so")
 
 PWN_OK, PWN_EINVAL, PWN_ENODEV, PWN_ENOMEM, PWN_EIO, PWN_EHIP, PWN_ENOLEVEL, PWN_ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
 PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS = 1, 2
+PWN_OBJ_MAX = 10000
 (PROBE_RCP, PROBE_RSQRT, PROBE_SINF, PROBE_COSF, PROBE_EXPF, PROBE_SQRT, PROBE_DIV,
  PROBE_FTOINT, PROBE_RANDFS, PROBE_SIN_OF_PAIR, PROBE_COS_OF_PAIR) = range(11)
 
@@ -30,7 +31,7 @@ class Stats(C.Structure):
 
 
 # every symbol include/pwnhip.h declares: (name, restype, argtypes)
-_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+_vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
 ABI = [
     ("pwn_init", _i, [C.POINTER(_vp), _i, _i, _i]),
     ("pwn_destroy", None, [_vp]),
@@ -43,6 +44,12 @@ ABI = [
     ("pwn_get_level", _i, [_vp, _vp, _vp, _vp]),
     ("pwn_upload_spheres", _i, [_vp, _vp, _i]),
     ("pwn_get_bins", _i, [_vp, _vp, _vp, _i]),
+    ("pwn_obj_new", _i, [_vp]),
+    ("pwn_obj_set_sphere", _i, [_vp, _i, _d, _d, _d, _d, _d, _d, _d, _d]),
+    ("pwn_obj_free", _i, [_vp, _i]),
+    ("pwn_level_get", _i, [_vp, _i, _i]),
+    ("pwn_prepare_render", _i, [_vp]),
+    ("pwn_get_objects", _i, [_vp, _vp, _i]),
     ("pwn_trace_screen_centred", _i, [_vp, _vp, _f, _vp, _vp]),
     ("pwn_trace_rows_device", _i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
     ("pwn_blur_rows_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
@@ -60,6 +67,16 @@ def load():
             "pwnfps_amd: %s is missing -- build it with `make -C pwnfps_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
             "There is no CPU fallback." % LIB_PATH)
+    # One process, one HIP runtime.  The PyTorch wheel ships its own libamdhip64 /
+    # libhsa-runtime64; if libpwnhip.so pulled in /opt/rocm's copy first and torch then
+    # brought its own, the second runtime to initialise finds no device (pwn_init ->
+    # PWN_ENODEV).  Loading torch first makes libpwnhip.so bind to the copy torch uses,
+    # which is also what lets the strip entry points take torch's device pointers and
+    # streams.  Without torch (the C host) the library uses /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in ABI:
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete

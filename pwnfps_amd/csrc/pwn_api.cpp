@@ -50,8 +50,10 @@ struct pwn_ctx
 	uint8_t cells[4096];
 	pwn_portal pmap[26];
 	int32_t spawn[2];
-	std::vector<pwn_sphere> spheres;
+	std::vector<pwn_sphere> spheres;          // the live spheres the current lists index
 	std::vector<int32_t> bin_off, bin_idx;
+	std::vector<pwn_sphere> objs;             // lv->objs (defs.h:98): every slot ever handed out
+	std::vector<uint8_t> obj_typ;             // P_INVAL / P_FREE / P_SPHERE (defs.h:55-60)
 
 	std::vector<uint8_t> blob;       // host image of the LDS blob
 	uint8_t *d_blob; size_t d_blob_cap;
@@ -318,9 +320,110 @@ extern "C" int pwn_get_level(pwn_ctx *c, uint8_t data[4096], pwn_portal pmap[26]
 	return PWN_OK;
 }
 
+enum { OBJ_INVAL = 0, OBJ_FREE = 1, OBJ_SPHERE = 2 };   // defs.h:55-60
+
+// level_prepare_render's binning + upload for a compact list of live spheres
+static int upload_live(pwn_ctx *c, const pwn_sphere *s, int n);
+
 extern "C" int pwn_upload_spheres(pwn_ctx *c, const pwn_sphere *s, int n)
 {
-	if(c == NULL || n < 0 || (n > 0 && s == NULL)) return PWN_EINVAL;
+	if(c == NULL || n < 0 || n > PWN_OBJ_MAX || (n > 0 && s == NULL)) return PWN_EINVAL;
+	int rc = upload_live(c, s, n);
+	if(rc == PWN_OK)
+	{
+		c->objs.assign(s, s + n);
+		c->obj_typ.assign((size_t)n, OBJ_SPHERE);
+	}
+	return rc;
+}
+
+extern "C" int pwn_obj_new(pwn_ctx *c)
+{
+	if(c == NULL) return PWN_EINVAL;
+	for(size_t i = 0; i < c->obj_typ.size(); i++)
+		if(c->obj_typ[i] == OBJ_FREE) { c->obj_typ[i] = OBJ_INVAL; return (int)i; }
+	if(c->obj_typ.size() >= (size_t)PWN_OBJ_MAX)
+	{
+		snprintf(c->err, sizeof(c->err), "obj_new: all %d object slots are taken", PWN_OBJ_MAX);
+		return PWN_ENOMEM;
+	}
+	c->objs.push_back(pwn_sphere());
+	c->obj_typ.push_back(OBJ_INVAL);
+	return (int)c->obj_typ.size() - 1;
+}
+
+static bool obj_ok(pwn_ctx *c, int obj, const char *who)
+{
+	if(c == NULL) return false;
+	if(obj >= 0 && (size_t)obj < c->obj_typ.size() && c->obj_typ[(size_t)obj] != OBJ_FREE) return true;
+	snprintf(c->err, sizeof(c->err), "%s: %d is not an object", who, obj);
+	return false;
+}
+
+extern "C" int pwn_obj_set_sphere(pwn_ctx *c, int obj, double r, double refl, double x, double y, double z,
+	double cb, double cg, double cr)
+{
+	if(!obj_ok(c, obj, "obj_set")) return PWN_EINVAL;
+	pwn_sphere &s = c->objs[(size_t)obj];
+	s.r = (float)r; s.refl = (float)refl;
+	s.x = (float)x; s.y = (float)y; s.z = (float)z;
+	s.cb = (float)cb; s.cg = (float)cg; s.cr = (float)cr;
+	c->obj_typ[(size_t)obj] = OBJ_SPHERE;
+	return PWN_OK;
+}
+
+extern "C" int pwn_obj_free(pwn_ctx *c, int obj)
+{
+	if(!obj_ok(c, obj, "obj_free")) return PWN_EINVAL;
+	c->obj_typ[(size_t)obj] = OBJ_FREE;
+	return PWN_OK;
+}
+
+extern "C" int pwn_level_get(pwn_ctx *c, int cx, int cz)
+{
+	if(c == NULL) return PWN_EINVAL;
+	if(!c->have_level) return PWN_ENOLEVEL;
+	if(cx < 0 || cx >= 64) cx = 0;
+	if(cz < 0 || cz >= 64) cz = 0;
+	return c->cells[cz * 64 + cx];
+}
+
+static int live_objects(pwn_ctx *c, std::vector<pwn_sphere> &live)
+{
+	for(size_t i = 0; i < c->obj_typ.size(); i++)
+	{
+		if(c->obj_typ[i] == OBJ_FREE) continue;
+		if(c->obj_typ[i] != OBJ_SPHERE)
+		{
+			snprintf(c->err, sizeof(c->err), "object %d was created but never set", (int)i);
+			return PWN_EINVAL;
+		}
+		live.push_back(c->objs[i]);
+	}
+	return PWN_OK;
+}
+
+extern "C" int pwn_prepare_render(pwn_ctx *c)
+{
+	if(c == NULL) return PWN_EINVAL;
+	std::vector<pwn_sphere> live;
+	int rc = live_objects(c, live);
+	if(rc != PWN_OK) return rc;
+	return upload_live(c, live.data(), (int)live.size());
+}
+
+extern "C" int pwn_get_objects(pwn_ctx *c, pwn_sphere *out, int cap)
+{
+	if(c == NULL || cap < 0 || (cap > 0 && out == NULL)) return PWN_EINVAL;
+	std::vector<pwn_sphere> live;
+	int rc = live_objects(c, live);
+	if(rc != PWN_OK) return rc;
+	for(size_t i = 0; i < live.size() && i < (size_t)cap; i++) out[i] = live[i];
+	return (int)live.size();
+}
+
+static int upload_live(pwn_ctx *c, const pwn_sphere *s, int n)
+{
 	(void)hipSetDevice(c->device);
 	std::vector<int32_t> off(4097, 0);
 	int nb = pwn_bin_spheres(s, n, off.data(), NULL, 0);

@@ -92,6 +92,35 @@ class Renderer:
         self._chk(lib.pwn_upload_spheres(self._ctx, spheres.ctypes.data if len(spheres) else None,
                                          len(spheres)), "pwn_upload_spheres")
 
+    def obj_new(self):
+        """obj_new() (script.h:1-8): index of a fresh object slot."""
+        return self._chk(lib.pwn_obj_new(self._ctx), "pwn_obj_new")
+
+    def obj_set(self, obj, typ, r, refl, x, y, z, cb, cg, cr):
+        """obj_set(o, "sphere", r, refl, x, y, z, b, g, r) (script.h:10-40)."""
+        if str(typ).lower() != "sphere":
+            raise ValueError('obj_set: invalid typ "%s"' % typ)
+        self._chk(lib.pwn_obj_set_sphere(self._ctx, int(obj), r, refl, x, y, z, cb, cg, cr), "pwn_obj_set_sphere")
+        return obj
+
+    def obj_free(self, obj):
+        self._chk(lib.pwn_obj_free(self._ctx, int(obj)), "pwn_obj_free")
+
+    def level_get(self, cx, cz):
+        """level_get(cx, cz) (script.h:53-64): the cell as a 1-character string."""
+        return chr(self._chk(lib.pwn_level_get(self._ctx, int(cx), int(cz)), "pwn_level_get"))
+
+    def level_prepare_render(self):
+        """level_prepare_render (level.h:64-81) over the object table."""
+        self._chk(lib.pwn_prepare_render(self._ctx), "pwn_prepare_render")
+
+    def get_objects(self):
+        n = self._chk(lib.pwn_get_objects(self._ctx, None, 0), "pwn_get_objects")
+        out = np.zeros(n, SPHERE_DTYPE)
+        if n:
+            self._chk(lib.pwn_get_objects(self._ctx, out.ctypes.data, n), "pwn_get_objects")
+        return out
+
     def get_bins(self):
         counts = np.zeros(4096, np.uint16)
         n = self._chk(lib.pwn_get_bins(self._ctx, counts.ctypes.data, None, 0), "pwn_get_bins")

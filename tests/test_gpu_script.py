@@ -1,0 +1,190 @@
+"""The object calls of the C ABI (pwn_obj_new / _set_sphere / _free,
+pwn_level_get, pwn_prepare_render: script.h:1-64, level.h:41-81) and the game
+script on top of them, on the GPU: scripted runs frame by frame against the
+oracle and the compiled reference's hashes (tests/golden/anim.npz), the
+Python and the C restatement of the script against each other."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, ROOT, level_path
+from pwnfps_amd.script import DATA, GameScript, ObjectTable, frame_times
+
+pytestmark = pytest.mark.gpu
+W, H = 320, 200
+
+
+@pytest.fixture(scope="module")
+def anim():
+    return np.load(os.path.join(GOLD, "anim.npz"))
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _renderer():
+    import pwnfps_amd
+    r = pwnfps_amd.Renderer(W, H)
+    r.level_load(level_path("pwnfps_level"))
+    return r
+
+
+def test_object_calls_follow_the_host_table():
+    import pwnfps_amd
+    r = _renderer()
+    data, _, _ = r.get_level()
+    T = ObjectTable(data)
+    rng = np.random.default_rng(5)
+    live = []
+    for step in range(300):
+        op = rng.integers(0, 4)
+        if op <= 1 or not live:
+            a, b = r.obj_new(), T.obj_new()
+            assert a == b
+            args = (rng.uniform(0.05, 0.4), rng.choice([0.0, 0.3, 0.6]), rng.uniform(1, 30), rng.uniform(0.1, 1.5),
+                    rng.uniform(1, 26), *rng.uniform(0, 1.3, 3))
+            r.obj_set(a, "sphere", *args)
+            T.obj_set(b, "sphere", *args)
+            live.append(a)
+        elif op == 2:
+            h = live.pop(int(rng.integers(len(live))))
+            r.obj_free(h)
+            T.obj_free(h)
+        else:
+            h = live[int(rng.integers(len(live)))]
+            args = (rng.uniform(0.05, 0.4), 0.5, rng.uniform(1, 30), 0.4, rng.uniform(1, 26), 1.0, 0.5, 0.25)
+            r.obj_set(h, "Sphere", *args)
+            T.obj_set(h, "Sphere", *args)
+        assert (bits(r.get_objects()) == bits(T.live())).all(), step
+    # binning goes over the live objects in table order (level.h:64-81)
+    r.level_prepare_render()
+    counts, idx = r.get_bins()
+    from oracle import Oracle
+    O = Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    O.set_spheres(T.live())
+    oc, oi = O.get_bins()
+    assert (counts == oc).all() and (idx == oi).all()
+    for (cx, cz) in ((9, 4), (-1, 5), (64, 5), (11, 99), (0, 0), (63, 63)):
+        assert r.level_get(cx, cz) == T.level_get(cx, cz)
+    # errors come back as codes (the reference aborts / raises a Lua error)
+    h = r.obj_new()
+    with pytest.raises(pwnfps_amd.PwnError) as e:
+        r.level_prepare_render()                 # created but never set (level.h:34-37)
+    assert e.value.code == -1 and "never set" in str(e.value)
+    r.obj_free(h)
+    r.level_prepare_render()
+    for bad in (-1, 99999, h):
+        with pytest.raises(pwnfps_amd.PwnError):
+            r.obj_set(bad, "sphere", 1, 1, 1, 1, 1, 1, 1, 1)
+        with pytest.raises(pwnfps_amd.PwnError):
+            r.obj_free(bad)
+    with pytest.raises(ValueError, match="invalid typ"):
+        r.obj_set(live[0], "cube", 1, 1, 1, 1, 1, 1, 1, 1)
+    # set_objects replaces the table
+    r.set_objects(T.live()[:3])
+    assert (bits(r.get_objects()) == bits(T.live()[:3])).all() and r.obj_new() == 3
+    r.close()
+
+
+def test_object_table_is_bounded():
+    import pwnfps_amd
+    from pwnfps_amd import _lib
+    r = pwnfps_amd.Renderer(64, 64)
+    for i in range(_lib.PWN_OBJ_MAX):
+        assert r.obj_new() == i
+    with pytest.raises(pwnfps_amd.PwnError) as e:     # level.h:54-55 returns NULL
+        r.obj_new()
+    assert e.value.code == -3
+    r.obj_free(1234)
+    assert r.obj_new() == 1234
+    r.close()
+
+
+@pytest.mark.parametrize("run", ["static", "chase"])
+def test_scripted_run_on_the_gpu(run, anim, oracle_lib):
+    """The frame loop of main.c:93-140 with the script driving the GPU context's
+    own object table: every frame bit-identical to the oracle, hashes equal to
+    the compiled reference's."""
+    from oracle import Oracle
+    r = _renderer()
+    g = GameScript(r)
+    O = Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    n = len(anim[run + "_sec"])
+    secs, ticks = frame_times(n, float(anim[run + "_dt"]))
+    nonfinite = anim[run + "_nonfinite"]
+    for f in range(n):
+        cam = anim[run + "_cam"][f]
+        r.level_prepare_render()
+        assert (bits(r.get_objects()) == bits(anim[run + "_spheres"][f])).all(), f
+        r.set_blur_passes(0)
+        pre, z = r.trace_screen_centred(cam, secs[f])
+        r.set_blur_passes(1)
+        post, z2 = r.trace_screen_centred(cam, secs[f])
+        O.set_spheres(anim[run + "_spheres"][f])
+        opre, oz = O.render(W, H, cam, sec=secs[f], blur=0)
+        opost, _ = O.render(W, H, cam, sec=secs[f], blur=1)
+        assert (pre == opre).all(), (run, f, np.argwhere(pre != opre)[:4].tolist())
+        assert (bits(z) == bits(oz)).all() and (bits(z2) == bits(oz)).all(), (run, f)
+        assert (post == opost).all(), (run, f)
+        want = anim[run + ("_hashes_nf" if nonfinite[f] else "_hashes")][f]
+        assert [oracle_lib.fnv64(pre), oracle_lib.fnv64(post), oracle_lib.fnv64(z)] == list(want), (run, f)
+        g.on_tick(*ticks[f])
+    r.close()
+
+
+def test_c_host_runs_the_script_like_the_python_mirror(anim, oracle_lib):
+    """host/pwnhost -g: game_script.c over the C ABI, fixed clock step; its
+    per-frame hashes are the reference's for the static run."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "pwnfps_amd", "csrc")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "host")], stdout=subprocess.DEVNULL)
+    n = len(anim["static_sec"])
+    p = subprocess.run([os.path.join(ROOT, "host", "pwnhost"), level_path("pwnfps_level"), "-g", DATA,
+                        "-w", str(W), "-h", str(H), "-x", "1", "-n", str(n), "-t", "0.05", "-v", "1"],
+                       capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    got = re.findall(r"frame (\d+) sec (\S+) fnv64 ([0-9a-f]{16})", p.stdout.decode())
+    assert len(got) == n
+    for f, (i, sec, h) in enumerate(got):
+        assert int(i) == f and np.float32(float(sec)) == anim["static_sec"][f]
+        assert h == anim["static_hashes"][f][1], f
+    # a longer run: the C script's cluster follows the Python script's, tick for tick
+    # (same frame hashes as the oracle-checked python path would need the frames; here
+    # the sphere tables are compared through a second context driven from Python)
+    r = _renderer()
+    g = GameScript(r)
+    r.set_blur_passes(1)
+    cam = anim["static_cam"][0]
+    secs, ticks = frame_times(60, 0.25)
+    want = []
+    for f in range(60):
+        r.level_prepare_render()
+        sb = r.trace_screen_centred(cam, secs[f], want_z=False)
+        want.append(oracle_lib.fnv64(sb))
+        g.on_tick(*ticks[f])
+    r.close()
+    p = subprocess.run([os.path.join(ROOT, "host", "pwnhost"), level_path("pwnfps_level"), "-g", DATA,
+                        "-w", str(W), "-h", str(H), "-x", "1", "-n", "60", "-t", "0.25", "-v", "1"],
+                       capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    got = [h for _, _, h in re.findall(r"frame (\d+) sec (\S+) fnv64 ([0-9a-f]{16})", p.stdout.decode())]
+    assert got == want
+
+
+
+def test_package_can_be_imported_before_torch():
+    """libpwnhip.so and torch have to share one HIP runtime whichever is asked for first."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import pwnfps_amd\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "r = pwnfps_amd.Renderer(64, 64)\n"
+            "x = torch.ones(4, device='cuda').sum().item()\n"
+            "print('ok', x)\n") % ROOT
+    p = subprocess.run(["python3", "-c", code], capture_output=True, timeout=300)
+    assert p.returncode == 0 and b"ok 4.0" in p.stdout, p.stderr.decode()[-2000:]

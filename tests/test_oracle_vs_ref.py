@@ -168,3 +168,32 @@ def test_fuzz_scenes_oracle_vs_reference():
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     assert "120 scenes, 0 mismatches" in p.stdout
+
+
+def test_axis_aligned_cameras_and_the_ramp_divide_by_zero(oracle_lib):
+    """Axis-aligned cameras give rays with exactly rational slopes; where such a
+    ray meets a ramp with ray.y == 0.5*ray.x the tilt divides by zero
+    (trace.h:447-461).  Those pixels are the only ones at which the reference's
+    two builds (shipped flags / plus -fno-finite-math-only) differ, and the
+    oracle follows the second, i.e. plain SSE/IEEE behaviour."""
+    if not refharness.available("nf"):
+        pytest.skip("oracle/_ref/libpwnref_nf.so not built")
+    R, N = refharness.RefHarness("tab"), refharness.RefHarness("nf")
+    O = oracle_lib.Oracle()
+    for X in (R, N, O):
+        X.load_level(level_path("pwnfps_level"))
+        X.set_spheres(load_spheres("t0"))
+    seen = 0
+    for (px, pz) in ((11.0, 6.0), (11.0, 5.5), (11.0, 5.0), (11.5, 4.5), (13.0, 2.5), (12.5, 6.0)):
+        for (vx, vz) in ((0, -1), (0, 1), (1, 0), (-1, 0)):
+            cam = np.zeros((4, 4), np.float32)
+            cam[0], cam[1], cam[2], cam[3] = (vz, 0, -vx, 0), (0, 1, 0, 0), (vx, 0, vz, 0), (px, 0.5, pz, 1)
+            a, za = R.render(320, 200, cam, sec=1.0, blur=0)
+            n, zn = N.render(320, 200, cam, sec=1.0, blur=0)
+            o, zo = O.render(320, 200, cam, sec=1.0, blur=0)
+            assert (n == o).all() and (zn.view(np.uint32) == zo.view(np.uint32)).all(), (px, pz, vx, vz)
+            assert (za.view(np.uint32) == zo.view(np.uint32)).all()
+            differ = a != o
+            assert not (differ & np.isfinite(zo)).any(), (px, pz, vx, vz)
+            seen += int(differ.sum())
+    assert seen > 0    # the case is really exercised

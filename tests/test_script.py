@@ -1,0 +1,131 @@
+"""The game script (game.lua restated, pwnfps_amd/script.py) and the object
+table it drives (script.h:1-64, level.h:41-81), without a GPU:
+
+  * the objects it creates at load are the golden t=0 sphere table
+  * ObjectTable follows level_obj_new / obj_free / level_prepare_render
+  * a scripted run reproduces the sphere tables in tests/golden/anim.npz, and the
+    oracle renders those frames to the hashes the COMPILED REFERENCE produced
+    (tools/gen_anim_golden.py)
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, level_path
+from pwnfps_amd.script import GameScript, ObjectTable, frame_times, load_object_rows, OBJ_MAX
+
+W, H = 320, 200
+
+
+@pytest.fixture(scope="module")
+def anim():
+    return np.load(os.path.join(GOLD, "anim.npz"))
+
+
+@pytest.fixture(scope="module")
+def level_cells():
+    return np.load(os.path.join(GOLD, "levels", "pwnfps_level_tables.npz"))["data"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_load_time_objects_are_the_golden_t0_table(level_cells):
+    T = ObjectTable(level_cells)
+    g = GameScript(T)
+    assert len(load_object_rows()) == 14 and g.oball == list(range(14))
+    want = np.load(os.path.join(GOLD, "spheres_t0.npy"))
+    assert (bits(T.live()) == bits(want)).all()
+
+
+def test_object_table_slot_reuse_and_errors():
+    T = ObjectTable()
+    a, b, c = T.obj_new(), T.obj_new(), T.obj_new()
+    assert (a, b, c) == (0, 1, 2)
+    with pytest.raises(ValueError, match="never set"):       # level.h:34-37: the reference aborts
+        T.live()
+    for i, h in enumerate((a, b, c)):
+        T.obj_set(h, "sphere", 0.1 * (i + 1), 0.5, i, 0.5, i, 1, 1, 1)
+    T.obj_free(b)
+    assert [float(r) for r in T.live()["r"]] == [np.float32(0.1), np.float32(0.1 * 3)]
+    assert T.obj_new() == b                                  # level.h:45-51: first gap is reused
+    T.obj_set(b, "SPHERE", 0.7, 0.5, 9, 0.5, 9, 1, 1, 1)     # strcasecmp (script.h:18)
+    assert [float(r) for r in T.live()["r"]] == [np.float32(0.1), np.float32(0.7), np.float32(0.1 * 3)]
+    with pytest.raises(ValueError, match="invalid typ"):
+        T.obj_set(a, "cube", 1, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(ValueError):
+        T.obj_free(17)
+    T.obj_free(c)
+    with pytest.raises(ValueError):
+        T.obj_set(c, "sphere", 1, 1, 1, 1, 1, 1, 1, 1)
+    # doubles are narrowed on store (script.h:22-32)
+    T.obj_set(a, "sphere", 0.1, 0.2, 9.5 + 0.3, 0.3, 5.5 - 0.3, 0.7, 0.7, 1.0)
+    assert T.live()["x"][0] == np.float32(9.5 + 0.3) and T.live()["r"][0] == np.float32(0.1)
+
+
+def test_object_table_is_bounded_like_objs():
+    T = ObjectTable()
+    T.slots = [("x",)] * OBJ_MAX
+    with pytest.raises(MemoryError):
+        T.obj_new()
+
+
+def test_level_get_clamps_like_get_cell(level_cells):
+    T = ObjectTable(level_cells)
+    assert T.level_get(9, 4) == chr(level_cells[4][9])
+    assert T.level_get(-1, 5) == chr(level_cells[5][0]) and T.level_get(64, 5) == chr(level_cells[5][0])
+    assert T.level_get(11, 99) == chr(level_cells[0][11])
+
+
+@pytest.mark.parametrize("run", ["static", "chase"])
+def test_scripted_run_reproduces_the_golden_sphere_tables(run, anim, level_cells):
+    T = ObjectTable(level_cells)
+    g = GameScript(T)
+    n = len(anim[run + "_sec"])
+    secs, ticks = frame_times(n, float(anim[run + "_dt"]))
+    assert (bits(np.array(secs, np.float32)) == bits(anim[run + "_sec"])).all()
+    for f in range(n):
+        assert (bits(T.live()) == bits(anim[run + "_spheres"][f])).all(), f
+        assert (g.obx, g.obz, g.obvx, g.obvz) == tuple(anim[run + "_centre"][f]), f
+        g.on_tick(*ticks[f])
+
+
+def test_cluster_patrols_open_cells_and_turns_at_walls(level_cells):
+    T = ObjectTable(level_cells)
+    g = GameScript(T)
+    headings = set()
+    _, ticks = frame_times(1200, 1.0 / 60.0)
+    for t in ticks:
+        g.on_tick(*t)
+        headings.add((g.obvx, g.obvz))
+        assert T.level_get(int(g.obx), int(g.obz)) != "."
+    assert len(headings) == 4
+    # the top sphere blinks (game.lua:36-40): both colours occur
+    g.on_tick(0.1, 0.0)
+    assert T.live()["cr"][1] == np.float32(1.3)
+    g.on_tick(0.3, 0.0)
+    assert T.live()["cr"][1] == np.float32(0.3)
+
+
+@pytest.mark.parametrize("run", ["static", "chase"])
+def test_oracle_renders_the_scripted_frames_like_the_reference(run, anim, oracle_lib):
+    from oracle import Oracle
+    O = Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    nonfinite = anim[run + "_nonfinite"]
+    assert (nonfinite == 0).all() if run == "static" else (nonfinite > 0).sum() == 3
+    for f in range(len(anim[run + "_sec"])):
+        O.set_spheres(anim[run + "_spheres"][f])
+        cam, sec = anim[run + "_cam"][f], float(anim[run + "_sec"][f])
+        pre, z = O.render(W, H, cam, sec=sec, blur=0)
+        post, _ = O.render(W, H, cam, sec=sec, blur=1)
+        got = [oracle_lib.fnv64(pre), oracle_lib.fnv64(post), oracle_lib.fnv64(z)]
+        # frames holding a pixel whose arithmetic left the finite range (1/0 in a ramp,
+        # trace.h:461) are defined by the reference built without -ffinite-math-only
+        want = anim[run + ("_hashes_nf" if nonfinite[f] else "_hashes")][f]
+        assert got == list(want), (run, f)
+        assert int((~np.isfinite(z)).sum()) == nonfinite[f]
+        if nonfinite[f]:
+            assert got[2] == anim[run + "_hashes"][f][2]     # depth agrees under both builds
