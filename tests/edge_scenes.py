@@ -52,6 +52,26 @@ def scenes(sphere_dtype):
     # large sec_current: the floor ripple angle leaves sinf/cosf's fast range (trace.h:42-46)
     out.append(Scene("sec_5000", None, 160, 96, 5000.0, spawn, spheres(14), True))
     out.append(Scene("sec_3e7", None, 64, 32, 3.0e7, spawn, spheres(14), True))
+    # sphere parameters nobody would script on purpose: zero / tiny / negative radius (c/r^2
+    # divides by zero, trace.h:277), a sphere around the camera, reflectivity outside [0,1],
+    # colours that are negative, huge or NaN, coincident spheres (strict '<' keeps the first,
+    # trace.h:281), spheres above and below the rooms
+    weird = {
+        "r0": [(0.0, 0.5, 9.5, 0.3, 5.5, 1, 1, 1)],
+        "r_tiny": [(1e-20, 0.5, 9.5, 0.3, 5.5, 1, 1, 1)],
+        "r_big": [(3.0, 0.5, 9.5, 0.3, 8.5, 1, 0.5, 0.2)],
+        "cam_inside": [(1.5, 0.6, 9.5, 0.5, 4.5, 1, 0.5, 0.2)],
+        "refl_gt1": [(0.3, 1.5, 9.5, 0.3, 5.5, 1, 1, 1)],
+        "refl_neg": [(0.3, -0.5, 9.5, 0.3, 5.5, 1, 1, 1)],
+        "col_neg_big": [(0.3, 0.5, 9.5, 0.3, 5.5, -1, 50, 1e30)],
+        "r_neg": [(-0.3, 0.5, 9.5, 0.3, 5.5, 1, 1, 1)],
+        "coincident": [(0.3, 0.5, 9.5, 0.3, 5.5, 1, 0, 0), (0.3, 0.5, 9.5, 0.3, 5.5, 0, 1, 0)],
+        "y_outside": [(0.3, 0.5, 9.5, 5.3, 5.5, 1, 1, 1), (0.3, 0.5, 9.5, -3.0, 5.5, 1, 1, 1)],
+        "nan_col": [(0.3, 0.5, 9.5, 0.3, 5.5, np.nan, 1, 1)],
+    }
+    for name, rows in weird.items():
+        for tag, c in (("", spawn), ("_axis", _cam(9.5, 0.5, 4.5))):
+            out.append(Scene("sphere_" + name + tag, None, 160, 100, 0.5, c, np.array(rows, sphere_dtype), True))
     # (A degenerate camera that makes every ray NaN is NOT a test input: the reference is
     # built with -ffast-math, i.e. -ffinite-math-only, so its NaN behaviour is whatever
     # the compiler happened to emit and is outside the contract.)
