@@ -52,11 +52,14 @@ def pmc_traffic(kernel, w, h):
         return None
 
 
-def pmc_issue_rate(kernel, w, h):
+def pmc_issue_rate(kernel, w, h, launch_ms):
     """What actually bounds the trace kernel: wave-instructions issued per
-    cycle and SIMD, from the same committed PMC summary, next to the rate a SIMD sustains
-    on this chip (tools/ubench/valu_rate.hip: one simple VALU instruction per 1.65 cycles at
-    4+ waves, 1.76 for a VALU/SALU mix)."""
+    SIMD and nanosecond -- instruction counts from the committed PMC summary (they do not
+    depend on the run), time from this run's HIP events -- next to the rates one SIMD was
+    measured to sustain on this chip under the same wall clock (tools/ubench/valu_rate.hip
+    with VALU_RATE_CALIBRATE=1, 5-8 waves per SIMD): plain VOP2 ALU ops 0.9-1.0, v_cmp and
+    VOP3 v_cndmask 0.55, v_rcp/v_sqrt 0.29, SALU 0.56, an alternating VALU/SALU stream 0.96-1.0
+    in total.  (Clocks sag under VALU load, so rates per cycle are not comparable between runs.)"""
     path = os.path.join(ROOT, "profiles", "pmc_latest.csv")
     try:
         meta = [l for l in open(path) if l.startswith("#")]
@@ -64,10 +67,13 @@ def pmc_issue_rate(kernel, w, h):
             return None
         rows = [l.rstrip("\n").rsplit(",", 3) for l in open(path)]
         v = {r[1]: float(r[3]) for r in rows if len(r) == 4 and kernel in r[0] and "<true" not in r[0]}
-        insts = v["SQ_INSTS_VALU"] + v["SQ_INSTS_SALU"] + v["SQ_INSTS_BRANCH"] + v["SQ_INSTS_LDS"]
-        cycles = v["GRBM_GUI_ACTIVE"] / 8.0                 # the counter sums the 8 XCDs
-        return {"wave_instructions_per_launch": int(insts), "cycles": int(cycles), "simds": 1024,
-                "issued_per_cycle_per_simd": round(insts / 1024.0 / cycles, 3), "sustainable_per_cycle_per_simd": 0.57,
+        scalar = v["SQ_INSTS_SALU"] + v["SQ_INSTS_BRANCH"]
+        insts = v["SQ_INSTS_VALU"] + scalar + v["SQ_INSTS_LDS"]
+        per = 1.0 / (1024.0 * launch_ms * 1e6)          # per SIMD and ns
+        return {"wave_instructions_per_launch": int(insts), "simds": 1024,
+                "valu_per_ns_per_simd": round(v["SQ_INSTS_VALU"] * per, 3), "valu_peak_per_ns_per_simd": 1.0,
+                "scalar_per_ns_per_simd": round(scalar * per, 3), "scalar_peak_per_ns_per_simd": 0.56,
+                "all_per_ns_per_simd": round(insts * per, 3), "mixed_stream_peak_per_ns_per_simd": 1.0,
                 "active_lanes_per_valu_instruction": round(v["SQ_THREAD_CYCLES_VALU"] / v["SQ_ACTIVE_INST_VALU"], 1)
                 if "SQ_ACTIVE_INST_VALU" in v else None}
     except (OSError, KeyError, ValueError, ZeroDivisionError):
@@ -323,7 +329,7 @@ def main():
                          "traffic": pmc_traffic("pwn_trace_kernel", w, h) if world == 1 else None,
                          "traffic_unit": "bytes/launch (PMC WRITE_SIZE + 2*FETCH_SIZE, profiles/pmc_latest.csv)",
                          "algorithmic_bytes_per_launch": TRACE_BYTES_PER_PIXEL * strip_pix,
-                         "instruction_issue": pmc_issue_rate("pwn_trace_kernel", w, h) if world == 1 else None,
+                         "instruction_issue": pmc_issue_rate("pwn_trace_kernel", w, h, trace_ms) if world == 1 and trace_ms > 0 else None,
                          "bytes_per_pixel": TRACE_BYTES_PER_PIXEL, "pixels_per_launch": strip_pix,
                          "avg_launch_ms": round(trace_ms, 4),
                          "note": "VALU/divergence-bound DDA: tables live in LDS, compulsory HBM traffic is the 8 B/pixel written"},

@@ -4,6 +4,8 @@
 // Output: cycles per wave-instruction per SIMD = elapsed / (ITER*16*waves_per_simd).
 //   hipcc --offload-arch=gfx950 -O2 -o valu_rate valu_rate.hip && ./valu_rate
 #include <hip/hip_runtime.h>
+#pragma clang diagnostic ignored "-Wunused-value"
+#pragma clang diagnostic ignored "-Wunused-result"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -96,16 +98,28 @@ template<int OPS> static void run(const char *name, void (*k)(unsigned long long
 		int nblk = ncu * wps;
 		int nw = ncu * 4 * wps;
 		hipMemset(d, 0, 8 * (nw + 1));
+		hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
 		hipLaunchKernelGGL(k, dim3(nblk), dim3(threads), 0, 0, d, 1.0f);
-		hipLaunchKernelGGL(k, dim3(nblk), dim3(threads), 0, 0, d, 1.0f);
+		const int NL = 8;                      // back-to-back launches under the host's clock
+		hipEventRecord(e0, 0);
+		for(int l = 0; l < NL; l++) hipLaunchKernelGGL(k, dim3(nblk), dim3(threads), 0, 0, d, 1.0f);
+		hipEventRecord(e1, 0);
 		hipDeviceSynchronize();
+		float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+		ms /= NL;
+		hipEventDestroy(e0); hipEventDestroy(e1);
 		std::vector<unsigned long long> h(nw + 1);
 		hipMemcpy(h.data(), d, 8 * (nw + 1), hipMemcpyDeviceToHost);
 		double s = 0, q = 0; for(int i = 1; i <= nw; i++) { s += (double)(h[i] >> 24); q += (double)(h[i] & 0xffffff); }
 		double per = s / nw / ((double)ITER * OPS * wps);
 		printf("  w%d: %5.2f", wps, per);
+		if(getenv("VALU_RATE_CALIBRATE"))
+			// s_memtime ticks against the 100 MHz s_memrealtime and against the host's event clock:
+			// tick frequency, and wave-instructions per SIMD per nanosecond of the whole launch
+			printf(" [tick %.0f MHz, launch %.3f ms = %.3f instr/ns/SIMD]", s / q * 100.0, ms,
+				(double)ITER * OPS * wps / (ms * 1e6));
 	}
-	printf("   cycles per wave-instruction per SIMD\n");
+	printf("   s_memtime ticks per wave-instruction per SIMD\n");
 }
 
 int main(int argc, char **argv)
