@@ -139,8 +139,10 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	// The colour's w lane is not carried: every surface colour has w = 0 (defs.h:16-18, spheres'
 	// col.w is never set), so col.w = diffuse * (icol.w * 0) is 0 -- unless the shading factor is
 	// not finite (a ray that went through 1/0 in a ramp, trace.h:461), when it is NaN and so is
-	// everything composited from it.  One flag stands for that lane.
-	bool w_nan = false;
+	// everything composited from it.  One accumulator stands for that lane: w_acc += factor * 0 stays
+	// +0 until a factor is NaN or inf and is NaN from then on (a register rather than a flag: a
+	// lane-divergent bool carried across the walk loop costs three mask updates per iteration).
+	float w_acc = 0.0f;
 
 #pragma unroll 1
 	for(;;)
@@ -512,7 +514,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			if(depth > 0) { icx = STK(depth - 1, 2); icy = STK(depth - 1, 3); icz = STK(depth - 1, 4); }
 #endif
 			colx = diffuse * (icx * bx); coly = diffuse * (icy * by); colz = diffuse * (icz * bz);
-			w_nan |= !__builtin_isfinite(diffuse);
+			w_acc = __builtin_fmaf(diffuse, 0.0f, w_acc);
 			refl = (ldir == FYN ? 0.7f : 0.25f);
 		}
 		else
@@ -525,7 +527,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			if constexpr(HAS_W) d.w = aux_pos.w - 1.0f; else d.w = 0.0f;
 			aux_norm = vnormalise<HAS_W>(L.rsq, d);
 			colx = aux_diff * s1.y; coly = aux_diff * s1.z; colz = aux_diff * s1.w;
-			w_nan |= !__builtin_isfinite(aux_diff);
+			w_acc = __builtin_fmaf(aux_diff, 0.0f, w_acc);
 			refl = s0.y;
 			ldir = -1;
 			pos = aux_pos;
@@ -608,7 +610,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 		}
 	}
-	out_x = vx; out_y = vy; out_z = vz; out_w = w_nan ? __builtin_nanf("") : vw;
+	out_x = vx; out_y = vy; out_z = vz; out_w = vw + w_acc;
 }
 
 template<bool COUNT, bool HAS_W>
