@@ -51,6 +51,11 @@ typedef struct pwn_stats
 	float trace_ms;         /* trace kernel, HIP events                        */
 	float blur_ms;          /* blur kernel(s), HIP events                      */
 	float total_ms;         /* whole pwn_trace_screen_centred call incl. D2H   */
+	float reserved_;
+	/* divergence profile of the walk loop: how many wave64 iterations entered each code
+	   path with at least one lane.  0 sphere list of the cell, 1 room body, 2 fog,
+	   3 two-level transition (" / # / &), 4 ramp, 5 portal, 6 solid, 7 sphere hit maths */
+	uint64_t wave_paths[8];
 } pwn_stats;
 
 /* options for pwn_set_option */

@@ -27,7 +27,8 @@ class Sphere(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("portals", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("exhausted", C.c_uint64), ("wave_steps", C.c_uint64),
-                ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("total_ms", C.c_float)]
+                ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("total_ms", C.c_float), ("reserved_", C.c_float),
+                ("wave_paths", C.c_uint64 * 8)]
 
 
 # every symbol include/pwnhip.h declares: (name, restype, argtypes)

@@ -141,7 +141,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		if(hipMalloc((void **)&c->d_pre, n * 4) != hipSuccess ||
 		   hipMalloc((void **)&c->d_out, n * 4) != hipSuccess ||
 		   hipMalloc((void **)&c->d_z, n * 4) != hipSuccess ||
-		   hipMalloc((void **)&c->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+		   hipMalloc((void **)&c->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
 		   hipMalloc((void **)&c->d_skip, sizeof(uint2) * (size_t)(width / 4 + 1)) != hipSuccess) { rc = PWN_ENOMEM; break; }
 		if(hipMemset(c->d_z, 0, n * 4) != hipSuccess || hipMemset(c->d_pre, 0, n * 4) != hipSuccess ||
 		   hipMemset(c->d_out, 0, n * 4) != hipSuccess) { rc = PWN_EHIP; break; }
@@ -504,7 +504,7 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	P.has_w = !(cam[3] == 0.0f && cam[7] == 0.0f && cam[11] == 0.0f && cam[15] == 1.0f);
 	// test hook (tests/test_gpu_fuzz.py): send every camera through the general variant
 	if(getenv("PWN_DBG_FORCE_HASW")) P.has_w = 1;
-	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), stream));
 	// persistent grid: as many workgroups as are resident at once, each striding over tiles
 	const size_t lds_bytes = ((P.blob_bytes + 15u) & ~15u) + pwn_trace_lds_extra();
 	// resident workgroups per CU depend on (LDS bytes, kernel variant) only: ask once per combination
@@ -622,10 +622,11 @@ extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 	(void)hipSetDevice(c->device);
 	if(c->counters_on)
 	{
-		unsigned long long v[8];
+		unsigned long long v[16];
 		HIPCHK(c, hipMemcpy(v, c->d_counters, sizeof(v), hipMemcpyDeviceToHost));
 		c->stats.rays = v[0]; c->stats.steps = v[1]; c->stats.portals = v[2];
 		c->stats.sphere_tests = v[3]; c->stats.exhausted = v[4]; c->stats.wave_steps = v[5];
+		for(int i = 0; i < 8; i++) c->stats.wave_paths[i] = v[6 + i];
 	}
 	*out = c->stats;
 	return PWN_OK;

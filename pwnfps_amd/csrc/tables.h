@@ -90,6 +90,6 @@ struct pwn_trace_params
 	uint32_t *sbuf;                           // full frame, pitch w
 	float *zbuf;                              // full frame, pitch w
 	const uint32_t *blob;
-	unsigned long long *counters;             // 5 x u64 or NULL
+	unsigned long long *counters;             // 14 x u64 (pwn_stats counters + wave_paths) or NULL
 	int has_w;                                // camera has w components (general 4-lane path)
 };

@@ -109,7 +109,9 @@ enum { EV_NONE = 0, EV_WALL, EV_SPHERE, EV_EXHAUSTED };
 // the face and the colour follow from the ray's y sign after the walk
 enum { BASE_CEIL = 0, BASE_FLOOR, BASE_WALL, BASE_MAGENTA, BASE_ROOM_Y };
 
-struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps; };
+struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps, wp[8]; };
+// one count per wave64 that enters a code path with at least one lane (pwn_stats.wave_paths)
+#define WAVE_PATH(k) do { if(COUNT && (__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt.wp[k]++; } while(0)
 
 // One pixel = trace_ray(0, ...) of screen.h:22-24 with the recursion unrolled.
 template<bool COUNT, bool HAS_W>
@@ -198,7 +200,8 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		// (trace.h:345-349,381-385); iay_dn is the amount added when stepping DOWN into it
 		const float iay_dn = gyp ? iay : -iay;
 		const int ldy = gyp ? FYP : FYN;
-		const uint32_t iay_up_bits = gyp ? __float_as_uint(iay) : 0u;   // +iay when looking up, else +0
+		uint32_t iay_up_bits = gyp ? __float_as_uint(iay) : 0u;         // +iay when looking up, else +0
+		asm volatile("" : "+v"(iay_up_bits));        // keep it a register, not a select on gyp per step
 		int ldx = (gx < 0 ? FXN : FXP), ldz = (gz < 0 ? FZN : FZP);
 
 		uint32_t cw = cellword_at(L, cx, cz);
@@ -226,6 +229,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			// trace.h:252-296: spheres binned to this cell
 			if((int)cw < 0)
 			{
+				WAVE_PATH(0);
 				const uint16_t *lp = L.binidx + ((cw >> 16) & 0x7fffu);
 				for(uint32_t si = *lp; si != PWN_LIST_END; si = *++lp)
 				{
@@ -244,6 +248,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 						float calc = d2 - dt * dt;
 						if(calc < rad2)
 						{
+							WAVE_PATH(7);
 							float sd2 = 1.0f - calc / rad2;
 							float sdist = sqrtf(d2) - sqrtf(sd2);
 							if(sdist + cdist < aux_dist)
@@ -268,11 +273,17 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 
 			if(cw & PWN_C_ROOM)
 			{
+				WAVE_PATH(1);
 				// trace.h:302-352 (1-high) and 354-441 (2-high) share this body
 				const bool room2 = (cw & PWN_C_ROOM2) != 0u;
 				// 2-high: the ceiling is one unit further when looking up (trace.h:357,392)
 				// = (room2 && gyp) ? iay : 0: the ROOM2 bit stretched to a mask (one v_bfe_i32)
-				const float up2 = __uint_as_float(iay_up_bits & (uint32_t)(((int32_t)(cw << 22)) >> 31));
+				// (a sign-extended 1-bit field; written as an instruction because the compiler turns the
+				// shift form back into two compares and a select on gyp)
+				uint32_t m2;
+				asm("v_bfe_i32 %0, %1, 9, 1" : "=v"(m2) : "v"(cw));
+				static_assert(PWN_C_ROOM2 == (1u << 9), "v_bfe_i32 above reads bit 9");
+				const float up2 = __uint_as_float(iay_up_bits & m2);
 				wy += up2;
 				const float cdist0 = cdist;
 				// trace.h:156-184, then 331-340 on the same comparisons
@@ -285,6 +296,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 				const bool hit = AUX_HIT();
 				if(cw & PWN_C_FOG)
 				{
+					WAVE_PATH(2);
 					// fogbeg = distance at entry (trace.h:309,359); sums in the
 					// reference build's operation order
 					const float fh = (fog + aux_dist) - cdist0;
@@ -301,6 +313,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 				const uint32_t ncw = cellword_at(L, cx, cz);
 				if((cw & (PWN_C_DQ | PWN_C_ROOM2)) != 0u && ev == 0)
 				{
+					WAVE_PATH(3);
 					if(!room2)
 					{
 						if(ncw & PWN_C_ROOM2)        // here cw is the "-cell
@@ -346,6 +359,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			{
 				if(cw & PWN_C_RAMP)
 				{
+					WAVE_PATH(4);
 					// trace.h:443-505: ramps
 					const float ramp = 0.5f;
 					const bool alongx = (cw & PWN_C_RAMPX) != 0u;
@@ -393,6 +407,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 				}
 				else if(cw & PWN_C_PORTAL)
 				{
+					WAVE_PATH(5);
 					// trace.h:508-650: portal
 					const int pi = (int)(cw & 0xffu) - 'A';
 					uint32_t p0 = L.pmap[2 * pi], p1 = L.pmap[2 * pi + 1];
@@ -470,6 +485,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 				else
 				{
 					// trace.h:651-664: solid
+					WAVE_PATH(6);
 					if(AUX_HIT()) ev = EV_SPHERE;
 					else { ev = EV_WALL; base = (ldir == FYP ? BASE_CEIL : BASE_WALL); }
 				}
@@ -480,6 +496,10 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
 		} while(ev == 0);
 #undef AUX_HIT
+		// what the ray ended on is read back from the register: without this the compiler keeps
+		// "ev == EV_EXHAUSTED" as a lane mask that it updates in every iteration of the walk
+		// (5 of ~85 instructions per step)
+		asm volatile("" : "+v"(ev));
 
 		if(ev == EV_EXHAUSTED)
 		{
@@ -653,7 +673,7 @@ pwn_trace_kernel(pwn_trace_params P)
 	const int lx = sub * 32 + half * 16 + l16;
 	const int ly = ((wave >> 1) & 1) * 4 + (lane >> 4);
 
-	Counters cnt = { 0, 0, 0, 0, 0, 0 };
+	Counters cnt = {};
 
 	// Persistent workgroups, static split: workgroup b takes tiles b, b + gridDim.x, ...
 	// Measured alternatives that lost: a ticket counter (one atomic per wave and 128
@@ -714,8 +734,9 @@ pwn_trace_kernel(pwn_trace_params P)
 	if(COUNT)
 	{
 		// wave reduce, one atomic per wave and counter
-		unsigned long long v[6] = { cnt.rays, cnt.steps, cnt.portals, cnt.tests, cnt.exhausted, cnt.wsteps };
-		for(int i = 0; i < 6; i++)
+		unsigned long long v[14] = { cnt.rays, cnt.steps, cnt.portals, cnt.tests, cnt.exhausted, cnt.wsteps,
+			cnt.wp[0], cnt.wp[1], cnt.wp[2], cnt.wp[3], cnt.wp[4], cnt.wp[5], cnt.wp[6], cnt.wp[7] };
+		for(int i = 0; i < 14; i++)
 		{
 			unsigned long long s = v[i];
 			for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);

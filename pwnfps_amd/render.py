@@ -181,7 +181,9 @@ class Renderer:
     def stats(self):
         st = _lib.Stats()
         self._chk(lib.pwn_get_stats(self._ctx, C.byref(st)), "pwn_get_stats")
-        return {n: getattr(st, n) for n, _ in _lib.Stats._fields_}
+        out = {n: getattr(st, n) for n, _ in _lib.Stats._fields_ if n != "reserved_"}
+        out["wave_paths"] = list(st.wave_paths)
+        return out
 
     def probe(self, op, words):
         words = np.ascontiguousarray(words).view(np.uint32).ravel()

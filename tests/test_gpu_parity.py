@@ -452,3 +452,31 @@ def test_two_contexts_interleaved(oracle_lib, cases):
         assert _fnv(oracle_lib, fa) == a["post"]
         assert _fnv(oracle_lib, fb) == b["post"]
     ra.close(); rb.close()
+
+
+def test_wave_level_counters_are_consistent(cases):
+    """pwn_stats.wave_steps / wave_paths (the divergence profile of the walk loop): bounded by
+    the lane-level counters they summarise, and the same from run to run."""
+    c = next(x for x in cases if x["name"] == "level_spawn_1280x720")
+    r = _renderer(c["w"], c["h"])
+    r.level_load(level_path(c["level"]))
+    r.set_objects(load_spheres(c["spheres"]))
+    r.set_blur_passes(0)
+    r.set_counters(True)
+    cam = np.array(c["cam"], np.float32)
+    r.trace_screen_centred(cam, c["sec"], want_z=False)
+    st = r.stats()
+    assert (st["rays"], st["steps"], st["portals"]) == (c["rays"], c["steps"], c["portals"])
+    ws, wp = st["wave_steps"], st["wave_paths"]
+    assert st["steps"] / 64.0 <= ws <= st["steps"]             # 1..64 lanes per wave iteration
+    assert all(0 <= v <= ws for v in wp[:7])
+    assert wp[1] > 0.5 * ws                                     # most iterations walk a room cell
+    assert wp[5] <= st["portals"] and wp[5] * 64 >= st["portals"]
+    assert wp[0] * 64 >= 1 and wp[7] <= st["sphere_tests"]
+    assert wp[4] > 0 and wp[2] > 0 and wp[3] > 0 and wp[6] > 0  # level.txt has ramps, fog, two-level rooms, walls
+    r.trace_screen_centred(cam, c["sec"], want_z=False)
+    st2 = r.stats()
+    assert st2["wave_steps"] == ws and st2["wave_paths"] == wp
+    r.set_counters(False)
+    r.trace_screen_centred(cam, c["sec"], want_z=False)
+    r.close()
