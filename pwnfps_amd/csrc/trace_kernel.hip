@@ -311,7 +311,13 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 				cx += xlt ? gx : 0;
 				cz += xlt ? 0 : gz;
 				const uint32_t ncw = cellword_at(L, cx, cz);
-				if((cw & (PWN_C_DQ | PWN_C_ROOM2)) != 0u && ev == 0)
+				// trace.h:341-351,393-441 do something only when the height changes: from a "-cell
+				// into a 2-high one, or out of a 2-high cell into anything else ('#'/'&' are the only
+				// 2-high cells, so 2-high -> 2-high neither shifts y nor can be a wall).  One bit:
+				// next is 2-high ? current is " : current is 2-high  (DQ sits two bits above ROOM2)
+				static_assert(PWN_C_DQ == (PWN_C_ROOM2 << 2), "the shift below lines DQ up with ROOM2");
+				const uint32_t height_changes = (((cw >> 2) & ncw) | (cw & ~ncw)) & PWN_C_ROOM2;
+				if(height_changes != 0u && ev == 0)
 				{
 					WAVE_PATH(3);
 					if(!room2)
