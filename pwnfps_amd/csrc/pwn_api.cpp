@@ -66,6 +66,7 @@ struct pwn_ctx
 	float *d_z;
 	uint2 *d_skip;                   // blur LCG skip-ahead, w/4 entries
 	unsigned long long *d_counters;
+	uint32_t *d_tickets; unsigned ticket_set;  // two sets of work-queue counters of the trace kernel, used alternately
 	uint32_t *d_scratch; size_t scratch_cap;   // upscale / probe staging
 
 	hipStream_t stream;
@@ -115,7 +116,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->device = device; c->w = width; c->h = height;
 	c->blur_passes = 1; c->counters_on = 0; c->have_level = false;
 	c->d_blob = NULL; c->d_blob_cap = 0; c->blob_dirty = true; c->off_sph = 0;
-	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL;
+	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0;
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 4; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
 	c->ev_tables = NULL; c->tables_in_use = false;
@@ -142,6 +143,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		   hipMalloc((void **)&c->d_out, n * 4) != hipSuccess ||
 		   hipMalloc((void **)&c->d_z, n * 4) != hipSuccess ||
 		   hipMalloc((void **)&c->d_counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+		   hipMalloc((void **)&c->d_tickets, 2 * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
+		   hipMemset(c->d_tickets, 0, 2 * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
 		   hipMalloc((void **)&c->d_skip, sizeof(uint2) * (size_t)(width / 4 + 1)) != hipSuccess) { rc = PWN_ENOMEM; break; }
 		if(hipMemset(c->d_z, 0, n * 4) != hipSuccess || hipMemset(c->d_pre, 0, n * 4) != hipSuccess ||
 		   hipMemset(c->d_out, 0, n * 4) != hipSuccess) { rc = PWN_EHIP; break; }
@@ -176,7 +179,7 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 	if(c->ev_tables) (void)hipEventDestroy(c->ev_tables);
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	(void)hipFree(c->d_blob); (void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z);
-	(void)hipFree(c->d_skip); (void)hipFree(c->d_counters); (void)hipFree(c->d_scratch);
+	(void)hipFree(c->d_skip); (void)hipFree(c->d_counters); (void)hipFree(c->d_tickets); (void)hipFree(c->d_scratch);
 	delete c;
 }
 
@@ -498,6 +501,11 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	P.sbuf = d_sbuf; P.zbuf = d_zbuf;
 	P.blob = (const uint32_t *)c->d_blob;
 	P.counters = c->d_counters;
+	// the kernel's work queues: this launch counts in one set and clears the other for the next
+	// launch of this context (stream-ordered behind it, include/pwnhip.h)
+	P.tickets = c->d_tickets + (c->ticket_set & 1u) * PWN_QUEUES * PWN_QUEUE_STRIDE;
+	P.tickets_next = c->d_tickets + ((c->ticket_set + 1u) & 1u) * PWN_QUEUES * PWN_QUEUE_STRIDE;
+	c->ticket_set++;
 	// ordinary cameras (rows x,y,z with w = 0, position w = 1: mat4_iden + rotations,
 	// main.c:61-64) never put anything but 0 / 1 into the w lanes; the kernel has a
 	// 3-lane specialisation for them that is arithmetically identical
@@ -527,18 +535,6 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	if(const char *cap = getenv("PWN_DBG_BLOCKS_PER_CU")) { if(atoi(cap) > 0) per_cu = atoi(cap); }   // experiments
 	int grid = c->num_cus * per_cu;
 	if(grid > P.tiles_total) grid = P.tiles_total;
-	// Workgroup b takes tiles b, b + grid, ...: column (b + k*grid) % tiles_x.  If grid and
-	// tiles_x share a factor a workgroup only ever sees a few tile columns, and a frame whose
-	// expensive rays form a vertical band (a mirror hall) loads a few workgroups with all of
-	// it (8K: 1280 workgroups over 240 columns = 3 columns each: +40 % frame time).  Make the
-	// two coprime; this costs at most a handful of workgroups.
-	while(grid > 1)
-	{
-		int a = grid, b = P.tiles_x;
-		while(b) { int t = a % b; a = b; b = t; }
-		if(a == 1) break;
-		grid--;
-	}
 	HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	HIPCHK(c, hipEventRecord(c->ev_tables, stream));
 	c->tables_in_use = true;

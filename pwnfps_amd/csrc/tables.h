@@ -92,4 +92,12 @@ struct pwn_trace_params
 	const uint32_t *blob;
 	unsigned long long *counters;             // 14 x u64 (pwn_stats counters + wave_paths) or NULL
 	int has_w;                                // camera has w components (general 4-lane path)
+	// work queues of the wave scheduler (trace_kernel.hip): PWN_QUEUES counters, one per 128 B,
+	// for this launch; the set of the next launch, which this one clears
+	uint32_t *tickets, *tickets_next;
 };
+
+#ifndef PWN_QUEUES
+#define PWN_QUEUES 64u                       /* a power of two <= 64: one lane of a wave looks at each */
+#endif
+#define PWN_QUEUE_STRIDE 32u                  /* uint32 words between two counters (128 B) */

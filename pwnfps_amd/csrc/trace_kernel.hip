@@ -670,27 +670,89 @@ pwn_trace_kernel(pwn_trace_params P)
 	from.x = P.from[0]; from.y = P.from[1]; from.z = P.from[2]; from.w = HAS_W ? P.from[3] : 1.0f;
 
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	// a wave64 covers 16 x 4 pixels: lane & 15 = column inside one half of the
-	// 32-wide tile (= one DPP row), lane >> 4 = row; waves 2k / 2k+1 are the
-	// left / right half of rows 4k .. 4k+3
-	const int half = wave & 1;
 	const int l16 = lane & 15;
-	const int sub = wave >> 2;                           // which 32 x 8 sub-tile of the workgroup's tile
-	const int lx = sub * 32 + half * 16 + l16;
-	const int ly = ((wave >> 1) & 1) * 4 + (lane >> 4);
 
 	Counters cnt = {};
 
-	// Persistent workgroups, static split: workgroup b takes tiles b, b + gridDim.x, ...
-	// Measured alternatives that lost: a ticket counter (one atomic per wave and 128
-	// pixels serialises at ~4 ns per atomic: +50 % at 4K) and a pseudo-random
-	// tile permutation (-2 %; it does not shorten the tail of mirror-hall frames,
-	// which is one wave walking 1000 cells, a dependent chain).
-	for(int tile = blockIdx.x; tile < P.tiles_total; tile += gridDim.x)
+	// Work distribution.  A unit is one wave64's 16 x 4 pixels (lane & 15 = column inside one
+	// half of the 32-wide tile of screen.h:6-7 = one DPP row, lane >> 4 = row).  Rays differ in
+	// cost by an order of magnitude from one part of a frame to another, and with a static split
+	// (unit k to wave k mod #waves) the slowest wave ran 1.5x (level.txt) to 2.7x (synth256) as long as
+	// the average one: the chip idled a third of the kernel's time.  So waves pull units:
+	// PWN_QUEUES counters 128 B apart (same-address atomics serialise at ~4 ns; one counter for a
+	// 4K frame's 130 k units would be the bottleneck, as an earlier attempt showed; 8 / 16 / 32 / 64
+	// queues measured 0.402 / 0.394 / 0.388 / 0.383 ms at 4K), queue q holds
+	// the units u = q (mod PWN_QUEUES); a wave drains its home queue, then helps with the others,
+	// and asks for its next unit before it starts on the current one (the ~2 us round trip of
+	// the atomic hides behind ~15 us of tracing).  The counters of the NEXT launch of this context
+	// are cleared here (launches of a context are stream-ordered, include/pwnhip.h).
+	const uint32_t units_x = ((uint32_t)P.w + 15u) >> 4;
+	const uint32_t units = units_x * (((uint32_t)(P.y1 - P.y0) + 3u) >> 2);
+	if(blockIdx.x == 0 && threadIdx.x < PWN_QUEUES) P.tickets_next[threadIdx.x * PWN_QUEUE_STRIDE] = 0u;
+	uint32_t q = (blockIdx.x * (PWN_BLOCK / 64) + (uint32_t)wave) % PWN_QUEUES;
+	uint32_t ticket;
 	{
-		int tx = tile % P.tiles_x, ty = tile / P.tiles_x;
-		int cx0 = tx * TILE_W + sub * 32;                 // the 32-pixel tile of screen.h:6-7 this wave is in
-		int x = tx * TILE_W + lx, y = P.y0 + ty * TILE_H + ly;
+		uint32_t t = 0;
+		if(lane == 0) t = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], 1u);
+		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+	}
+	// A wave that keeps finding queues empty although they looked open stops helping after a
+	// few rounds: every queue is drained by its home waves anyway (a wave leaves its home queue
+	// only when that is empty), so this costs parallelism at the very end at worst and makes
+	// sure every wave's loop ends whatever the loads return.
+	int misses = 0;
+	for(;;)
+	{
+		// units of queue q: q, q + Q, ...  below `units`
+		const uint32_t qlen = (units + PWN_QUEUES - 1u - q) / PWN_QUEUES;
+		if(ticket >= qlen)
+		{
+			if(++misses > 2 * (int)PWN_QUEUES) break;
+			// this queue is empty: find one that is not (plain loads; a stale value can only
+			// look fuller than the queue is, and then the atomic below says so)
+			uint32_t seen = 0xffffffffu;
+			if((uint32_t)lane < PWN_QUEUES)
+				seen = __hip_atomic_load(&P.tickets[(uint32_t)lane * PWN_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t len_l = (units + PWN_QUEUES - 1u - ((uint32_t)lane & (PWN_QUEUES - 1u))) / PWN_QUEUES;
+			const unsigned long long open = __ballot((uint32_t)lane < PWN_QUEUES && seen < len_l);
+			if(open == 0ull) break;
+			// the next open queue after q, cyclically: bit i of the shifted double mask is queue q+1+i
+			static_assert(PWN_QUEUES <= 64u && (PWN_QUEUES & (PWN_QUEUES - 1u)) == 0u, "a power of two, one lane per queue");
+			if constexpr(PWN_QUEUES == 64u)
+			{
+				const uint32_t rot = q + 1u;                 // 1..64
+				const unsigned long long r = rot == 64u ? open : ((open >> rot) | (open << (64u - rot)));
+				q = (q + 1u + (uint32_t)__builtin_ctzll(r)) & 63u;
+			}
+			else
+				q = (q + 1u + (uint32_t)__builtin_ctzll((open | (open << (PWN_QUEUES & 31u))) >> (q + 1u))) & (PWN_QUEUES - 1u);
+			uint32_t t = 0;
+			if(lane == 0) t = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], 1u);
+			ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+			continue;
+		}
+		misses = 0;
+		const uint32_t unit = ticket * PWN_QUEUES + q;
+		uint32_t next_raw = 0;
+		if(lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], 1u);
+		// rows from the middle of the strip outwards: the horizon band, where rays run longest,
+		// is started first and the cheap top and bottom edges make up the tail
+		const uint32_t ux = unit % units_x, k = unit / units_x;
+		const uint32_t rows_u = ((uint32_t)(P.y1 - P.y0) + 3u) >> 2;
+		const uint32_t mid = rows_u >> 1;
+		// k = 0,1,2,3,... -> mid, mid-1, mid+1, mid-2, ...; rows that fall off one end continue on the other
+		uint32_t uy;
+		{
+			const uint32_t d = (k + 1u) >> 1;
+			const bool down = (k & 1u) != 0u;            // odd: above the middle
+			int cand = down ? (int)mid - (int)d : (int)mid + (int)d;
+			if(cand < 0) cand = (int)mid + (int)(k - mid);           // ran past the top: the remaining rows are at the bottom
+			else if(cand >= (int)rows_u) cand = (int)mid - (int)(k - (rows_u - 1u - mid)) ;   // ran past the bottom
+			uy = (uint32_t)cand;
+		}
+		const int half = (int)(ux & 1u);                  // left / right half of the 32-wide tile
+		const int cx0 = (int)(ux >> 1) * 32;              // the 32-pixel tile of screen.h:6-7 this wave is in
+		const int x = (int)ux * 16 + l16, y = P.y0 + (int)uy * 4 + (lane >> 4);
 
 		// screen.h:12-18, in the order the reference build evaluates it:
 		// rayl = (cx*rdx + rayb) + y*rdy, then one "+= rdx" per pixel of the
@@ -735,6 +797,7 @@ pwn_trace_kernel(pwn_trace_params P)
 				(float *)(lds_raw + ((P.blob_bytes + 15u) & ~15u)) + threadIdx.x);
 			P.sbuf[o] = ftoint_lane(ox) | (ftoint_lane(oy) << 8) | (ftoint_lane(oz) << 16) | (ftoint_lane(ow) << 24);
 		}
+		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
 	}
 
 	if(COUNT)
