@@ -55,11 +55,11 @@ def pmc_traffic(kernel, w, h):
 def pmc_issue_rate(kernel, w, h, launch_ms):
     """What actually bounds the trace kernel: wave-instructions issued per
     SIMD and nanosecond -- instruction counts from the committed PMC summary (they do not
-    depend on the run), time from this run's HIP events -- next to the rates one SIMD was
-    measured to sustain on this chip under the same wall clock (tools/ubench/valu_rate.hip
-    with VALU_RATE_CALIBRATE=1, 5-8 waves per SIMD): plain VOP2 ALU ops 0.9-1.0, v_cmp and
-    VOP3 v_cndmask 0.55, v_rcp/v_sqrt 0.29, SALU 0.56, an alternating VALU/SALU stream 0.96-1.0
-    in total.  (Clocks sag under VALU load, so rates per cycle are not comparable between runs.)"""
+    depend on the run), time from this run's HIP events.  Reference points: a CDNA4 SIMD is
+    32 lanes wide, so a wave64 VALU instruction takes 2 cycles = 1.2 per ns at 2.4 GHz
+    (MI355X_MICROARCH.md); streams of independent plain VALU instructions were measured at
+    0.9-1.0 per ns (tools/ubench/valu_rate.hip, VALU_RATE_CALIBRATE=1: the clock sags under
+    pure VALU load), v_cmp / VOP3 v_cndmask at 0.55, SALU alone at 0.56."""
     path = os.path.join(ROOT, "profiles", "pmc_latest.csv")
     try:
         meta = [l for l in open(path) if l.startswith("#")]
@@ -70,12 +70,17 @@ def pmc_issue_rate(kernel, w, h, launch_ms):
         scalar = v["SQ_INSTS_SALU"] + v["SQ_INSTS_BRANCH"]
         insts = v["SQ_INSTS_VALU"] + scalar + v["SQ_INSTS_LDS"]
         per = 1.0 / (1024.0 * launch_ms * 1e6)          # per SIMD and ns
-        return {"wave_instructions_per_launch": int(insts), "simds": 1024,
-                "valu_per_ns_per_simd": round(v["SQ_INSTS_VALU"] * per, 3), "valu_peak_per_ns_per_simd": 1.0,
-                "scalar_per_ns_per_simd": round(scalar * per, 3), "scalar_peak_per_ns_per_simd": 0.56,
-                "all_per_ns_per_simd": round(insts * per, 3), "mixed_stream_peak_per_ns_per_simd": 1.0,
-                "active_lanes_per_valu_instruction": round(v["SQ_THREAD_CYCLES_VALU"] / v["SQ_ACTIVE_INST_VALU"], 1)
-                if "SQ_ACTIVE_INST_VALU" in v else None}
+        out = {"wave_instructions_per_launch": int(insts), "simds": 1024,
+               "valu_per_ns_per_simd": round(v["SQ_INSTS_VALU"] * per, 3),
+               "valu_architectural_peak_per_ns_per_simd": 1.2, "valu_microbenchmark_per_ns_per_simd": 1.0,
+               "scalar_per_ns_per_simd": round(scalar * per, 3),
+               "all_per_ns_per_simd": round(insts * per, 3),
+               "active_lanes_per_valu_instruction": round(v["SQ_THREAD_CYCLES_VALU"] / v["SQ_ACTIVE_INST_VALU"], 1)
+               if "SQ_ACTIVE_INST_VALU" in v else None}
+        if "SQ_WAVE_CYCLES" in v and "SQ_WAVES" in v and "GRBM_GUI_ACTIVE" in v:
+            # share of the kernel's duration the average wave is resident (quad-cycles; GRBM sums 8 XCDs)
+            out["mean_wave_residency"] = round(4.0 * v["SQ_WAVE_CYCLES"] / (v["SQ_WAVES"] * v["GRBM_GUI_ACTIVE"] / 8.0), 3)
+        return out
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
