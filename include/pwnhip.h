@@ -9,8 +9,11 @@
  *
  * Like the reference's render path (globals, one main thread: main.c:26-34) a
  * context is not re-entrant: one thread at a time per context, and the strip
- * forms of one context must be ordered with respect to each other by their
- * streams.  Different contexts (one per GPU, one process per GPU) are independent.
+ * forms of one context must be ordered with respect to each other (and to the
+ * blocking frame call) by their streams: two trace launches of one context
+ * never run at the same time -- they share the level tables and the work-queue
+ * counters of the kernel.  Different contexts (one per GPU, one process per
+ * GPU) are independent.
  */
 #ifndef PWNHIP_H
 #define PWNHIP_H

@@ -505,7 +505,6 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	// launch of this context (stream-ordered behind it, include/pwnhip.h)
 	P.tickets = c->d_tickets + (c->ticket_set & 1u) * PWN_QUEUES * PWN_QUEUE_STRIDE;
 	P.tickets_next = c->d_tickets + ((c->ticket_set + 1u) & 1u) * PWN_QUEUES * PWN_QUEUE_STRIDE;
-	c->ticket_set++;
 	// ordinary cameras (rows x,y,z with w = 0, position w = 1: mat4_iden + rotations,
 	// main.c:61-64) never put anything but 0 / 1 into the w lanes; the kernel has a
 	// 3-lane specialisation for them that is arithmetically identical
@@ -536,6 +535,7 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	int grid = c->num_cus * per_cu;
 	if(grid > P.tiles_total) grid = P.tiles_total;
 	HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
+	c->ticket_set++;                     // only a launch that went out has cleared the other set
 	HIPCHK(c, hipEventRecord(c->ev_tables, stream));
 	c->tables_in_use = true;
 	return PWN_OK;
