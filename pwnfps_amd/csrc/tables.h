@@ -85,7 +85,7 @@ struct pwn_trace_params
 	float rayb[4], rdx[4], rdy[4], from[4];   // screen.h:43-57
 	float sec_current;                        // defs.h:23
 	int w, h, y0, y1;
-	int tiles_x, tiles_total;                 // 32 x TILE_H pixel tiles: per row, in all
+	int tiles_x, tiles_total;                 // 16 x 4 pixel units (one wave64 each): per row, in all
 	uint32_t blob_bytes, off_sph;
 	uint32_t *sbuf;                           // full frame, pitch w
 	float *zbuf;                              // full frame, pitch w

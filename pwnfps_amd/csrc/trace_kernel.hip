@@ -6,15 +6,17 @@
 // Shape: persistent 256-thread workgroups (4 wave64), exactly as many as are
 // resident at once.  Each workgroup copies the level blob (rcp/rsqrt tables,
 // per-cell word, portals, per-cell sphere lists, spheres: tables.h) HBM -> LDS
-// once, then walks 32x8-pixel tiles of its row strip, one thread per pixel.
+// once; then every wave pulls 16x4-pixel units of the row strip from work
+// queues until none are left (rays differ in cost by an order of magnitude
+// across a frame; see the kernel body), one thread per pixel.
 // The reference's recursion (depth <= REFLECT) is a loop over at most three ray
 // segments; the composites of trace.h:91-101 are applied on unwinding.
 // Output: BGRA8 colour + fp32 depth, row-major, 4-byte stores.
 //
 // No MFMA: this is a branchy DDA, not a contraction.  HBM traffic is the two
 // output planes only (8 B / pixel); everything the inner loop reads is in LDS.
-// The kernel is instruction-issue bound, so the code is
-// organised for few instructions per cell step and few scalar mask sequences:
+// Its time follows the number of wave-instructions issued, so the code
+// is organised for few instructions per cell step and few scalar mask sequences:
 //   - one walk loop with one exit; the cell class is a bit test on ONE LDS
 //     word per step (class flags + sphere-list offset, 65x65 clamp-free grid),
 //   - the room body (1-high and 2-high share it) is written with selects,
@@ -32,12 +34,13 @@
 #define REFLECT_MAX 2             // defs.h:7
 enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
 
-// workgroup = PWN_BLOCK threads = one 32 x (PWN_BLOCK/32) pixel tile
+// workgroup = PWN_BLOCK threads sharing one copy of the blob in LDS; a wave's unit of work is
+// 16 x 4 pixels (half the width of the 32-pixel tile of screen.h:6-7, one DPP row per pixel row)
 #ifndef PWN_BLOCK
 #define PWN_BLOCK 256
 #endif
-#define TILE_W (PWN_BLOCK / 8)    // a workgroup covers TILE_W x 8 pixels = PWN_BLOCK/256 sub-tiles of 32 x 8
-#define TILE_H 8
+#define TILE_W 16
+#define TILE_H 4
 
 // min waves per SIMD the register allocator must leave room for (Makefile MINW)
 #ifndef PWN_MIN_WAVES
