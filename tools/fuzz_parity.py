@@ -33,6 +33,11 @@ if "--keep-nonfinite" in sys.argv:
     i = sys.argv.index("--keep-nonfinite")
     KEEP = sys.argv[i + 1]
     del sys.argv[i:i + 2]
+FORCE_SIZE = None                 # --size WxH: every scene at this frame size (e.g. 1600x900: many units per wave)
+if "--size" in sys.argv:
+    i = sys.argv.index("--size")
+    FORCE_SIZE = tuple(int(v) for v in sys.argv[i + 1].lower().split("x"))
+    del sys.argv[i:i + 2]
 LATTICE = "--lattice" in sys.argv
 if LATTICE:
     sys.argv.remove("--lattice")
@@ -127,6 +132,8 @@ for it in range(n):
     w, h = sizes[it % len(sizes)]
     if it % 16 == 9:
         w, h = big_sizes[(it // 16) % len(big_sizes)]
+    if FORCE_SIZE:
+        w, h = FORCE_SIZE
     blur = int(rng.integers(0, 2)) if w % 4 == 0 else 0
     O.set_spheres(sph)
     if REF_MODE:
