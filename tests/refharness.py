@@ -4,6 +4,7 @@ tools/gen_goldens.py, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -134,24 +135,11 @@ def identity_cam(x, y, z):
 def game_lua_spheres():
     """The 14 spheres game.lua:2-30 creates at load (t=0): obj_set(r, refl,
     obx+dx, oby+dy, obz+dz, c1, c2, c3) with (obx,oby,obz)=(9.5,0.3,5.5);
-    sums are Lua doubles, narrowed to float by script.h:22-32.
-    Rows: dx, dy, dz, r, c1, c2, c3, refl (the numeric table of game.lua:3-22)."""
-    opos = [
-        (0.0, 0.0, 0.0, 0.3, 0.8, 0.8, 0.8, 0.6),
-        (0.0, 0.3, 0.0, 0.1, 0.4, 0.4, 0.4, 0.2),
-        (0.3, 0.0, 0.0, 0.1, 0.7, 0.7, 1.0, 0.4),
-        (0.0, 0.0, 0.3, 0.1, 0.7, 1.0, 0.7, 0.4),
-        (-0.3, 0.0, 0.0, 0.1, 1.0, 0.7, 0.7, 0.4),
-        (0.0, 0.0, -0.3, 0.1, 0.5, 1.0, 1.0, 0.4),
-        (0.3, 0.0, 0.1, 0.03, 0.4, 0.4, 0.4, 0.2),
-        (0.1, 0.0, 0.3, 0.03, 0.4, 0.4, 0.4, 0.2),
-        (-0.3, 0.0, 0.1, 0.03, 0.4, 0.4, 0.4, 0.2),
-        (0.1, 0.0, -0.3, 0.03, 0.4, 0.4, 0.4, 0.2),
-        (0.3, 0.0, -0.1, 0.03, 0.4, 0.4, 0.4, 0.2),
-        (-0.1, 0.0, 0.3, 0.03, 0.4, 0.4, 0.4, 0.2),
-        (-0.3, 0.0, -0.1, 0.03, 0.4, 0.4, 0.4, 0.2),
-        (-0.1, 0.0, -0.3, 0.03, 0.4, 0.4, 0.4, 0.2),
-    ]
+    sums are Lua doubles, narrowed to float by script.h:22-32.  The script's
+    object table is data: pwnfps_amd/data/game_objects.txt."""
+    sys.path.insert(0, ROOT)
+    from pwnfps_amd.script import load_object_rows
+    opos = load_object_rows()
     s = np.zeros(len(opos), SPHERE_DTYPE)
     for i, (dx, dy, dz, r, c1, c2, c3, refl) in enumerate(opos):
         s[i] = (r, refl, 9.5 + dx, 0.3 + dy, 5.5 + dz, c1, c2, c3)
