@@ -11,8 +11,15 @@ level_prepare_render() + trace_screen_centred() (main.c:95,107; screen.h:31-124)
 rank r traces rows [r*H/N, (r+1)*H/N), the pre-blur strips are all-gathered
 (RCCL), each rank blurs its strip, and the strips are gathered on rank 0
 (pwnfps_amd/dist.py).  Level/sphere tables and all frame buffers are resident
-in HBM before the timed region; the frame stays on the device (the
-PCIe-inclusive rate is reported separately as pcie_inclusive_mpix_s).
+in HBM before the timed region; in the timed region of `value` the frame stays
+on the device.  The rate with every frame handed over to the host (what
+trace_screen_centred does with sbuf, main.c:107) is measured in the same run
+through the frames-in-flight API and reported as `d2h_inclusive`.
+
+Timing: the K timed steps are one block, bracketed by barrier + synchronize.
+A block of 20 frames lasts 9 ms, so blocks are repeated until a second has
+been timed and `value` is the MEDIAN block (every block is exactly K steps);
+the spread over blocks and over single launches is reported next to it.
 
 Prints ONE JSON line on rank 0.  After the timed region the last frame is
 hashed and compared with the golden hash of the compiled reference.
@@ -147,6 +154,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--level", default="pwnfps_level")
     ap.add_argument("--blur", type=int, default=1)
+    ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step block until this many seconds were timed")
+    ap.add_argument("--slots", type=int, default=3, help="frames in flight of the d2h_inclusive leg")
+    ap.add_argument("--scheduler", choices=["units", "refill"], default=None, help="trace kernel scheduler (default: the library's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: finish each frame before starting the next")
     ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
@@ -193,6 +203,8 @@ def main():
     r = pwnfps_amd.Renderer(w, h, device=local)
     r.level_load(level_file)
     r.set_objects(spheres)
+    if args.scheduler:
+        r.set_scheduler(args.scheduler)
     _, _, spawn = r.get_level()
     cam = pwnfps_amd.spawn_camera(spawn)            # main.c:61-64
     sec = 0.0
@@ -233,30 +245,42 @@ def main():
     else:
         for _ in range(args.warmup):
             out = fr.render(cam, sec)
-    barrier()
-    t0 = time.perf_counter()
     # every step re-bins and re-uploads the spheres first, like the reference's frame loop does
     # (level_prepare_render, main.c:95), although this benchmark's spheres do not move
-    if pipelined:
-        for i in range(args.steps):
-            slot["i"] = i
-            r.set_objects(spheres)
-            fr.submit(cam, sec)
-        slot["i"] = -1
-        out = fr.flush()
-    else:
-        for i in range(args.steps):
-            slot["i"] = i
-            r.set_objects(spheres)
-            out = fr.render(cam, sec)
-        slot["i"] = -1
-    barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    trace_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else 0.0
+    def block():
+        """exactly K steps between barrier + synchronize; seconds, max over ranks"""
+        nonlocal out
+        barrier()
+        t0 = time.perf_counter()
+        if pipelined:
+            for i in range(args.steps):
+                slot["i"] = i
+                r.set_objects(spheres)
+                fr.submit(cam, sec)
+            slot["i"] = -1
+            out = fr.flush()
+        else:
+            for i in range(args.steps):
+                slot["i"] = i
+                r.set_objects(spheres)
+                out = fr.render(cam, sec)
+            slot["i"] = -1
+        barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+    block_s, launch_ms = [], []
+    while True:
+        block_s.append(block())
+        launch_ms.extend(a.elapsed_time(b) for a, b in ev)
+        # all ranks see the same (max-reduced) times, so they stop together
+        if sum(block_s) >= args.min_time or len(block_s) >= 500:
+            break
+    dt = float(np.median(block_s))
+    trace_ms = float(np.mean(launch_ms)) if launch_ms else 0.0
     tr = torch.tensor([trace_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tr, op=dist.ReduceOp.MAX)
@@ -294,13 +318,48 @@ def main():
                     "sphere_tests_per_ray": round(st["sphere_tests"] / max(st["rays"], 1), 4),
                     # lanes doing a cell step / lanes of the wave64s running the walk loop
                     "walk_active_lane_fraction": round(st["steps"] / max(64 * st["wave_steps"], 1), 4)}
-        best = 1e9
+        blocking_best = 1e9
         for _ in range(5):
             t1 = time.perf_counter()
             r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
-            best = min(best, time.perf_counter() - t1)
-        pcie = round(w * h / best / 1e6, 2)
-        st = r.stats()
+            blocking_best = min(blocking_best, time.perf_counter() - t1)
+        st = r.stats()                     # kernel times of an uncounted frame
+        # The metric as SURVEY.md 8(d) words it: every frame handed over to the host.  Same
+        # step as above (re-bin + upload, trace, blur) plus the D2H into the library's pinned
+        # sbuf, `slots` frames in flight; the same K-step blocks, median block.
+        nsl = max(2, min(args.slots, 4))
+        r.frames_config(nsl, sbuf=True)
+        last = None
+
+        def d2h_block(n):
+            nonlocal last
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for f in range(n + nsl - 1):
+                if f >= nsl - 1:
+                    last = r.wait_frame((f - nsl + 1) % nsl)
+                if f < n:
+                    r.set_objects(spheres)
+                    r.submit_frame(cam, sec, f % nsl)
+            return time.perf_counter() - t1
+        d2h_block(args.warmup)
+        d2h_s = []
+        while sum(d2h_s) < args.min_time and len(d2h_s) < 500:
+            d2h_s.append(d2h_block(args.steps))
+        d2h_dt = float(np.median(d2h_s))
+        d2h_ok = None
+        if parity is not None:
+            d2h_ok = bool(oracle.fnv64(last["sbuf"]) == frame_hash)
+        pcie = {"value": round(w * h * args.steps / d2h_dt / 1e6, 3), "unit": "Mpixels/s",
+                "ms_per_step": round(d2h_dt / args.steps * 1e3, 4), "frames_in_flight": nsl,
+                "blocks": len(d2h_s), "block_ms_p10_p50_p90": [round(float(np.percentile(d2h_s, q)) * 1e3, 3) for q in (10, 50, 90)],
+                "bytes_over_pcie_per_frame": 4 * w * h,
+                "pcie_gbs": round(4 * w * h * args.steps / d2h_dt / 1e9, 2),
+                "blocking_call_mpix_s": round(w * h / blocking_best / 1e6, 2),
+                "last_frame_equals_resident_frame": d2h_ok,
+                "what": "set_objects + pwn_submit_frame / pwn_wait_frame: trace + blur + D2H of sbuf into pinned host memory; "
+                        "blocking_call = one pwn_trace_screen_centred into pageable memory at a time"}
+        r.frames_config(0)
         kernel_ms = {"trace": round(st["trace_ms"], 4), "blur": round(st["blur_ms"], 4)}
     else:
         kernel_ms = None
@@ -315,6 +374,11 @@ def main():
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "timing": {"blocks_of_k_steps": len(block_s), "value_is": "median block",
+                       "block_ms_p10_p50_p90": [round(float(np.percentile(block_s, q)) * 1e3, 4) for q in (10, 50, 90)],
+                       "first_block_ms": round(block_s[0] * 1e3, 4),
+                       "trace_launch_ms_p10_p50_p90": [round(float(np.percentile(launch_ms, q)), 4) for q in (10, 50, 90)],
+                       "launches_timed": len(launch_ms)},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -355,7 +419,7 @@ def main():
         if kernel_ms:
             line["kernel_ms"] = kernel_ms
         if pcie:
-            line["pcie_inclusive_mpix_s"] = pcie
+            line["d2h_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w, h, cam, spheres, level_file)
         print(json.dumps(line), flush=True)

@@ -14,10 +14,14 @@
  *
  *   pwnhost level.txt [-s spheres.txt | -g game_objects.txt] [-w W] [-h H]
  *           [-x SCALE] [-n FRAMES] [-t SECONDS_PER_FRAME] [-a TURN_PER_FRAME]
- *           [-p PITCH] [-b BLUR_PASSES] [-o out.ppm] [-d DEVICE] [-v 1]
+ *           [-p PITCH] [-b BLUR_PASSES] [-o out.ppm] [-d DEVICE] [-v 1] [-q SLOTS]
  *
  * -t fixes the clock step (the reference uses wall time, main.c:112-114), which
  * makes a run reproducible; -v 1 prints every frame's hash.
+ * -q SLOTS (2..4) keeps that many frames in flight (pwn_submit_frame /
+ * pwn_wait_frame): the frame and its upscaled surface arrive in the library's
+ * pinned host buffers while the next frame's kernels run; frame f is presented
+ * SLOTS-1 frames late, the pixels are the same.
  *
  * Build: make -C host      (gcc only; links libpwnhip.so by path)
  */
@@ -118,7 +122,7 @@ static uint64_t fnv64(const uint32_t *p, size_t n)
 int main(int argc, char **argv)
 {
 	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL;
-	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0;
+	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
 	float turn = 0.0f, fixed_dt = -1.0f;
 	for(int i = 1; i < argc; i++)
 	{
@@ -139,15 +143,18 @@ int main(int argc, char **argv)
 			case 'b': blur = atoi(argv[++i]); break;
 			case 'o': out = argv[++i]; break;
 			case 'd': device = atoi(argv[++i]); break;
+			case 'q': slots = atoi(argv[++i]); break;
 			default: fprintf(stderr, "unknown option %s\n", argv[i]); return 2;
 		}
 	}
 	if(level == NULL)
 	{
 		fprintf(stderr, "usage: pwnhost level.txt [-s spheres.txt | -g game_objects.txt] [-w W] [-h H] [-x SCALE] "
-			"[-n FRAMES] [-t SEC_PER_FRAME] [-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE] [-v 1]\n");
+			"[-n FRAMES] [-t SEC_PER_FRAME] [-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE] [-v 1] [-q SLOTS]\n");
 		return 2;
 	}
+	if(slots != 0 && (slots < 2 || slots > PWN_MAX_SLOTS)) { fprintf(stderr, "-q takes 2..%d\n", PWN_MAX_SLOTS); return 2; }
+	if(slots != 0 && fixed_dt < 0.0f) fixed_dt = 0.0f;       /* frames in flight run on a fixed clock step (-t) */
 	if(rscale < 1) rscale = 1;
 	if(pitch == 0) pitch = rwidth * rscale * 4;
 
@@ -184,6 +191,51 @@ int main(int argc, char **argv)
 
 	float ang = 0.0f;
 	double t_first = 0.0, t_rest = 0.0;
+	if(slots > 0)
+	{
+		/* frames in flight: the loop of main.c:93-140 with the present step SLOTS-1 frames behind */
+		CHK(pwn_frames_config(ctx, slots, PWN_FRAME_SBUF | PWN_FRAME_SURFACE, rscale, pitch));
+		pwn_frame fr;
+		memset(&fr, 0, sizeof(fr));
+		double t0 = now_s(), t1 = t0;
+		for(int f = 0; f < frames + slots - 1; f++)
+		{
+			if(f >= slots - 1)
+			{
+				int k = f - (slots - 1);
+				CHK(pwn_wait_frame(ctx, k % slots, &fr));                              /* SDL_Flip's place, main.c:109 */
+				if(verbose)
+					printf("frame %d sec %.9g fnv64 %016llx\n", k, (double)fr.sec_current, (unsigned long long)fnv64(fr.sbuf, npix));
+				if(k == 0) t1 = now_s();
+			}
+			if(f < frames)
+			{
+				float cam[16];
+				cam_identity(cam);
+				if(ang != 0.0f) cam_roty(cam, ang);
+				cam[12] = 0.5f + (float)spawn[0]; cam[13] = 0.5f; cam[14] = 0.5f + (float)spawn[1];
+				CHK(pwn_prepare_render(ctx));                                           /* main.c:95 */
+				CHK(pwn_submit_frame(ctx, cam, sec_current, f % slots));                /* main.c:107-108 */
+				sec_current += fixed_dt;                                                /* main.c:112-114 */
+				if(gamefile != NULL)
+					CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)fixed_dt));   /* main.c:127-140 */
+				ang += turn;
+			}
+		}
+		double t2 = now_s();
+		printf("frame %dx%d x%d: sbuf fnv64 %016llx, surface fnv64 %016llx\n", rwidth, rheight, rscale,
+			(unsigned long long)fnv64(fr.sbuf, npix),
+			(unsigned long long)fnv64(fr.surface, (size_t)(pitch / 4) * (size_t)rheight * (size_t)rscale));
+		printf("last frame on the device: trace %.3f ms, blur %.3f ms, sink %.3f ms\n", fr.trace_ms, fr.blur_ms, fr.sink_ms);
+		if(frames > 1)
+			printf("host loop incl. upload, D2H and sink, %d frames in flight: %.2f Mpixels/s over %d frames (first frame %.1f ms)\n",
+				slots, (double)npix * (frames - 1) / (t2 - t1) / 1e6, frames - 1, (t1 - t0) * 1e3);
+		if(out != NULL && write_ppm(out, fr.surface, rwidth * rscale, rheight * rscale, pitch / 4) != 0)
+			fprintf(stderr, "cannot write %s\n", out);
+		pwn_destroy(ctx);
+		free(sph); free(sbuf); free(zbuf); free(surface.pixels);
+		return 0;
+	}
 	for(int f = 0; f < frames; f++)
 	{
 		float cam[16];

@@ -31,6 +31,8 @@ extern "C" {
 #define PWN_EHIP         -5  /* a HIP runtime call failed; see pwn_last_error() */
 #define PWN_ENOLEVEL     -6  /* render called before a level was uploaded */
 #define PWN_ETOOBIG      -7  /* sphere tables exceed the on-chip (LDS) budget */
+#define PWN_EBUSY        -8  /* the frame slot is still in flight (pwn_wait_frame it first) */
+#define PWN_ENOTSUP      -9  /* not available here (RCCL could not be loaded; not configured) */
 
 typedef struct pwn_ctx pwn_ctx;
 
@@ -64,6 +66,10 @@ typedef struct pwn_stats
 /* options for pwn_set_option */
 #define PWN_OPT_BLUR_PASSES 1  /* POSTPROC_BLUR (defs.h:9); default 1, 0 = off */
 #define PWN_OPT_COUNTERS    2  /* 1: frames also fill pwn_stats counters (slower) */
+#define PWN_OPT_SCHEDULER   3  /* how the trace kernel hands pixels to the lanes of a wave64: */
+#define PWN_SCHED_UNITS     0  /*   a wave traces 16x4-pixel units, all 64 lanes in step (ray set-up, walk, shading) */
+#define PWN_SCHED_REFILL    1  /*   lanes whose ray ended are refilled by ballot + prefix rank while the rest walk on */
+#define PWN_SCHED_DEFAULT   PWN_SCHED_UNITS
 
 /*
  * Replaces the buffer/global set-up of main.c:26-34,395-400 (rwidth, rheight,
@@ -99,7 +105,10 @@ int pwn_get_bins(pwn_ctx *ctx, uint16_t counts[4096], int32_t *idx, int cap);
  *   pwn_obj_set_sphere obj_set(o, "sphere", r, refl, x, y, z, b, g, r)
  *                      (script.h:10-40); Lua numbers are doubles and are
  *                      narrowed to float on store, as there
- *   pwn_obj_free       obj_free (script.h:42-51): the slot becomes reusable
+ *   pwn_obj_free       obj_free (script.h:42-51): the slot becomes reusable.  As with
+ *                      the reference's part pointers the handle stays usable:
+ *                      obj_set on a freed slot makes it a sphere again (script.h:24
+ *                      sets pt->typ whatever it was), obj_free on it changes nothing
  *   pwn_level_get      level_get(cx, cz) (script.h:53-64): the cell character
  *                      under get_cell's clamp (util.h:151-158)
  *   pwn_prepare_render level_prepare_render (level.h:64-81): bin every object
@@ -128,6 +137,50 @@ int pwn_get_objects(pwn_ctx *ctx, pwn_sphere *out, int cap);
  */
 int pwn_trace_screen_centred(pwn_ctx *ctx, const float cam[16], float sec_current,
 	uint32_t *sbuf, float *zbuf);
+
+/*
+ * Frames in flight.  The reference presents every frame on the host
+ * (trace_screen_centred fills sbuf, screen_upscale fills screen->pixels, SDL_Flip:
+ * main.c:107-109).  Over PCIe that hand-over takes longer than the kernels of a
+ * frame, so a host that wants throughput overlaps it: with 2-3 slots, frame i
+ * travels to the library's pinned host buffers on a copy stream while the
+ * kernels of frame i+1 run.
+ *   pwn_frames_config  nslots (1..PWN_MAX_SLOTS; 0 releases them) and what a frame
+ *                      delivers: PWN_FRAME_SBUF the colour plane (main.c:31),
+ *                      PWN_FRAME_ZBUF the depth plane (main.c:33), PWN_FRAME_SURFACE
+ *                      the scale x scale upscaled surface (screen_upscale,
+ *                      screen.h:126-149; pitch_bytes 0 = width*scale*4; bytes between
+ *                      the rows of a wider pitch read 0).  Buffers are library-owned
+ *                      pinned host memory.
+ *   pwn_submit_frame   enqueue trace + blur (+ sink) + the copies for `slot`; returns at
+ *                      once.  Uses the tables of the last pwn_upload_spheres /
+ *                      pwn_prepare_render / level call, which may be called between
+ *                      submits without waiting for anything.  PWN_EBUSY if the slot's
+ *                      previous frame has not been waited for.
+ *   pwn_wait_frame     block until the slot's frame is on the host; the pointers in
+ *                      *out stay valid until the next submit on that slot.
+ *   pwn_frame_ready    1 / 0 without blocking.
+ * Frames complete in submission order.  The blocking pwn_trace_screen_centred may be
+ * mixed in; it is ordered behind the submitted frames.
+ */
+#define PWN_MAX_SLOTS     4
+#define PWN_FRAME_SBUF    1
+#define PWN_FRAME_ZBUF    2
+#define PWN_FRAME_SURFACE 4
+typedef struct pwn_frame
+{
+	const uint32_t *sbuf;        /* BGRA8, pitch = width          (NULL unless PWN_FRAME_SBUF)    */
+	const float *zbuf;           /* fp32 depth, pitch = width     (NULL unless PWN_FRAME_ZBUF)    */
+	const uint32_t *surface;     /* upscaled, surface_pitch_bytes (NULL unless PWN_FRAME_SURFACE) */
+	int surface_pitch_bytes;
+	float sec_current;           /* as submitted */
+	float trace_ms, blur_ms, sink_ms;   /* device time of this frame's kernels */
+	uint64_t seq;                /* 1, 2, ... in submission order */
+} pwn_frame;
+int pwn_frames_config(pwn_ctx *ctx, int nslots, int flags, int scale, int pitch_bytes);
+int pwn_submit_frame(pwn_ctx *ctx, const float cam[16], float sec_current, int slot);
+int pwn_wait_frame(pwn_ctx *ctx, int slot, pwn_frame *out);
+int pwn_frame_ready(pwn_ctx *ctx, int slot);
 
 /*
  * Strip forms for row tiling across GPUs (one process per GPU; the exchange

@@ -10,7 +10,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PWNHIP_LIB") or os.path.join(_HERE, "libpwnhip.so")
 
 PWN_OK, PWN_EINVAL, PWN_ENODEV, PWN_ENOMEM, PWN_EIO, PWN_EHIP, PWN_ENOLEVEL, PWN_ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
-PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS = 1, 2
+PWN_EBUSY, PWN_ENOTSUP = -8, -9
+PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER = 1, 2, 3
+PWN_SCHED_UNITS, PWN_SCHED_REFILL = 0, 1
+PWN_MAX_SLOTS = 4
+PWN_FRAME_SBUF, PWN_FRAME_ZBUF, PWN_FRAME_SURFACE = 1, 2, 4
 PWN_OBJ_MAX = 10000
 (PROBE_RCP, PROBE_RSQRT, PROBE_SINF, PROBE_COSF, PROBE_EXPF, PROBE_SQRT, PROBE_DIV,
  PROBE_FTOINT, PROBE_RANDFS, PROBE_SIN_OF_PAIR, PROBE_COS_OF_PAIR) = range(11)
@@ -29,6 +33,12 @@ class Stats(C.Structure):
                 ("sphere_tests", C.c_uint64), ("exhausted", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("total_ms", C.c_float), ("reserved_", C.c_float),
                 ("wave_paths", C.c_uint64 * 8)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("sbuf", C.c_void_p), ("zbuf", C.c_void_p), ("surface", C.c_void_p), ("surface_pitch_bytes", C.c_int),
+                ("sec_current", C.c_float), ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("sink_ms", C.c_float),
+                ("seq", C.c_uint64)]
 
 
 # every symbol include/pwnhip.h declares: (name, restype, argtypes)
@@ -52,6 +62,10 @@ ABI = [
     ("pwn_prepare_render", _i, [_vp]),
     ("pwn_get_objects", _i, [_vp, _vp, _i]),
     ("pwn_trace_screen_centred", _i, [_vp, _vp, _f, _vp, _vp]),
+    ("pwn_frames_config", _i, [_vp, _i, _i, _i, _i]),
+    ("pwn_submit_frame", _i, [_vp, _vp, _f, _i]),
+    ("pwn_wait_frame", _i, [_vp, _i, C.POINTER(Frame)]),
+    ("pwn_frame_ready", _i, [_vp, _i]),
     ("pwn_trace_rows_device", _i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
     ("pwn_blur_rows_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("pwn_blur_rows_device_bounded", _i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),

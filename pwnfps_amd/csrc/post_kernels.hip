@@ -1,6 +1,7 @@
 // post_kernels.hip -- framebuffer-side kernels: depth-driven blur
 // (screen.h:69-123), SDL-sink upscale (screen.h:126-149), primitive probes.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "dev_math.h"
 #include "tables.h"
 
@@ -182,15 +183,19 @@ extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stre
 #else
 	const size_t lds = (size_t)BLUR_PITCH * BLUR_LH * sizeof(uint32_t);
 	static bool lds_mark[64];
+	static std::mutex lds_lock;      // contexts of several threads share the per-function attribute
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	bool &lds_set = lds_mark[dev & 63];
-	if(!lds_set)
 	{
-		hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if(e != hipSuccess) return e;
-		lds_set = true;
+		std::lock_guard<std::mutex> g(lds_lock);
+		bool &lds_set = lds_mark[dev & 63];
+		if(!lds_set)
+		{
+			hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			if(e != hipSuccess) return e;
+			lds_set = true;
+		}
 	}
 	const int ntiles = ((P->w + BLUR_TW - 1) / BLUR_TW) * ((P->y1 - P->y0 + BLUR_TH - 1) / BLUR_TH);
 	dim3 grid(((ntiles + 7) / 8) * 8);
@@ -211,16 +216,20 @@ __global__ void __launch_bounds__(256)
 pwn_upscale_kernel(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch)
 {
 	int dx = blockIdx.x * blockDim.x + threadIdx.x;
-	int dy = blockIdx.y;
-	if(dx >= w * scale || dy >= h * scale) return;
-	int py = dy / scale, y = dy - py * scale;
+	if(dx >= w * scale) return;
 	size_t rowadv = (size_t)w * scale + (size_t)pitch * (scale - 1);
-	dst[(size_t)py * rowadv + (size_t)y * pitch + dx] = src[(size_t)py * (size_t)w + (dx / scale)];
+	// grid.y is capped at 65535 rows; taller surfaces are walked in that stride
+	for(int dy = blockIdx.y; dy < h * scale; dy += gridDim.y)
+	{
+		int py = dy / scale, y = dy - py * scale;
+		dst[(size_t)py * rowadv + (size_t)y * pitch + dx] = src[(size_t)py * (size_t)w + (dx / scale)];
+	}
 }
 
 extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream)
 {
-	dim3 grid((w * scale + 255) / 256, h * scale);
+	const long long rows = (long long)h * scale;
+	dim3 grid((w * scale + 255) / 256, (unsigned)(rows > 65535 ? 65535 : rows));
 	hipLaunchKernelGGL(pwn_upscale_kernel, grid, dim3(256), 0, stream, src, dst, w, h, scale, pitch);
 	return hipGetLastError();
 }

@@ -11,72 +11,9 @@
 #include <vector>
 
 #include "pwnhip.h"
+#include "pwn_internal.h"
 #include "level_host.h"
-#include "tables.h"
 #include "approx_tables.inc"
-
-struct pwn_blur_params
-{
-	int w, h, y0, y1;
-	int groups;
-	const uint32_t *pre;
-	const float *zbuf;
-	uint32_t *out;
-	const uint2 *skip;
-	int avail_y0, avail_y1;
-	uint32_t *miss;
-};
-
-extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
-extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w);
-extern "C" int pwn_trace_tile_h(void);
-extern "C" int pwn_trace_tile_w(void);
-extern "C" unsigned pwn_trace_lds_extra(void);
-extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
-extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
-extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
-
-// LDS budget for the table blob: leave room so that at least two workgroups
-// fit per CU (160 KiB LDS per CU on gfx950)
-#define PWN_BLOB_MAX (72u * 1024u)
-
-struct pwn_ctx
-{
-	int device, w, h;
-	int num_cus;
-	int blur_passes, counters_on;
-	bool have_level;
-
-	uint8_t cells[4096];
-	pwn_portal pmap[26];
-	int32_t spawn[2];
-	std::vector<pwn_sphere> spheres;          // the live spheres the current lists index
-	std::vector<int32_t> bin_off, bin_idx;
-	std::vector<pwn_sphere> objs;             // lv->objs (defs.h:98): every slot ever handed out
-	std::vector<uint8_t> obj_typ;             // P_INVAL / P_FREE / P_SPHERE (defs.h:55-60)
-
-	std::vector<uint8_t> blob;       // host image of the LDS blob
-	uint8_t *d_blob; size_t d_blob_cap;
-	uint32_t off_sph;
-	bool blob_dirty;
-	size_t occ_lds[4]; int occ_blocks[4];    // cached occupancy query per kernel variant
-	hipEvent_t ev_tables; bool tables_in_use;   // recorded behind the last trace launch (it reads d_blob)
-
-	uint32_t *d_pre, *d_out;         // pre-blur ("tsbuf") and final ("sbuf") frames
-	float *d_z;
-	uint2 *d_skip;                   // blur LCG skip-ahead, w/4 entries
-	unsigned long long *d_counters;
-	uint32_t *d_tickets; unsigned ticket_set;  // two sets of work-queue counters of the trace kernel, used alternately
-	uint32_t *d_scratch; size_t scratch_cap;   // upscale / probe staging
-
-	hipStream_t stream;
-	hipEvent_t ev[4];
-	pwn_stats stats;
-	char err[256];
-};
-
-#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
-	snprintf((ctx)->err, sizeof((ctx)->err), "%s: %s", #call, hipGetErrorString(e_)); return PWN_EHIP; } } while(0)
 
 extern "C" const char *pwn_strerror(int code)
 {
@@ -90,6 +27,8 @@ extern "C" const char *pwn_strerror(int code)
 		case PWN_EHIP: return "HIP runtime error";
 		case PWN_ENOLEVEL: return "no level uploaded";
 		case PWN_ETOOBIG: return "sphere tables exceed the LDS budget";
+		case PWN_EBUSY: return "frame slot still in flight";
+		case PWN_ENOTSUP: return "not available (RCCL missing, or not configured)";
 	}
 	return "unknown error";
 }
@@ -105,6 +44,9 @@ static int ensure_scratch(pwn_ctx *c, size_t bytes)
 	return PWN_OK;
 }
 
+static void expand_tables(uint16_t *rcp, uint16_t *rsq);
+static void frames_release(pwn_ctx *c);
+
 extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 {
 	if(out == NULL || width <= 0 || height <= 0 || width > 32768 || height > 32768) return PWN_EINVAL;
@@ -114,18 +56,28 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	pwn_ctx *c = new(std::nothrow) pwn_ctx();
 	if(c == NULL) return PWN_ENOMEM;
 	c->device = device; c->w = width; c->h = height;
-	c->blur_passes = 1; c->counters_on = 0; c->have_level = false;
-	c->d_blob = NULL; c->d_blob_cap = 0; c->blob_dirty = true; c->off_sph = 0;
+	c->blur_passes = 1; c->counters_on = 0; c->scheduler = PWN_SCHED_DEFAULT; c->have_level = false;
+	c->blob_cur = 0; c->blob_dirty = true; c->off_sph = 0; c->stage_next = 0; c->up_stream = NULL;
+	for(int i = 0; i < PWN_NBLOB; i++)
+	{
+		c->d_blob[i] = NULL; c->blob_has_static[i] = false;
+		c->ev_tables[i] = NULL; c->tables_in_use[i] = false;
+		c->ev_upload[i] = NULL; c->upload_pending[i] = false;
+	}
+	for(int i = 0; i < PWN_NSTAGE; i++) { c->h_stage[i] = NULL; c->ev_stage[i] = NULL; c->stage_used[i] = false; }
 	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0;
 	c->d_scratch = NULL; c->scratch_cap = 0;
-	for(int i = 0; i < 4; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
-	c->ev_tables = NULL; c->tables_in_use = false;
-	c->stream = NULL;
+	for(int i = 0; i < 8; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
+	c->stream = NULL; c->copy_stream = NULL;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));
+	c->nslots = 0; c->frame_flags = 0; c->frame_scale = 1; c->frame_pitch = 0; c->frame_seq = 0;
+	memset(c->slot, 0, sizeof(c->slot));
+	c->tiled = NULL;
 	c->err[0] = 0;
 	pwn_level_clear(c->cells, c->pmap, c->spawn);
 	c->bin_off.assign(4097, 0);
+	expand_tables(c->tabs, c->tabs + 2048);
 
 	int rc = PWN_OK;
 	do
@@ -146,11 +98,22 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		   hipMalloc((void **)&c->d_tickets, 2 * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
 		   hipMemset(c->d_tickets, 0, 2 * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
 		   hipMalloc((void **)&c->d_skip, sizeof(uint2) * (size_t)(width / 4 + 1)) != hipSuccess) { rc = PWN_ENOMEM; break; }
+		for(int i = 0; i < PWN_NBLOB && rc == PWN_OK; i++)
+			if(hipMalloc((void **)&c->d_blob[i], PWN_BLOB_MAX) != hipSuccess) rc = PWN_ENOMEM;
+		for(int i = 0; i < PWN_NSTAGE && rc == PWN_OK; i++)
+			if(hipHostMalloc((void **)&c->h_stage[i], PWN_BLOB_MAX, hipHostMallocDefault) != hipSuccess) rc = PWN_ENOMEM;
+		if(rc != PWN_OK) break;
 		if(hipMemset(c->d_z, 0, n * 4) != hipSuccess || hipMemset(c->d_pre, 0, n * 4) != hipSuccess ||
 		   hipMemset(c->d_out, 0, n * 4) != hipSuccess) { rc = PWN_EHIP; break; }
-		if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+		if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+		   hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+		   hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
 		for(int i = 0; i < 4; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { rc = PWN_EHIP; break; }
-		if(rc == PWN_OK && hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming) != hipSuccess) rc = PWN_EHIP;
+		for(int i = 0; i < PWN_NBLOB && rc == PWN_OK; i++)
+			if(hipEventCreateWithFlags(&c->ev_tables[i], hipEventDisableTiming) != hipSuccess ||
+			   hipEventCreateWithFlags(&c->ev_upload[i], hipEventDisableTiming) != hipSuccess) rc = PWN_EHIP;
+		for(int i = 0; i < PWN_NSTAGE && rc == PWN_OK; i++)
+			if(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming) != hipSuccess) rc = PWN_EHIP;
 		if(rc != PWN_OK) break;
 
 		// blur LCG skip-ahead: entry g maps the row seed to the seed in front
@@ -174,11 +137,28 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 {
 	if(c == NULL) return;
 	(void)hipSetDevice(c->device);
+	if(c->tiled) pwn_tiled_destroy(c);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
+	if(c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+	if(c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+	(void)hipDeviceSynchronize();        // strip forms run on the caller's streams
+	frames_release(c);
 	for(int i = 0; i < 4; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
-	if(c->ev_tables) (void)hipEventDestroy(c->ev_tables);
+	for(int i = 0; i < PWN_NBLOB; i++)
+	{
+		if(c->ev_tables[i]) (void)hipEventDestroy(c->ev_tables[i]);
+		if(c->ev_upload[i]) (void)hipEventDestroy(c->ev_upload[i]);
+		(void)hipFree(c->d_blob[i]);
+	}
+	for(int i = 0; i < PWN_NSTAGE; i++)
+	{
+		if(c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
+		if(c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
+	}
 	if(c->stream) (void)hipStreamDestroy(c->stream);
-	(void)hipFree(c->d_blob); (void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z);
+	if(c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+	if(c->up_stream) (void)hipStreamDestroy(c->up_stream);
+	(void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z);
 	(void)hipFree(c->d_skip); (void)hipFree(c->d_counters); (void)hipFree(c->d_tickets); (void)hipFree(c->d_scratch);
 	delete c;
 }
@@ -190,6 +170,7 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 	{
 		case PWN_OPT_BLUR_PASSES: if(value < 0 || value > 16) return PWN_EINVAL; c->blur_passes = value; return PWN_OK;
 		case PWN_OPT_COUNTERS: c->counters_on = value ? 1 : 0; return PWN_OK;
+		case PWN_OPT_SCHEDULER: if(value < 0 || value > PWN_SCHED_REFILL) return PWN_EINVAL; c->scheduler = value; return PWN_OK;
 	}
 	return PWN_EINVAL;
 }
@@ -223,7 +204,7 @@ static int pack_blob(pwn_ctx *c)
 	if(nbin > 32767u || nsph >= PWN_LIST_END) return PWN_ETOOBIG;
 	uint32_t total = (pwn_t_total(nbin, nsph) + 15u) & ~15u;
 	if(total > PWN_BLOB_MAX) return PWN_ETOOBIG;
-	c->blob.assign(total, 0);
+	c->blob.assign(total, 0);        // (nothing has changed up to here: a failed call leaves the context as it was)
 	uint8_t *b = c->blob.data();
 	uint32_t *ci = (uint32_t *)(b + PWN_T_CELLINFO);
 	uint16_t *bi = (uint16_t *)(b + PWN_T_BINIDX);
@@ -246,7 +227,8 @@ static int pack_blob(pwn_ctx *c)
 	// never with spheres (the sphere loop runs for in-grid cells only, trace.h:252)
 	for(int z = 0; z < 64; z++) ci[z * PWN_GRID_PITCH + 64] = ci[z * PWN_GRID_PITCH] & ~(PWN_C_SPH | 0x7fff0000u);
 	for(int x = 0; x <= 64; x++) ci[64 * PWN_GRID_PITCH + x] = ci[x] & ~(PWN_C_SPH | 0x7fff0000u);
-	expand_tables((uint16_t *)(b + PWN_T_RCP), (uint16_t *)(b + PWN_T_RSQ));
+	memcpy(b + PWN_T_RCP, c->tabs, 4096);
+	memcpy(b + PWN_T_RSQ, c->tabs + 2048, 4096);
 	uint32_t *pm = (uint32_t *)(b + PWN_T_PMAP);
 	for(int i = 0; i < 26; i++)
 	{
@@ -257,17 +239,24 @@ static int pack_blob(pwn_ctx *c)
 	c->off_sph = pwn_t_sph_offset(nbin);
 	if(nsph) memcpy(b + c->off_sph, c->spheres.data(), nsph * sizeof(pwn_sphere));
 
-	if(total > c->d_blob_cap)
-	{
-		if(c->d_blob) { (void)hipFree(c->d_blob); c->d_blob = NULL; c->d_blob_cap = 0; }
-		HIPCHK(c, hipMalloc((void **)&c->d_blob, total));
-		c->d_blob_cap = total;
-	}
-	// a trace launch still in flight (strip forms run on the caller's stream) reads these tables:
-	// let it finish before they change (level_prepare_render runs between frames, main.c:95)
-	if(c->tables_in_use) { HIPCHK(c, hipEventSynchronize(c->ev_tables)); c->tables_in_use = false; }
-	HIPCHK(c, hipMemcpyAsync(c->d_blob, b, total, hipMemcpyHostToDevice, c->stream));
-	HIPCHK(c, hipStreamSynchronize(c->stream));
+	// Upload into the copy no launch in flight reads.  The rcp / rsqrt head of the blob never
+	// changes: once a copy has it, only [cellinfo, end) travels (cell words carry the sphere-list
+	// offsets, so they change with the spheres).  Nothing here blocks on the GPU except re-use
+	// of a staging buffer that is still being read, four uploads later.
+	const int nb = (c->blob_cur + 1) % PWN_NBLOB;
+	const uint32_t from = c->blob_has_static[nb] ? PWN_T_CELLINFO : 0u;
+	const unsigned st = c->stage_next++ % PWN_NSTAGE;
+	if(c->stage_used[st]) HIPCHK(c, hipEventSynchronize(c->ev_stage[st]));
+	memcpy(c->h_stage[st], b + from, total - from);
+	// launches still reading that copy (two uploads ago) finish first -- a wait between streams
+	if(c->tables_in_use[nb]) HIPCHK(c, hipStreamWaitEvent(c->up_stream, c->ev_tables[nb], 0));
+	HIPCHK(c, hipMemcpyAsync(c->d_blob[nb] + from, c->h_stage[st], total - from, hipMemcpyHostToDevice, c->up_stream));
+	HIPCHK(c, hipEventRecord(c->ev_stage[st], c->up_stream));
+	HIPCHK(c, hipEventRecord(c->ev_upload[nb], c->up_stream));
+	c->stage_used[st] = true;
+	c->upload_pending[nb] = true;
+	c->blob_has_static[nb] = true;
+	c->blob_cur = nb;
 	c->blob_dirty = false;
 	return PWN_OK;
 }
@@ -355,10 +344,13 @@ extern "C" int pwn_obj_new(pwn_ctx *c)
 	return (int)c->obj_typ.size() - 1;
 }
 
+// A handle is the index of a slot that level_obj_new once handed out.  Like the reference's
+// part pointers it stays usable after obj_free: obj_set on a freed slot makes it a sphere again
+// (script.h:24 sets pt->typ whatever it was), obj_free on it is a no-op (script.h:48).
 static bool obj_ok(pwn_ctx *c, int obj, const char *who)
 {
 	if(c == NULL) return false;
-	if(obj >= 0 && (size_t)obj < c->obj_typ.size() && c->obj_typ[(size_t)obj] != OBJ_FREE) return true;
+	if(obj >= 0 && (size_t)obj < c->obj_typ.size()) return true;
 	snprintf(c->err, sizeof(c->err), "%s: %d is not an object", who, obj);
 	return false;
 }
@@ -444,7 +436,8 @@ static int upload_live(pwn_ctx *c, const pwn_sphere *s, int n)
 	{
 		// keep the previous, working set
 		c->spheres.swap(keep_s); c->bin_off.swap(keep_o); c->bin_idx.swap(keep_i);
-		(void)pack_blob(c);
+		// too big: pack_blob gave up before it changed anything; a failed upload is tried again
+		if(rc == PWN_ETOOBIG) c->blob_dirty = false; else (void)pack_blob(c);
 	}
 	return rc;
 }
@@ -481,7 +474,7 @@ static void frame_setup(int w, int h, const float cam[16], pwn_trace_params *P)
 	}
 }
 
-static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y1,
+int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y1,
 	uint32_t *d_sbuf, float *d_zbuf, hipStream_t stream)
 {
 	if(!c->have_level) return PWN_ENOLEVEL;
@@ -499,7 +492,14 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	P.blob_bytes = (uint32_t)c->blob.size();
 	P.off_sph = c->off_sph;
 	P.sbuf = d_sbuf; P.zbuf = d_zbuf;
-	P.blob = (const uint32_t *)c->d_blob;
+	const int cur = c->blob_cur;
+	P.blob = (const uint32_t *)c->d_blob[cur];
+	// the upload of these tables runs on its own stream: this launch comes after it
+	if(c->upload_pending[cur])
+	{
+		if(hipEventQuery(c->ev_upload[cur]) == hipSuccess) c->upload_pending[cur] = false;
+		else HIPCHK(c, hipStreamWaitEvent(stream, c->ev_upload[cur], 0));
+	}
 	P.counters = c->d_counters;
 	// the kernel's work queues: this launch counts in one set and clears the other for the next
 	// launch of this context (stream-ordered behind it, include/pwnhip.h)
@@ -515,7 +515,8 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	// persistent grid: as many workgroups as are resident at once, each striding over tiles
 	const size_t lds_bytes = ((P.blob_bytes + 15u) & ~15u) + pwn_trace_lds_extra();
 	// resident workgroups per CU depend on (LDS bytes, kernel variant) only: ask once per combination
-	const int variant = (c->counters_on ? 2 : 0) | (P.has_w ? 1 : 0);
+	P.scheduler = c->scheduler;
+	const int variant = (c->scheduler == PWN_SCHED_REFILL ? 4 : 0) | (c->counters_on ? 2 : 0) | (P.has_w ? 1 : 0);
 	if(c->occ_lds[variant] != lds_bytes)
 	{
 		c->occ_blocks[variant] = pwn_trace_blocks_per_cu(lds_bytes, c->counters_on != 0, P.has_w != 0);
@@ -536,13 +537,13 @@ static int launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int 
 	if(grid > P.tiles_total) grid = P.tiles_total;
 	HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	c->ticket_set++;                     // only a launch that went out has cleared the other set
-	HIPCHK(c, hipEventRecord(c->ev_tables, stream));
-	c->tables_in_use = true;
+	HIPCHK(c, hipEventRecord(c->ev_tables[cur], stream));
+	c->tables_in_use[cur] = true;
 	return PWN_OK;
 }
 
-static int launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream,
-	int avail_y0 = 0, int avail_y1 = 0, uint32_t *d_miss = NULL)
+int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream,
+	int avail_y0, int avail_y1, uint32_t *d_miss)
 {
 	if((c->w & 3) != 0) return PWN_EINVAL; // screen.h:88,117: aligned 16-B store per group
 	pwn_blur_params B;
@@ -559,14 +560,14 @@ extern "C" int pwn_trace_rows_device(pwn_ctx *c, const float cam[16], float sec,
 {
 	if(c == NULL || cam == NULL || d_sbuf == NULL || d_zbuf == NULL || y0 < 0 || y1 > c->h || y0 > y1) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
-	return launch_trace(c, cam, sec, y0, y1, (uint32_t *)d_sbuf, (float *)d_zbuf, (hipStream_t)stream);
+	return pwn_i_launch_trace(c, cam, sec, y0, y1, (uint32_t *)d_sbuf, (float *)d_zbuf, (hipStream_t)stream);
 }
 
 extern "C" int pwn_blur_rows_device(pwn_ctx *c, int y0, int y1, const void *d_pre, const void *d_zbuf, void *d_out, void *stream)
 {
 	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || y0 < 0 || y1 > c->h || y0 > y1 || d_pre == d_out) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
-	return launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream);
+	return pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream, 0, 0, NULL);
 }
 
 extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const void *d_pre, const void *d_zbuf, void *d_out,
@@ -575,7 +576,7 @@ extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const vo
 	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || d_miss == NULL || y0 < 0 || y1 > c->h || y0 > y1 ||
 	   d_pre == d_out || avail_y0 > avail_y1) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
-	return launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream,
+	return pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream,
 		avail_y0, avail_y1, (uint32_t *)d_miss);
 }
 
@@ -590,12 +591,12 @@ extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float s
 	// trace into d_pre; with blur on, d_pre plays tsbuf and d_out plays sbuf
 	// (the memcpy of screen.h:75 becomes a pointer swap per pass)
 	uint32_t *cur = c->d_pre, *other = c->d_out;
-	int rc = launch_trace(c, cam, sec, 0, c->h, cur, c->d_z, s);
+	int rc = pwn_i_launch_trace(c, cam, sec, 0, c->h, cur, c->d_z, s);
 	if(rc != PWN_OK) return rc;
 	HIPCHK(c, hipEventRecord(c->ev[1], s));
 	for(int p = 0; p < c->blur_passes; p++)
 	{
-		rc = launch_blur(c, 0, c->h, cur, c->d_z, other, s);
+		rc = pwn_i_launch_blur(c, 0, c->h, cur, c->d_z, other, s, 0, 0, NULL);
 		if(rc != PWN_OK) return rc;
 		uint32_t *t = cur; cur = other; other = t;
 	}
@@ -609,6 +610,146 @@ extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float s
 	(void)hipEventElapsedTime(&c->stats.trace_ms, c->ev[0], c->ev[1]);
 	(void)hipEventElapsedTime(&c->stats.blur_ms, c->ev[1], c->ev[2]);
 	(void)hipEventElapsedTime(&c->stats.total_ms, c->ev[0], c->ev[3]);
+	return PWN_OK;
+}
+
+// ---- frames in flight ---------------------------------------------------------
+// The reference's loop presents every frame on the host (main.c:107-109).  Over PCIe that
+// copy takes longer than the kernels of a 4K frame, so a host that wants throughput keeps
+// two or three frames in flight: while frame i travels to its pinned host buffers on the
+// copy stream, the kernels of frame i+1 run on the compute stream.
+
+static void slot_release(pwn_slot &sl)
+{
+	(void)hipFree(sl.d_out); (void)hipFree(sl.d_z); (void)hipFree(sl.d_surface);
+	if(sl.h_sbuf) (void)hipHostFree(sl.h_sbuf);
+	if(sl.h_zbuf) (void)hipHostFree(sl.h_zbuf);
+	if(sl.h_surface) (void)hipHostFree(sl.h_surface);
+	for(int k = 0; k < 4; k++) if(sl.ev_k[k]) (void)hipEventDestroy(sl.ev_k[k]);
+	if(sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+	memset(&sl, 0, sizeof(sl));
+}
+
+static void frames_release(pwn_ctx *c)
+{
+	for(int i = 0; i < PWN_MAX_SLOTS; i++) slot_release(c->slot[i]);
+	c->nslots = 0;
+}
+
+extern "C" int pwn_frames_config(pwn_ctx *c, int nslots, int flags, int scale, int pitch_bytes)
+{
+	if(c == NULL || nslots < 0 || nslots > PWN_MAX_SLOTS || (flags & ~(PWN_FRAME_SBUF | PWN_FRAME_ZBUF | PWN_FRAME_SURFACE)) != 0) return PWN_EINVAL;
+	if(nslots > 0 && flags == 0) return PWN_EINVAL;
+	if(flags & PWN_FRAME_SURFACE)
+	{
+		if(scale <= 0) return PWN_EINVAL;
+		if(pitch_bytes == 0) pitch_bytes = c->w * scale * 4;
+		if((pitch_bytes & 3) != 0 || (long long)pitch_bytes < (long long)c->w * scale * 4) return PWN_EINVAL;
+	}
+	else { scale = 1; pitch_bytes = 0; }
+	(void)hipSetDevice(c->device);
+	for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
+	frames_release(c);
+	const size_t n = (size_t)c->w * (size_t)c->h;
+	const size_t surf_bytes = (size_t)pitch_bytes * (size_t)c->h * (size_t)scale;
+	int rc = PWN_OK;
+	for(int i = 0; i < nslots && rc == PWN_OK; i++)
+	{
+		pwn_slot &sl = c->slot[i];
+		if(hipMalloc((void **)&sl.d_out, n * 4) != hipSuccess) rc = PWN_ENOMEM;
+		if(rc == PWN_OK && (flags & PWN_FRAME_SBUF) && hipHostMalloc((void **)&sl.h_sbuf, n * 4, hipHostMallocDefault) != hipSuccess) rc = PWN_ENOMEM;
+		if(rc == PWN_OK && (flags & PWN_FRAME_ZBUF))
+		{
+			if(hipMalloc((void **)&sl.d_z, n * 4) != hipSuccess || hipHostMalloc((void **)&sl.h_zbuf, n * 4, hipHostMallocDefault) != hipSuccess) rc = PWN_ENOMEM;
+			// like the context's depth plane: zero, and kept at pixels whose primary ray runs out of steps
+			else if(hipMemset(sl.d_z, 0, n * 4) != hipSuccess) rc = PWN_EHIP;
+		}
+		if(rc == PWN_OK && (flags & PWN_FRAME_SURFACE))
+		{
+			if(hipMalloc((void **)&sl.d_surface, surf_bytes) != hipSuccess || hipHostMalloc((void **)&sl.h_surface, surf_bytes, hipHostMallocDefault) != hipSuccess) rc = PWN_ENOMEM;
+			else if(hipMemset(sl.d_surface, 0, surf_bytes) != hipSuccess) rc = PWN_EHIP;   // bytes between rows of a padded pitch stay 0
+		}
+		for(int k = 0; k < 4 && rc == PWN_OK; k++) if(hipEventCreate(&sl.ev_k[k]) != hipSuccess) rc = PWN_EHIP;
+		if(rc == PWN_OK && hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) != hipSuccess) rc = PWN_EHIP;
+	}
+	if(rc != PWN_OK) { frames_release(c); return rc; }
+	c->nslots = nslots; c->frame_flags = flags; c->frame_scale = scale; c->frame_pitch = pitch_bytes;
+	return PWN_OK;
+}
+
+extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int slot)
+{
+	if(c == NULL || cam == NULL || slot < 0 || slot >= c->nslots) return PWN_EINVAL;
+	if(c->blur_passes > 0 && (c->w & 3) != 0) return PWN_EINVAL;
+	pwn_slot &sl = c->slot[slot];
+	if(sl.in_flight) return PWN_EBUSY;
+	(void)hipSetDevice(c->device);
+	const size_t n = (size_t)c->w * (size_t)c->h;
+	hipStream_t s = c->stream;
+	float *dz = sl.d_z ? sl.d_z : c->d_z;
+	HIPCHK(c, hipEventRecord(sl.ev_k[0], s));
+	// the last pass writes into the slot's own plane, which is what the copy stream reads while
+	// the next frame's kernels reuse d_pre / d_out
+	uint32_t *cur = c->blur_passes > 0 ? c->d_pre : sl.d_out;
+	int rc = pwn_i_launch_trace(c, cam, sec, 0, c->h, cur, dz, s);
+	if(rc != PWN_OK) return rc;
+	HIPCHK(c, hipEventRecord(sl.ev_k[1], s));
+	for(int p = 0; p < c->blur_passes; p++)
+	{
+		uint32_t *dst = (p == c->blur_passes - 1) ? sl.d_out : (cur == c->d_pre ? c->d_out : c->d_pre);
+		rc = pwn_i_launch_blur(c, 0, c->h, cur, dz, dst, s, 0, 0, NULL);
+		if(rc != PWN_OK) return rc;
+		cur = dst;
+	}
+	HIPCHK(c, hipEventRecord(sl.ev_k[2], s));
+	if(c->frame_flags & PWN_FRAME_SURFACE)
+		HIPCHK(c, pwn_launch_upscale(sl.d_out, sl.d_surface, c->w, c->h, c->frame_scale, c->frame_pitch / 4, s));
+	HIPCHK(c, hipEventRecord(sl.ev_k[3], s));
+	HIPCHK(c, hipStreamWaitEvent(c->copy_stream, sl.ev_k[3], 0));
+	if(c->frame_flags & PWN_FRAME_SBUF) HIPCHK(c, hipMemcpyAsync(sl.h_sbuf, sl.d_out, n * 4, hipMemcpyDeviceToHost, c->copy_stream));
+	if(c->frame_flags & PWN_FRAME_ZBUF) HIPCHK(c, hipMemcpyAsync(sl.h_zbuf, sl.d_z, n * 4, hipMemcpyDeviceToHost, c->copy_stream));
+	if(c->frame_flags & PWN_FRAME_SURFACE)
+		HIPCHK(c, hipMemcpyAsync(sl.h_surface, sl.d_surface, (size_t)c->frame_pitch * (size_t)c->h * (size_t)c->frame_scale,
+			hipMemcpyDeviceToHost, c->copy_stream));
+	HIPCHK(c, hipEventRecord(sl.ev_done, c->copy_stream));
+	sl.in_flight = true; sl.sec = sec; sl.seq = ++c->frame_seq;
+	return PWN_OK;
+}
+
+extern "C" int pwn_frame_ready(pwn_ctx *c, int slot)
+{
+	if(c == NULL || slot < 0 || slot >= c->nslots) return PWN_EINVAL;
+	if(!c->slot[slot].in_flight) return 1;
+	(void)hipSetDevice(c->device);
+	hipError_t e = hipEventQuery(c->slot[slot].ev_done);
+	if(e == hipSuccess) return 1;
+	if(e == hipErrorNotReady) return 0;
+	snprintf(c->err, sizeof(c->err), "hipEventQuery: %s", hipGetErrorString(e));
+	return PWN_EHIP;
+}
+
+extern "C" int pwn_wait_frame(pwn_ctx *c, int slot, pwn_frame *out)
+{
+	if(c == NULL || slot < 0 || slot >= c->nslots) return PWN_EINVAL;
+	pwn_slot &sl = c->slot[slot];
+	if(sl.seq == 0) return PWN_EINVAL;            // nothing was ever submitted here
+	(void)hipSetDevice(c->device);
+	if(sl.in_flight)
+	{
+		HIPCHK(c, hipEventSynchronize(sl.ev_done));
+		sl.in_flight = false;
+	}
+	if(out != NULL)
+	{
+		memset(out, 0, sizeof(*out));
+		out->sbuf = sl.h_sbuf; out->zbuf = sl.h_zbuf; out->surface = sl.h_surface;
+		out->surface_pitch_bytes = c->frame_pitch;
+		out->sec_current = sl.sec; out->seq = sl.seq;
+		(void)hipEventElapsedTime(&out->trace_ms, sl.ev_k[0], sl.ev_k[1]);
+		(void)hipEventElapsedTime(&out->blur_ms, sl.ev_k[1], sl.ev_k[2]);
+		(void)hipEventElapsedTime(&out->sink_ms, sl.ev_k[2], sl.ev_k[3]);
+		c->stats.trace_ms = out->trace_ms; c->stats.blur_ms = out->blur_ms;
+	}
 	return PWN_OK;
 }
 
@@ -681,9 +822,7 @@ extern "C" int pwn_probe(pwn_ctx *c, int op, const uint32_t *in, uint32_t *out, 
 	uint8_t *base = (uint8_t *)c->d_scratch;
 	uint16_t *d_tabs = (uint16_t *)base;
 	uint32_t *d_in = (uint32_t *)(base + 8192), *d_out = (uint32_t *)(base + 8192 + in_bytes);
-	std::vector<uint16_t> tabs(4096);
-	expand_tables(tabs.data(), tabs.data() + 2048);
-	HIPCHK(c, hipMemcpy(d_tabs, tabs.data(), 8192, hipMemcpyHostToDevice));
+	HIPCHK(c, hipMemcpy(d_tabs, c->tabs, 8192, hipMemcpyHostToDevice));
 	HIPCHK(c, hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(c, pwn_launch_probe(op, d_in, d_out, n, d_tabs, c->stream));
 	HIPCHK(c, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));

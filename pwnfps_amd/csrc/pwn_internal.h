@@ -1,0 +1,112 @@
+// pwn_internal.h -- the context behind include/pwnhip.h, shared by the translation
+// units of libpwnhip.so (pwn_api.cpp: frames, tables; pwn_tiled.cpp: row tiling over RCCL).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <vector>
+
+#include "pwnhip.h"
+#include "tables.h"
+
+struct pwn_blur_params
+{
+	int w, h, y0, y1;
+	int groups;
+	const uint32_t *pre;
+	const float *zbuf;
+	uint32_t *out;
+	const uint2 *skip;
+	int avail_y0, avail_y1;
+	uint32_t *miss;
+};
+
+extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
+extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w);
+extern "C" int pwn_trace_tile_h(void);
+extern "C" int pwn_trace_tile_w(void);
+extern "C" unsigned pwn_trace_lds_extra(void);
+extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
+extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
+extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
+
+// LDS budget for the table blob: leave room so that at least two workgroups
+// fit per CU (160 KiB LDS per CU on gfx950)
+#define PWN_BLOB_MAX (72u * 1024u)
+#define PWN_NBLOB 2       // device copies of the blob (an upload never touches the one launches in flight read)
+#define PWN_NSTAGE 4      // pinned staging buffers for those uploads
+
+// one frame in flight (pwn_submit_frame / pwn_wait_frame)
+struct pwn_slot
+{
+	uint32_t *d_out; float *d_z; uint32_t *d_surface;      // device: final colour, depth (PWN_FRAME_ZBUF), upscaled surface
+	uint32_t *h_sbuf; float *h_zbuf; uint32_t *h_surface;  // pinned host copies handed to the caller
+	hipEvent_t ev_k[4];                                    // compute stream: start, after trace, after blur, after sink
+	hipEvent_t ev_done;                                    // copy stream: this frame's host buffers are complete
+	bool in_flight;
+	float sec;
+	uint64_t seq;
+};
+
+struct pwn_tiled;        // pwn_tiled.cpp
+
+struct pwn_ctx
+{
+	int device, w, h;
+	int num_cus;
+	int blur_passes, counters_on, scheduler;
+	bool have_level;
+
+	uint8_t cells[4096];
+	pwn_portal pmap[26];
+	int32_t spawn[2];
+	std::vector<pwn_sphere> spheres;          // the live spheres the current lists index
+	std::vector<int32_t> bin_off, bin_idx;
+	std::vector<pwn_sphere> objs;             // lv->objs (defs.h:98): every slot ever handed out
+	std::vector<uint8_t> obj_typ;             // P_INVAL / P_FREE / P_SPHERE (defs.h:55-60)
+
+	std::vector<uint8_t> blob;       // host image of the LDS blob
+	// The device copy exists twice: an upload goes into the buffer the launches in flight do not
+	// read, on its own stream and from a pinned staging ring, so the host never waits for the GPU
+	// between frames (level_prepare_render runs every frame, main.c:95).
+	uint8_t *d_blob[PWN_NBLOB]; int blob_cur;
+	bool blob_has_static[PWN_NBLOB];                                   // the rcp / rsqrt tables are in place
+	hipEvent_t ev_tables[PWN_NBLOB]; bool tables_in_use[PWN_NBLOB];    // behind the last trace launch reading that copy
+	hipEvent_t ev_upload[PWN_NBLOB]; bool upload_pending[PWN_NBLOB];   // behind the last upload into that copy
+	uint8_t *h_stage[PWN_NSTAGE]; hipEvent_t ev_stage[PWN_NSTAGE]; bool stage_used[PWN_NSTAGE]; unsigned stage_next;
+	hipStream_t up_stream;
+	uint16_t tabs[4096];             // expanded rcp + rsqrt tables (never change)
+	uint32_t off_sph;
+	bool blob_dirty;
+	size_t occ_lds[8]; int occ_blocks[8];    // cached occupancy query per kernel variant
+
+	uint32_t *d_pre, *d_out;         // pre-blur ("tsbuf") and final ("sbuf") frames
+	float *d_z;
+	uint2 *d_skip;                   // blur LCG skip-ahead, w/4 entries
+	unsigned long long *d_counters;
+	uint32_t *d_tickets; unsigned ticket_set;  // two sets of work-queue counters of the trace kernel, used alternately
+	uint32_t *d_scratch; size_t scratch_cap;   // upscale / probe staging
+
+	hipStream_t stream;              // compute
+	hipStream_t copy_stream;         // D2H of finished frames (frames in flight)
+	hipEvent_t ev[4];
+	pwn_stats stats;
+
+	// frames in flight
+	int nslots, frame_flags, frame_scale, frame_pitch;
+	pwn_slot slot[PWN_MAX_SLOTS];
+	uint64_t frame_seq;
+
+	pwn_tiled *tiled;                // row tiling over RCCL, NULL until pwn_tiled_init
+
+	char err[256];
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if(e_ != hipSuccess) { \
+	snprintf((ctx)->err, sizeof((ctx)->err), "%s: %s", #call, hipGetErrorString(e_)); return PWN_EHIP; } } while(0)
+
+// pwn_api.cpp internals used by pwn_tiled.cpp
+int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y1, uint32_t *d_sbuf, float *d_zbuf, hipStream_t stream);
+int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream,
+	int avail_y0, int avail_y1, uint32_t *d_miss);
+void pwn_tiled_destroy(pwn_ctx *c);

@@ -92,6 +92,7 @@ struct pwn_trace_params
 	const uint32_t *blob;
 	unsigned long long *counters;             // 14 x u64 (pwn_stats counters + wave_paths) or NULL
 	int has_w;                                // camera has w components (general 4-lane path)
+	int scheduler;                            // PWN_SCHED_* (pwnhip.h)
 	// work queues of the wave scheduler (trace_kernel.hip): PWN_QUEUES counters, one per 128 B,
 	// for this launch; the set of the next launch, which this one clears
 	uint32_t *tickets, *tickets_next;

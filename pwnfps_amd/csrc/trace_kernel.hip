@@ -26,6 +26,7 @@
 //     is arithmetically identical to the 4-lane SSE code (see HAS_W below),
 //   - no device function calls (dev_math.h) and no SLP packing (Makefile).
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "dev_math.h"
 #include "tables.h"
 
@@ -821,17 +822,22 @@ template<bool COUNT, bool HAS_W>
 static hipError_t launch_variant(const pwn_trace_params *P, int grid, size_t lds_bytes, hipStream_t stream)
 {
 	// the dynamic-LDS limit is a per-function attribute: raise it only when the blob grew
-	// (high-water mark per device and variant)
+	// (high-water mark per device and variant; contexts of several threads share it, so the
+	// check and the raise happen under a lock and the mark only ever grows)
 	static size_t lds_mark[64];
+	static std::mutex lds_lock;
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	size_t &lds_set = lds_mark[dev & 63];
-	if(lds_bytes > lds_set)
 	{
-		hipError_t e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W>,
-			hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-		if(e != hipSuccess) return e;
-		lds_set = lds_bytes;
+		std::lock_guard<std::mutex> g(lds_lock);
+		size_t &lds_set = lds_mark[dev & 63];
+		if(lds_bytes > lds_set)
+		{
+			hipError_t e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W>,
+				hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+			if(e != hipSuccess) return e;
+			lds_set = lds_bytes;
+		}
 	}
 	hipLaunchKernelGGL((pwn_trace_kernel<COUNT, HAS_W>), dim3(grid), dim3(PWN_BLOCK), lds_bytes, stream, *P);
 	return hipGetLastError();

@@ -58,6 +58,12 @@ class Renderer:
         """POSTPROC_BLUR (defs.h:9); 0 disables the post-process."""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_BLUR_PASSES, int(n)), "pwn_set_option")
 
+    def set_scheduler(self, which):
+        """PWN_OPT_SCHEDULER: "units" (a wave64 traces 16x4-pixel units in step) or "refill"
+        (lanes whose ray ended are refilled by ballot + prefix rank)."""
+        v = {"units": _lib.PWN_SCHED_UNITS, "refill": _lib.PWN_SCHED_REFILL}.get(which, which)
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_SCHEDULER, int(v)), "pwn_set_option")
+
     def set_counters(self, on):
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_COUNTERS, 1 if on else 0), "pwn_set_option")
 
@@ -139,6 +145,39 @@ class Renderer:
                                                sbuf.ctypes.data, zbuf.ctypes.data if want_z else None),
                   "pwn_trace_screen_centred")
         return (sbuf, zbuf) if want_z else sbuf
+
+    # -- frames in flight (main.c:93-109 with the hand-over to the host overlapped) ----------
+    def frames_config(self, nslots, sbuf=True, zbuf=False, surface_scale=0, pitch_bytes=0):
+        flags = (_lib.PWN_FRAME_SBUF if sbuf else 0) | (_lib.PWN_FRAME_ZBUF if zbuf else 0) | \
+                (_lib.PWN_FRAME_SURFACE if surface_scale else 0)
+        self._chk(lib.pwn_frames_config(self._ctx, int(nslots), flags, int(surface_scale), int(pitch_bytes)), "pwn_frames_config")
+        self._frame_scale = int(surface_scale)
+
+    def submit_frame(self, cam, sec_current, slot):
+        cam = np.ascontiguousarray(cam, np.float32).reshape(16)
+        self._chk(lib.pwn_submit_frame(self._ctx, cam.ctypes.data, float(sec_current), int(slot)), "pwn_submit_frame")
+
+    def frame_ready(self, slot):
+        return bool(self._chk(lib.pwn_frame_ready(self._ctx, int(slot)), "pwn_frame_ready"))
+
+    def wait_frame(self, slot):
+        """Blocks until the slot's frame is on the host.  Returns a dict of numpy VIEWS of the
+        library's pinned buffers (valid until the next submit on that slot) and device times."""
+        fr = _lib.Frame()
+        self._chk(lib.pwn_wait_frame(self._ctx, int(slot), C.byref(fr)), "pwn_wait_frame")
+        out = {"seq": fr.seq, "sec": fr.sec_current, "trace_ms": fr.trace_ms, "blur_ms": fr.blur_ms, "sink_ms": fr.sink_ms}
+        n = self.w * self.h
+
+        def view(ptr, ctype, count, shape):
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).reshape(shape)
+        if fr.sbuf:
+            out["sbuf"] = view(fr.sbuf, C.c_uint32, n, (self.h, self.w))
+        if fr.zbuf:
+            out["zbuf"] = view(fr.zbuf, C.c_float, n, (self.h, self.w))
+        if fr.surface:
+            pw = fr.surface_pitch_bytes // 4
+            out["surface"] = view(fr.surface, C.c_uint32, pw * self.h * self._frame_scale, (self.h * self._frame_scale, pw))
+        return out
 
     def trace_rows_device(self, cam, sec_current, y0, y1, d_sbuf, d_zbuf, stream=0):
         """Rows [y0,y1) into device frames given as raw device pointers."""

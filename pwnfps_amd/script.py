@@ -59,7 +59,9 @@ class ObjectTable:
         return len(self.slots) - 1
 
     def _live(self, obj, who):
-        if not (0 <= obj < len(self.slots)) or self.slots[obj] is self.FREE:
+        # a handle is a slot level_obj_new once handed out; like the reference's part pointers it
+        # stays usable after obj_free (script.h:24 revives a freed part, script.h:48 frees it again)
+        if not (0 <= obj < len(self.slots)):
             raise ValueError("%s: %r is not an object" % (who, obj))
 
     def obj_set(self, obj, typ, r, refl, x, y, z, cb, cg, cr):

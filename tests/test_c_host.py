@@ -33,8 +33,10 @@ def test_host_builds_with_gcc_only_and_links_the_abi(host_bin):
 def test_host_usage_and_bad_option(host_bin):
     p = subprocess.run([host_bin], capture_output=True)
     assert p.returncode == 2 and b"usage" in p.stderr
+    p = subprocess.run([host_bin, level_path("pwnfps_level"), "-Q", "1"], capture_output=True)
+    assert p.returncode == 2 and b"unknown option" in p.stderr
     p = subprocess.run([host_bin, level_path("pwnfps_level"), "-q", "1"], capture_output=True)
-    assert p.returncode == 2
+    assert p.returncode == 2 and b"-q takes 2.." in p.stderr
 
 
 @pytest.mark.gpu
@@ -61,6 +63,25 @@ def test_host_frame_is_the_reference_frame(host_bin, cases, tmp_path, oracle_lib
     assert raw.startswith(b"P6\n960 600\n255\n")
     rgb = np.frombuffer(raw[len(b"P6\n960 600\n255\n"):], np.uint8).reshape(600, 960, 3)
     assert (rgb[..., 0] == ((up >> 16) & 255)).all() and (rgb[..., 2] == (up & 255)).all()
+
+
+@pytest.mark.gpu
+def test_host_frames_in_flight_present_the_same_frames(host_bin):
+    """-q 3: the loop of main.c:93-140 with three frames in flight (pinned sbuf + surface through
+    pwn_submit_frame / pwn_wait_frame) shows, frame by frame, what the blocking loop shows:
+    scripted spheres (changed between submits without waiting), a turning camera, x2 upscale."""
+    args = [host_bin, level_path("pwnfps_level"), "-g", os.path.join(ROOT, "pwnfps_amd", "data", "game_objects.txt"),
+            "-w", "640", "-h", "360", "-x", "2", "-n", "12", "-t", "0.05", "-a", "0.07", "-v", "1"]
+    a = subprocess.run(args, capture_output=True, timeout=300)
+    b = subprocess.run(args + ["-q", "3"], capture_output=True, timeout=300)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr.decode(), b.stderr.decode())
+    fa = re.findall(r"frame (\d+) sec (\S+) fnv64 ([0-9a-f]{16})", a.stdout.decode())
+    fb = re.findall(r"frame (\d+) sec (\S+) fnv64 ([0-9a-f]{16})", b.stdout.decode())
+    assert len(fa) == 12 and fa == fb
+    assert len({h for _, _, h in fa}) == 12                  # the frames do differ from each other
+    sa = re.search(r"surface fnv64 ([0-9a-f]{16})", a.stdout.decode()).group(1)
+    sb = re.search(r"surface fnv64 ([0-9a-f]{16})", b.stdout.decode()).group(1)
+    assert sa == sb
 
 
 @pytest.mark.gpu

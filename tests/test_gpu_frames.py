@@ -1,0 +1,105 @@
+"""Frames in flight (pwn_frames_config / pwn_submit_frame / pwn_wait_frame): the loop of
+main.c:93-109 with the hand-over to the host overlapped.  Every delivered frame -- colour,
+depth and upscaled surface -- is the oracle's frame for the inputs of ITS submit, although
+spheres, camera and sec_current change between submits without any wait."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, level_path, load_spheres
+
+pytestmark = pytest.mark.gpu
+
+W, H = 640, 352
+
+
+def _scene(f, base):
+    """frame f: a turned camera, moved and recoloured spheres, one sphere fewer every third frame"""
+    import pwnfps_amd
+    sph = base.copy()
+    sph["x"] += np.float32(0.11 * f)
+    sph["z"] -= np.float32(0.07 * f)
+    sph["cb"] = np.float32(0.2 + 0.1 * (f % 5))
+    if f % 3 == 2:
+        sph = sph[:-1 - (f % 4)]
+    cam = pwnfps_amd.spawn_camera((9, 4), ang_y=0.13 * f, ang_x=0.02 * f)
+    return cam, 0.05 * f, sph
+
+
+@pytest.mark.parametrize("slots", [2, 3, 4])
+def test_frames_in_flight_are_the_oracles_frames(slots, oracle_lib):
+    import pwnfps_amd
+    from oracle import Oracle
+    base = load_spheres("t0")
+    r = pwnfps_amd.Renderer(W, H)
+    r.level_load(level_path("pwnfps_level"))
+    scale, pitch = 2, (W * 2 + 8) * 4                      # a padded surface pitch
+    r.frames_config(slots, sbuf=True, zbuf=True, surface_scale=scale, pitch_bytes=pitch)
+    O = Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    nframes = 9
+    got = {}
+    for f in range(nframes + slots - 1):
+        if f >= slots - 1:
+            k = f - (slots - 1)
+            fr = r.wait_frame(k % slots)
+            assert fr["seq"] == k + 1
+            got[k] = (fr["sbuf"].copy(), fr["zbuf"].copy(), fr["surface"].copy(), fr["sec"])
+        if f < nframes:
+            cam, sec, sph = _scene(f, base)
+            r.set_objects(sph)                              # level_prepare_render, main.c:95: no wait
+            if f >= 1:
+                with pytest.raises(pwnfps_amd.PwnError) as e:
+                    r.submit_frame(cam, sec, (f - 1) % slots)   # the previous frame's slot is still in flight
+                assert e.value.code == -8                       # PWN_EBUSY
+            r.submit_frame(cam, sec, f % slots)
+    # depth is kept at pixels whose primary ray runs out of steps (trace.h:677); none does here,
+    # so every plane is fully defined by its own frame
+    for k in range(nframes):
+        cam, sec, sph = _scene(k, base)
+        O.set_spheres(sph)
+        ob, oz = O.render(W, H, cam, sec=sec, blur=1)
+        sb, zb, surf, fsec = got[k]
+        assert fsec == np.float32(sec)
+        assert (sb == ob).all(), "frame %d colour" % k
+        assert (zb.view(np.uint32) == oz.view(np.uint32)).all(), "frame %d depth" % k
+        # with a padded pitch the reference packs the rows its own way (screen.h:132,138-139);
+        # bytes it never writes read 0 here
+        up = O.upscale(ob, scale, pitch)
+        assert surf.shape == up.shape and (surf == up).all(), "frame %d surface" % k
+    # the blocking call can be mixed in and the slots re-configured once nothing is in flight
+    cam, sec, sph = _scene(1, base)
+    r.set_objects(sph)
+    sb, zb = r.trace_screen_centred(cam, sec)
+    assert (sb == got[1][0]).all()
+    r.frames_config(2, sbuf=True)
+    r.submit_frame(cam, sec, 0)
+    with pytest.raises(pwnfps_amd.PwnError):
+        r.frames_config(3, sbuf=True)                       # a frame is in flight
+    fr = r.wait_frame(0)
+    assert (fr["sbuf"] == got[1][0]).all() and "zbuf" not in fr and "surface" not in fr
+    r.frames_config(0)
+    with pytest.raises(pwnfps_amd.PwnError):
+        r.submit_frame(cam, sec, 0)
+    r.close()
+
+
+def test_frames_without_blur_and_at_4k(oracle_lib, cases):
+    """POSTPROC_BLUR off (the trace writes the slot's plane directly) and the BASELINE frame
+    size against the compiled reference's golden hashes, three frames in flight."""
+    import pwnfps_amd
+    want = [c for c in cases if c["name"] == "level_spawn_3840x2160"][0]
+    r = pwnfps_amd.Renderer(3840, 2160)
+    r.level_load(level_path("pwnfps_level"))
+    r.set_objects(load_spheres("t0"))
+    cam = np.array(want["cam"], np.float32)
+    for blur, key in ((0, "pre"), (1, "post")):
+        r.set_blur_passes(blur)
+        r.frames_config(3, sbuf=True)
+        for f in range(3):
+            r.set_objects(load_spheres("t0"))
+            r.submit_frame(cam, 0.0, f)
+        for f in range(3):
+            assert oracle_lib.fnv64(r.wait_frame(f)["sbuf"]) == want[key]
+    r.close()

@@ -78,11 +78,18 @@ def test_object_calls_follow_the_host_table():
     assert e.value.code == -1 and "never set" in str(e.value)
     r.obj_free(h)
     r.level_prepare_render()
-    for bad in (-1, 99999, h):
+    for bad in (-1, 99999):
         with pytest.raises(pwnfps_amd.PwnError):
             r.obj_set(bad, "sphere", 1, 1, 1, 1, 1, 1, 1, 1)
         with pytest.raises(pwnfps_amd.PwnError):
             r.obj_free(bad)
+    # a freed handle stays usable like the reference's part pointer: obj_set revives it
+    # (script.h:24), obj_free on it changes nothing (script.h:48)
+    r.obj_free(h); T_h = T.obj_new(); T.obj_free(T_h); T.obj_free(T_h)
+    assert T_h == h and (bits(r.get_objects()) == bits(T.live())).all()
+    r.obj_set(h, "sphere", 0.2, 0.5, 3, 0.5, 3, 1, 1, 1); T.obj_set(h, "sphere", 0.2, 0.5, 3, 0.5, 3, 1, 1, 1)
+    assert (bits(r.get_objects()) == bits(T.live())).all()
+    r.obj_free(h); T.obj_free(h)
     with pytest.raises(ValueError, match="invalid typ"):
         r.obj_set(live[0], "cube", 1, 1, 1, 1, 1, 1, 1, 1)
     # set_objects replaces the table

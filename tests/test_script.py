@@ -58,8 +58,11 @@ def test_object_table_slot_reuse_and_errors():
     with pytest.raises(ValueError):
         T.obj_free(17)
     T.obj_free(c)
-    with pytest.raises(ValueError):
-        T.obj_set(c, "sphere", 1, 1, 1, 1, 1, 1, 1, 1)
+    T.obj_free(c)                                            # script.h:48: freeing twice changes nothing
+    assert len(T.live()) == 2
+    T.obj_set(c, "sphere", 0.9, 1, 1, 1, 1, 1, 1, 1)         # script.h:24: obj_set revives a freed part
+    assert [float(r) for r in T.live()["r"]] == [np.float32(0.1), np.float32(0.7), np.float32(0.9)]
+    T.obj_free(c)
     # doubles are narrowed on store (script.h:22-32)
     T.obj_set(a, "sphere", 0.1, 0.2, 9.5 + 0.3, 0.3, 5.5 - 0.3, 0.7, 0.7, 1.0)
     assert T.live()["x"][0] == np.float32(9.5 + 0.3) and T.live()["r"][0] == np.float32(0.1)
