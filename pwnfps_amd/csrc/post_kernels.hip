@@ -234,6 +234,26 @@ extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int
 	return hipGetLastError();
 }
 
+// ---------------------------------------------------------- table upload ----
+// The per-frame table upload (level_prepare_render, main.c:95: ~18 KB) as a kernel that reads
+// the pinned staging buffer over PCIe itself.  A hipMemcpyAsync would queue on a DMA engine
+// behind the 33 MB copy of the previous frame to the host, and the next trace launch waits
+// for its tables: measured 0.83 ms per 4K frame with frames in flight against 0.60 with this.
+__global__ void __launch_bounds__(256)
+pwn_upload_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int n16)
+{
+	for(int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" hipError_t pwn_launch_upload(const void *h_pinned_src, void *d_dst, size_t bytes, hipStream_t stream)
+{
+	const int n16 = (int)((bytes + 15) / 16);
+	if(n16 <= 0) return hipSuccess;
+	hipLaunchKernelGGL(pwn_upload_kernel, dim3((n16 + 255) / 256 > 8 ? 8 : (n16 + 255) / 256), dim3(256), 0, stream,
+		(const uint4 *)h_pinned_src, (uint4 *)d_dst, n16);
+	return hipGetLastError();
+}
+
 // --------------------------------------------------------------- probes ----
 // Device-side known-answer access to the arithmetic primitives (pwnhip.h
 // PWN_PROBE_*).  tabs = the rcp+rsqrt part of the blob (2 x 2048 u16).

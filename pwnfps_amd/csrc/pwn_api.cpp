@@ -250,7 +250,8 @@ static int pack_blob(pwn_ctx *c)
 	memcpy(c->h_stage[st], b + from, total - from);
 	// launches still reading that copy (two uploads ago) finish first -- a wait between streams
 	if(c->tables_in_use[nb]) HIPCHK(c, hipStreamWaitEvent(c->up_stream, c->ev_tables[nb], 0));
-	HIPCHK(c, hipMemcpyAsync(c->d_blob[nb] + from, c->h_stage[st], total - from, hipMemcpyHostToDevice, c->up_stream));
+	// (a kernel that reads the pinned buffer, not a DMA copy: see pwn_upload_kernel; total and from are multiples of 16)
+	HIPCHK(c, pwn_launch_upload(c->h_stage[st], c->d_blob[nb] + from, total - from, c->up_stream));
 	HIPCHK(c, hipEventRecord(c->ev_stage[st], c->up_stream));
 	HIPCHK(c, hipEventRecord(c->ev_upload[nb], c->up_stream));
 	c->stage_used[st] = true;

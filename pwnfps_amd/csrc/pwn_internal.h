@@ -28,6 +28,7 @@ extern "C" int pwn_trace_tile_w(void);
 extern "C" unsigned pwn_trace_lds_extra(void);
 extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
+extern "C" hipError_t pwn_launch_upload(const void *h_pinned_src, void *d_dst, size_t bytes, hipStream_t stream);
 extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
 
 // LDS budget for the table blob: leave room so that at least two workgroups

@@ -49,7 +49,7 @@ def test_frames_in_flight_are_the_oracles_frames(slots, oracle_lib):
         if f < nframes:
             cam, sec, sph = _scene(f, base)
             r.set_objects(sph)                              # level_prepare_render, main.c:95: no wait
-            if f >= 1:
+            if f >= 1 and slots >= 3:
                 with pytest.raises(pwnfps_amd.PwnError) as e:
                     r.submit_frame(cam, sec, (f - 1) % slots)   # the previous frame's slot is still in flight
                 assert e.value.code == -8                       # PWN_EBUSY
