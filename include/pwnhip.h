@@ -61,6 +61,9 @@ typedef struct pwn_stats
 	   path with at least one lane.  0 sphere list of the cell, 1 room body, 2 fog,
 	   3 two-level transition (" / # / &), 4 ramp, 5 portal, 6 solid, 7 sphere hit maths */
 	uint64_t wave_paths[8];
+	/* PWN_SCHED_REFILL: passes of a wave64 through the shade / new-pixel / set-up phase, and the
+	   lanes that had a ray to shade in them (phase_lanes / (64 * phase_passes) = their lane use) */
+	uint64_t phase_passes, phase_lanes;
 } pwn_stats;
 
 /* options for pwn_set_option */
@@ -70,6 +73,10 @@ typedef struct pwn_stats
 #define PWN_SCHED_UNITS     0  /*   a wave traces 16x4-pixel units, all 64 lanes in step (ray set-up, walk, shading) */
 #define PWN_SCHED_REFILL    1  /*   lanes whose ray ended are refilled by ballot + prefix rank while the rest walk on */
 #define PWN_SCHED_DEFAULT   PWN_SCHED_UNITS
+#define PWN_OPT_REFILL_LIMIT 4 /* PWN_SCHED_REFILL: lane-steps (1..64000) the ended rays of a batch may wait, in sum, for
+                                  the batch's other rays before they are shaded and replaced; rays still walking
+                                  then walk on beside the next batches */
+#define PWN_REFILL_LIMIT_DEFAULT 256
 
 /*
  * Replaces the buffer/global set-up of main.c:26-34,395-400 (rwidth, rheight,

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("PWNHIP_LIB") or os.path.join(_HERE, "libpwnhip.so")
 
 PWN_OK, PWN_EINVAL, PWN_ENODEV, PWN_ENOMEM, PWN_EIO, PWN_EHIP, PWN_ENOLEVEL, PWN_ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
 PWN_EBUSY, PWN_ENOTSUP = -8, -9
-PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER = 1, 2, 3
+PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER, PWN_OPT_REFILL_LIMIT = 1, 2, 3, 4
 PWN_SCHED_UNITS, PWN_SCHED_REFILL = 0, 1
 PWN_MAX_SLOTS = 4
 PWN_FRAME_SBUF, PWN_FRAME_ZBUF, PWN_FRAME_SURFACE = 1, 2, 4
@@ -32,7 +32,7 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("portals", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("exhausted", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("total_ms", C.c_float), ("reserved_", C.c_float),
-                ("wave_paths", C.c_uint64 * 8)]
+                ("wave_paths", C.c_uint64 * 8), ("phase_passes", C.c_uint64), ("phase_lanes", C.c_uint64)]
 
 
 class Frame(C.Structure):

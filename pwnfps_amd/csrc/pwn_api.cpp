@@ -56,7 +56,10 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	pwn_ctx *c = new(std::nothrow) pwn_ctx();
 	if(c == NULL) return PWN_ENOMEM;
 	c->device = device; c->w = width; c->h = height;
-	c->blur_passes = 1; c->counters_on = 0; c->scheduler = PWN_SCHED_DEFAULT; c->have_level = false;
+	c->blur_passes = 1; c->counters_on = 0; c->scheduler = PWN_SCHED_DEFAULT; c->refill_limit = PWN_REFILL_LIMIT_DEFAULT; c->have_level = false;
+	// experiments and the test suite pick the trace scheduler for every context of a process
+	if(const char *e = getenv("PWN_SCHEDULER")) c->scheduler = (strcmp(e, "refill") == 0 || strcmp(e, "1") == 0) ? PWN_SCHED_REFILL : PWN_SCHED_UNITS;
+	if(const char *e = getenv("PWN_REFILL_LIMIT")) { int v = atoi(e); if(v >= 1 && v <= 64000) c->refill_limit = v; }
 	c->blob_cur = 0; c->blob_dirty = true; c->off_sph = 0; c->stage_next = 0; c->up_stream = NULL;
 	for(int i = 0; i < PWN_NBLOB; i++)
 	{
@@ -171,6 +174,7 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 		case PWN_OPT_BLUR_PASSES: if(value < 0 || value > 16) return PWN_EINVAL; c->blur_passes = value; return PWN_OK;
 		case PWN_OPT_COUNTERS: c->counters_on = value ? 1 : 0; return PWN_OK;
 		case PWN_OPT_SCHEDULER: if(value < 0 || value > PWN_SCHED_REFILL) return PWN_EINVAL; c->scheduler = value; return PWN_OK;
+		case PWN_OPT_REFILL_LIMIT: if(value < 1 || value > 64000) return PWN_EINVAL; c->refill_limit = value; return PWN_OK;
 	}
 	return PWN_EINVAL;
 }
@@ -514,13 +518,16 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	if(getenv("PWN_DBG_FORCE_HASW")) P.has_w = 1;
 	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), stream));
 	// persistent grid: as many workgroups as are resident at once, each striding over tiles
-	const size_t lds_bytes = ((P.blob_bytes + 15u) & ~15u) + pwn_trace_lds_extra();
+	const bool refill = c->scheduler == PWN_SCHED_REFILL;
+	const size_t lds_bytes = ((P.blob_bytes + 15u) & ~15u) + (refill ? pwn_trace_refill_lds_extra(P.has_w != 0) : pwn_trace_lds_extra());
 	// resident workgroups per CU depend on (LDS bytes, kernel variant) only: ask once per combination
 	P.scheduler = c->scheduler;
-	const int variant = (c->scheduler == PWN_SCHED_REFILL ? 4 : 0) | (c->counters_on ? 2 : 0) | (P.has_w ? 1 : 0);
+	P.refill_limit = c->refill_limit;
+	const int variant = (refill ? 4 : 0) | (c->counters_on ? 2 : 0) | (P.has_w ? 1 : 0);
 	if(c->occ_lds[variant] != lds_bytes)
 	{
-		c->occ_blocks[variant] = pwn_trace_blocks_per_cu(lds_bytes, c->counters_on != 0, P.has_w != 0);
+		c->occ_blocks[variant] = refill ? pwn_trace_refill_blocks_per_cu(lds_bytes, c->counters_on != 0, P.has_w != 0)
+		                                : pwn_trace_blocks_per_cu(lds_bytes, c->counters_on != 0, P.has_w != 0);
 		c->occ_lds[variant] = lds_bytes;
 	}
 	int per_cu = c->occ_blocks[variant];
@@ -536,7 +543,8 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	if(const char *cap = getenv("PWN_DBG_BLOCKS_PER_CU")) { if(atoi(cap) > 0) per_cu = atoi(cap); }   // experiments
 	int grid = c->num_cus * per_cu;
 	if(grid > P.tiles_total) grid = P.tiles_total;
-	HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
+	if(refill) HIPCHK(c, pwn_launch_trace_refill(&P, grid, lds_bytes, c->counters_on != 0, stream));
+	else HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	c->ticket_set++;                     // only a launch that went out has cleared the other set
 	HIPCHK(c, hipEventRecord(c->ev_tables[cur], stream));
 	c->tables_in_use[cur] = true;
@@ -765,6 +773,7 @@ extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 		c->stats.rays = v[0]; c->stats.steps = v[1]; c->stats.portals = v[2];
 		c->stats.sphere_tests = v[3]; c->stats.exhausted = v[4]; c->stats.wave_steps = v[5];
 		for(int i = 0; i < 8; i++) c->stats.wave_paths[i] = v[6 + i];
+		c->stats.phase_passes = v[14]; c->stats.phase_lanes = v[15];
 	}
 	*out = c->stats;
 	return PWN_OK;

@@ -22,6 +22,9 @@ struct pwn_blur_params
 };
 
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
+extern "C" hipError_t pwn_launch_trace_refill(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
+extern "C" unsigned pwn_trace_refill_lds_extra(bool has_w);
+extern "C" int pwn_trace_refill_blocks_per_cu(size_t lds_bytes, bool count, bool has_w);
 extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w);
 extern "C" int pwn_trace_tile_h(void);
 extern "C" int pwn_trace_tile_w(void);
@@ -55,7 +58,7 @@ struct pwn_ctx
 {
 	int device, w, h;
 	int num_cus;
-	int blur_passes, counters_on, scheduler;
+	int blur_passes, counters_on, scheduler, refill_limit;
 	bool have_level;
 
 	uint8_t cells[4096];

@@ -93,6 +93,7 @@ struct pwn_trace_params
 	unsigned long long *counters;             // 14 x u64 (pwn_stats counters + wave_paths) or NULL
 	int has_w;                                // camera has w components (general 4-lane path)
 	int scheduler;                            // PWN_SCHED_* (pwnhip.h)
+	int refill_limit;                         // PWN_SCHED_REFILL: walk on while more lanes than this walk (trace_refill.hip)
 	// work queues of the wave scheduler (trace_kernel.hip): PWN_QUEUES counters, one per 128 B,
 	// for this launch; the set of the next launch, which this one clears
 	uint32_t *tickets, *tickets_next;

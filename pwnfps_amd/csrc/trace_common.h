@@ -1,0 +1,94 @@
+// trace_common.h -- types and helpers shared by the two trace kernels
+// (trace_kernel.hip: a wave64 traces 16x4-pixel units in step; trace_refill.hip: lanes are
+// refilled with new rays by ballot + prefix rank while the others walk on).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_math.h"
+#include "tables.h"
+
+#define EPS 0.0000000000001f      // defs.h:1
+#define REFLECT_BLUR_F 0.03f      // defs.h:5
+#define REFLECT_MAX 2             // defs.h:7
+enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
+
+// workgroup = PWN_BLOCK threads sharing one copy of the blob in LDS; a wave's unit of work is
+// 16 x 4 pixels (half the width of the 32-pixel tile of screen.h:6-7, one DPP row per pixel row)
+#ifndef PWN_BLOCK
+#define PWN_BLOCK 256
+#endif
+#define TILE_W 16
+#define TILE_H 4
+
+// min waves per SIMD the register allocator must leave room for (Makefile MINW)
+#ifndef PWN_MIN_WAVES
+#define PWN_MIN_WAVES 3
+#endif
+
+struct Lds
+{
+	const uint32_t *cellinfo;
+	const uint16_t *rcp, *rsq;
+	const uint32_t *pmap;
+	const uint16_t *binidx;
+	const float *sph;
+};
+
+// util.h:151-158 (per-axis clamp to 0) -> the packed cell word.  The table has
+// 65 rows / columns; index 64 repeats index 0 (tables.h), so the clamp is a min.
+__device__ __forceinline__ uint32_t cellword_at(const Lds &L, int cx, int cz)
+{
+	uint32_t ux = min((uint32_t)cx, 64u), uz = min((uint32_t)cz, 64u);
+	return L.cellinfo[uz * PWN_GRID_PITCH + ux];
+}
+
+// HAS_W = false: the camera rows x,y,z carry w = 0 and the position w = 1
+// (mat4_iden + rotations, main.c:61-64).  Then every ray has w = +-0 and every
+// position w = 1, sphere-relative vectors have w = 0, and each 4-lane dot
+// (x+z)+(y+w) of util.h:18-30 equals (x+z)+y bit for bit (a product of zeros
+// adds +0; the only sign-of-zero effect is on a dot that is itself +-0, which
+// the code only compares with 0 or squares).  The w lanes are dropped.
+template<bool HAS_W> struct Vec { float x, y, z, w; };
+
+template<bool W> __device__ __forceinline__ float dot3(const Vec<W> &a, const Vec<W> &b)
+{
+	if constexpr(W) return (a.x * b.x + a.z * b.z) + (a.y * b.y + a.w * b.w);
+	else return (a.x * b.x + a.z * b.z) + a.y * b.y;
+}
+template<bool W> __device__ __forceinline__ Vec<W> vscale(float s, const Vec<W> &a)
+{
+	Vec<W> r; r.x = s * a.x; r.y = s * a.y; r.z = s * a.z;
+	if constexpr(W) r.w = s * a.w; else r.w = 0.0f;
+	return r;
+}
+template<bool W> __device__ __forceinline__ Vec<W> vadd(const Vec<W> &a, const Vec<W> &b)
+{
+	Vec<W> r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z;
+	if constexpr(W) r.w = a.w + b.w; else r.w = 0.0f;
+	return r;
+}
+template<bool W> __device__ __forceinline__ Vec<W> vsub(const Vec<W> &a, const Vec<W> &b)
+{
+	Vec<W> r; r.x = a.x - b.x; r.y = a.y - b.y; r.z = a.z - b.z;
+	if constexpr(W) r.w = a.w - b.w; else r.w = 0.0f;
+	return r;
+}
+// util.h:32-46
+template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const uint16_t *rsq, const Vec<W> &a)
+{
+	return vscale<W>(tab_rsqrt(rsq, dot3<W>(a, a)), a);
+}
+
+// lane j of each 16-lane DPP row reads lane j-1; lane 0 reads 0.0f
+__device__ __forceinline__ float dpp_row_shr1(float v)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xf, 0xf, true));
+}
+
+enum { EV_NONE = 0, EV_WALL, EV_SPHERE, EV_EXHAUSTED };
+// BASE_ROOM_Y: the ray left a room through its floor / ceiling (trace.h:323-329,373-379);
+// the face and the colour follow from the ray's y sign after the walk
+enum { BASE_CEIL = 0, BASE_FLOOR, BASE_WALL, BASE_MAGENTA, BASE_ROOM_Y };
+
+struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps, wp[8], apasses, apass_lanes; };
+// one count per wave64 that enters a code path with at least one lane (pwn_stats.wave_paths)
+#define WAVE_PATH(k) do { if(COUNT && (__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt.wp[k]++; } while(0)

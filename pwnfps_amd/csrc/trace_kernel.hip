@@ -27,95 +27,8 @@
 //   - no device function calls (dev_math.h) and no SLP packing (Makefile).
 #include <hip/hip_runtime.h>
 #include <mutex>
-#include "dev_math.h"
-#include "tables.h"
+#include "trace_common.h"
 
-#define EPS 0.0000000000001f      // defs.h:1
-#define REFLECT_BLUR_F 0.03f      // defs.h:5
-#define REFLECT_MAX 2             // defs.h:7
-enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
-
-// workgroup = PWN_BLOCK threads sharing one copy of the blob in LDS; a wave's unit of work is
-// 16 x 4 pixels (half the width of the 32-pixel tile of screen.h:6-7, one DPP row per pixel row)
-#ifndef PWN_BLOCK
-#define PWN_BLOCK 256
-#endif
-#define TILE_W 16
-#define TILE_H 4
-
-// min waves per SIMD the register allocator must leave room for (Makefile MINW)
-#ifndef PWN_MIN_WAVES
-#define PWN_MIN_WAVES 3
-#endif
-
-struct Lds
-{
-	const uint32_t *cellinfo;
-	const uint16_t *rcp, *rsq;
-	const uint32_t *pmap;
-	const uint16_t *binidx;
-	const float *sph;
-};
-
-// util.h:151-158 (per-axis clamp to 0) -> the packed cell word.  The table has
-// 65 rows / columns; index 64 repeats index 0 (tables.h), so the clamp is a min.
-__device__ __forceinline__ uint32_t cellword_at(const Lds &L, int cx, int cz)
-{
-	uint32_t ux = min((uint32_t)cx, 64u), uz = min((uint32_t)cz, 64u);
-	return L.cellinfo[uz * PWN_GRID_PITCH + ux];
-}
-
-// HAS_W = false: the camera rows x,y,z carry w = 0 and the position w = 1
-// (mat4_iden + rotations, main.c:61-64).  Then every ray has w = +-0 and every
-// position w = 1, sphere-relative vectors have w = 0, and each 4-lane dot
-// (x+z)+(y+w) of util.h:18-30 equals (x+z)+y bit for bit (a product of zeros
-// adds +0; the only sign-of-zero effect is on a dot that is itself +-0, which
-// the code only compares with 0 or squares).  The w lanes are dropped.
-template<bool HAS_W> struct Vec { float x, y, z, w; };
-
-template<bool W> __device__ __forceinline__ float dot3(const Vec<W> &a, const Vec<W> &b)
-{
-	if constexpr(W) return (a.x * b.x + a.z * b.z) + (a.y * b.y + a.w * b.w);
-	else return (a.x * b.x + a.z * b.z) + a.y * b.y;
-}
-template<bool W> __device__ __forceinline__ Vec<W> vscale(float s, const Vec<W> &a)
-{
-	Vec<W> r; r.x = s * a.x; r.y = s * a.y; r.z = s * a.z;
-	if constexpr(W) r.w = s * a.w; else r.w = 0.0f;
-	return r;
-}
-template<bool W> __device__ __forceinline__ Vec<W> vadd(const Vec<W> &a, const Vec<W> &b)
-{
-	Vec<W> r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z;
-	if constexpr(W) r.w = a.w + b.w; else r.w = 0.0f;
-	return r;
-}
-template<bool W> __device__ __forceinline__ Vec<W> vsub(const Vec<W> &a, const Vec<W> &b)
-{
-	Vec<W> r; r.x = a.x - b.x; r.y = a.y - b.y; r.z = a.z - b.z;
-	if constexpr(W) r.w = a.w - b.w; else r.w = 0.0f;
-	return r;
-}
-// util.h:32-46
-template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const uint16_t *rsq, const Vec<W> &a)
-{
-	return vscale<W>(tab_rsqrt(rsq, dot3<W>(a, a)), a);
-}
-
-// lane j of each 16-lane DPP row reads lane j-1; lane 0 reads 0.0f
-__device__ __forceinline__ float dpp_row_shr1(float v)
-{
-	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111 /* row_shr:1 */, 0xf, 0xf, true));
-}
-
-enum { EV_NONE = 0, EV_WALL, EV_SPHERE, EV_EXHAUSTED };
-// BASE_ROOM_Y: the ray left a room through its floor / ceiling (trace.h:323-329,373-379);
-// the face and the colour follow from the ray's y sign after the walk
-enum { BASE_CEIL = 0, BASE_FLOOR, BASE_WALL, BASE_MAGENTA, BASE_ROOM_Y };
-
-struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps, wp[8]; };
-// one count per wave64 that enters a code path with at least one lane (pwn_stats.wave_paths)
-#define WAVE_PATH(k) do { if(COUNT && (__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt.wp[k]++; } while(0)
 
 // One pixel = trace_ray(0, ...) of screen.h:22-24 with the recursion unrolled.
 template<bool COUNT, bool HAS_W>
@@ -212,300 +125,13 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		int ldir = FYN;
 		int ev = EV_NONE, base = BASE_ROOM_Y;
 
-#define AUX_HIT() (cdist > aux_dist)
-
-		// ------------------------------------------------ trace.h:250-675
-		// One cell per iteration, one loop exit at the bottom.  The cell class is a
-		// bit test on the LDS word (tables.h).  The room body - by far the most
-		// frequent - is written with selects; lanes whose ray ended in it carry on
-		// through the (then meaningless) cell advance and leave at the bottom.
+		// ------------------------------------------------ trace.h:250-675 (trace_walk.inc)
 		int maxsteps = 1000;
 #pragma unroll 1
 		do
 		{
-			if(COUNT)
-			{
-				cnt.steps++;
-				// once per wave and iteration: the lowest active lane
-				if((__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt.wsteps++;
-			}
-
-			// trace.h:252-296: spheres binned to this cell
-			if((int)cw < 0)
-			{
-				WAVE_PATH(0);
-				const uint16_t *lp = L.binidx + ((cw >> 16) & 0x7fffu);
-				for(uint32_t si = *lp; si != PWN_LIST_END; si = *++lp)
-				{
-					const float4 *sp = (const float4 *)(L.sph + 8 * si);
-					const float4 s0 = sp[0];         // r, refl, x, y
-					const float4 s1 = sp[1];         // z, cb, cg, cr
-					if(COUNT) cnt.tests++;
-					V rel;
-					rel.x = s0.z - pos.x; rel.y = s0.w - pos.y; rel.z = s1.x - pos.z;
-					if constexpr(HAS_W) rel.w = 1.0f - pos.w; else rel.w = 0.0f;
-					float rad2 = s0.x * s0.x;
-					float d2 = dot3<HAS_W>(rel, rel);
-					float dt = dot3<HAS_W>(rel, ray);
-					if(dt > 0.0f)
-					{
-						float calc = d2 - dt * dt;
-						if(calc < rad2)
-						{
-							WAVE_PATH(7);
-							float sd2 = 1.0f - calc / rad2;
-							float sdist = sqrtf(d2) - sqrtf(sd2);
-							if(sdist + cdist < aux_dist)
-							{
-								aux_dist = sdist + cdist;
-								if(aux_dist == -1.0f) aux_dist = __builtin_inff();
-								aux_pos = vadd<HAS_W>(pos, vscale<HAS_W>(sdist, ray));
-								V d;
-								d.x = aux_pos.x - s0.z; d.y = aux_pos.y - s0.w; d.z = aux_pos.z - s1.x;
-								if constexpr(HAS_W) d.w = aux_pos.w - 1.0f; else d.w = 0.0f;
-								const V nrm = vnormalise<HAS_W>(L.rsq, d);
-								float diff = -dot3<HAS_W>(ray, nrm);
-								if(diff < 0.0f) diff = 0.0f;
-								const float amb = 0.2f;
-								aux_diff = amb + (1.0f - amb) * diff;
-								aux_idx = si;
-							}
-						}
-					}
-				}
-			}
-
-			if(cw & PWN_C_ROOM)
-			{
-				WAVE_PATH(1);
-				// trace.h:302-352 (1-high) and 354-441 (2-high) share this body
-				const bool room2 = (cw & PWN_C_ROOM2) != 0u;
-				// 2-high: the ceiling is one unit further when looking up (trace.h:357,392)
-				// = (room2 && gyp) ? iay : 0: the ROOM2 bit stretched to a mask (one v_bfe_i32)
-				// (a sign-extended 1-bit field; written as an instruction because the compiler turns the
-				// shift form back into two compares and a select on gyp)
-				uint32_t m2;
-				asm("v_bfe_i32 %0, %1, 9, 1" : "=v"(m2) : "v"(cw));
-				static_assert(PWN_C_ROOM2 == (1u << 9), "v_bfe_i32 above reads bit 9");
-				const float up2 = __uint_as_float(iay_up_bits & m2);
-				wy += up2;
-				const float cdist0 = cdist;
-				// trace.h:156-184, then 331-340 on the same comparisons
-				const bool ymin = (wy < wx) && (wy < wz);
-				const bool xlt = wx < wz;
-				const float txz = xlt ? wx : wz;
-				const float t = ymin ? wy : txz;
-				cdist += t;
-				pos = vadd<HAS_W>(vscale<HAS_W>(t, ray), pos);
-				const bool hit = AUX_HIT();
-				if(cw & PWN_C_FOG)
-				{
-					WAVE_PATH(2);
-					// fogbeg = distance at entry (trace.h:309,359); sums in the
-					// reference build's operation order
-					const float fh = (fog + aux_dist) - cdist0;
-					const float fn = (fog - cdist0) + cdist;
-					fog = hit ? (aux_dist > cdist0 ? fh : fog) : fn;
-				}
-				ldir = xlt ? ldx : ldz;                      // a y exit is patched in after the walk
-				ev = hit ? EV_SPHERE : (ymin ? EV_WALL : 0);
-				wy = (wy - txz) - up2;
-				wz = xlt ? wz - txz : iaz;
-				wx = xlt ? iax : wx - txz;
-				cx += xlt ? gx : 0;
-				cz += xlt ? 0 : gz;
-				const uint32_t ncw = cellword_at(L, cx, cz);
-				// trace.h:341-351,393-441 do something only when the height changes: from a "-cell
-				// into a 2-high one, or out of a 2-high cell into anything else ('#'/'&' are the only
-				// 2-high cells, so 2-high -> 2-high neither shifts y nor can be a wall).  One bit:
-				// next is 2-high ? current is " : current is 2-high  (DQ sits two bits above ROOM2)
-				static_assert(PWN_C_DQ == (PWN_C_ROOM2 << 2), "the shift below lines DQ up with ROOM2");
-				const uint32_t height_changes = (((cw >> 2) & ncw) | (cw & ~ncw)) & PWN_C_ROOM2;
-				if(height_changes != 0u && ev == 0)
-				{
-					WAVE_PATH(3);
-					if(!room2)
-					{
-						if(ncw & PWN_C_ROOM2)        // here cw is the "-cell
-						{
-							pos.y += 1.0f;
-							wy -= iay_dn;
-						}
-					}
-					else
-					{
-						if(ncw & PWN_C_DQ)
-						{
-							pos.y -= 1.0f;
-							wy += iay_dn;
-						}
-						if(pos.y < 0.0f || pos.y > 1.0f)
-						{
-							// trace.h:404-413: look through a portal at the cell type behind it
-							int xcell = (int)(ncw & 0xffu);
-							if(ncw & PWN_C_PORTAL)
-							{
-								uint32_t p0 = L.pmap[2 * (xcell - 'A')], p1 = L.pmap[2 * (xcell - 'A') + 1];
-								int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
-								int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
-								if(x1 == cx && z1 == cz) xcell = (int)((p1 >> 16) & 0xff);
-								else if(x2 == cx && z2 == cz) xcell = (int)((p1 >> 8) & 0xff);
-							}
-							if(!(xcell == '#' || xcell == '&'))
-							{
-								if(xcell == '"')
-								{
-									pos.y += 1.0f;
-									wy -= iay_dn;
-								}
-								ev = EV_WALL; base = BASE_WALL;
-							}
-						}
-					}
-				}
-				cw = ncw;
-			}
-			else
-			{
-				if(cw & PWN_C_RAMP)
-				{
-					WAVE_PATH(4);
-					// trace.h:443-505: ramps
-					const float ramp = 0.5f;
-					const bool alongx = (cw & PWN_C_RAMPX) != 0u;
-					const bool minus = (cw & PWN_C_RAMPM) != 0u;
-					float tilt = alongx ? ray.x : ray.z;
-					if(minus) ray.y -= ramp * tilt; else ray.y += ramp * tilt;
-					wy = pos.y;
-					if(ray.y >= 0.0f) wy = 1.0f - wy;
-					wy *= 1.0f / (ray.y < 0.0f ? -ray.y : ray.y);
-					if(AUX_HIT()) ev = EV_SPHERE;
-					else
-					{
-						// trace.h:470 passes gy where trace_ray_through expects gx; the
-						// face is recomputed from the ray signs right after (:474-487)
-						const bool ymin = (wy < wx) && (wy < wz);
-						const bool xlt = wx < wz;
-						const float t = ymin ? wy : (xlt ? wx : wz);
-						cdist += t;
-						pos = vadd<HAS_W>(vscale<HAS_W>(t, ray), pos);
-						if(ymin)
-						{
-							ldir = (ray.y < 0.0f ? FYN : FYP);
-							ev = EV_WALL; base = (ray.y >= 0.0f ? BASE_CEIL : BASE_FLOOR);
-						}
-						else
-						{
-							if(xlt)
-							{
-								ldir = (ray.x < 0.0f ? FXN : FXP);
-								wy -= wx; wz -= wx; wx = iax; cx += gx;
-							}
-							else
-							{
-								ldir = (ray.z < 0.0f ? FZN : FZP);
-								wx -= wz; wy -= wz; wz = iaz; cz += gz;
-							}
-							tilt = alongx ? ray.x : ray.z;
-							if(minus) ray.y += ramp * tilt; else ray.y -= ramp * tilt;
-							wy = pos.y;
-							if(ray.y >= 0.0f) wy = 1.0f - wy;
-							wy *= iay;
-							cw = cellword_at(L, cx, cz);
-						}
-					}
-				}
-				else if(cw & PWN_C_PORTAL)
-				{
-					WAVE_PATH(5);
-					// trace.h:508-650: portal
-					const int pi = (int)(cw & 0xffu) - 'A';
-					uint32_t p0 = L.pmap[2 * pi], p1 = L.pmap[2 * pi + 1];
-					int x1 = (int)(int8_t)(p0 & 0xff), z1 = (int)(int8_t)((p0 >> 8) & 0xff);
-					int x2 = (int)(int8_t)((p0 >> 16) & 0xff), z2 = (int)(int8_t)(p0 >> 24);
-					int rot12 = (int)(p1 & 0xff);
-					const bool at1 = (x1 == cx && z1 == cz), at2 = (x2 == cx && z2 == cz);
-					if(x2 == -1 || !(at1 || at2))
-					{
-						// unpaired letter, or a letter standing in a cell that is not one
-						// of its endpoints (trace.h:514-520,551-559)
-						if(AUX_HIT()) ev = EV_SPHERE;
-						else { ev = EV_WALL; base = (x2 == -1 ? BASE_WALL : BASE_MAGENTA); }
-					}
-					else
-					{
-						int rot;
-						if(at1)
-						{
-							cx = x2; cz = z2;
-							pos.x += (float)(x2 - x1);
-							pos.z += (float)(z2 - z1);
-							rot = (-rot12) & 3;
-						}
-						else
-						{
-							cx = x1; cz = z1;
-							pos.x -= (float)(x2 - x1);
-							pos.z -= (float)(z2 - z1);
-							rot = rot12 & 3;
-						}
-						if(COUNT) cnt.portals++;
-
-						// trace.h:561-622.  The operation order is the one the reference
-						// build executes (its -ffast-math cancels the +-0.5 terms).
-						const float trx = pos.x, trz = pos.z, trvx = ray.x, trvz = ray.z;
-						const int tgx = gx, tgz = gz;
-						const float fcx = (float)cx, fcz = (float)cz;
-						ldir = (ldir - rot) & 3;
-						if(rot & 1)
-						{
-							float t = wx; wx = wz; wz = t;
-							t = iax; iax = iaz; iaz = t;
-							if(rot == 1)
-							{
-								pos.x = (trz + fcx) - fcz;
-								pos.z = (1.0f - trx) + (fcx + fcz);
-								ray.x = trvz; ray.z = -trvx;
-								gx = tgz; gz = -tgx;
-							}
-							else
-							{
-								pos.x = (1.0f - trz) + (fcx + fcz);
-								pos.z = (fcz + trx) - fcx;
-								ray.x = -trvz; ray.z = trvx;
-								gx = -tgz; gz = tgx;
-							}
-						}
-						else if(rot == 2)
-						{
-							pos.x = (fcx + 0.5f) * 2.0f - trx;
-							pos.z = (fcz + 0.5f) * 2.0f - trz;
-							ray.x = -trvx; ray.z = -trvz;
-							gx = -tgx; gz = -tgz;
-						}
-						ldx = (gx < 0 ? FXN : FXP); ldz = (gz < 0 ? FZN : FZP);
-						// trace.h:624-647: step out of the far endpoint
-						if(ldir == FZP) { cz++; pos.z += 1.0f; }
-						else if(ldir == FXN) { cx--; pos.x -= 1.0f; }
-						else if(ldir == FZN) { cz--; pos.z -= 1.0f; }
-						else { cx++; pos.x += 1.0f; }
-						cw = cellword_at(L, cx, cz);
-					}
-				}
-				else
-				{
-					// trace.h:651-664: solid
-					WAVE_PATH(6);
-					if(AUX_HIT()) ev = EV_SPHERE;
-					else { ev = EV_WALL; base = (ldir == FYP ? BASE_CEIL : BASE_WALL); }
-				}
-				// trace.h:668-673 (in the room body the same test sits right after the step)
-				if(ev == 0 && AUX_HIT()) ev = EV_SPHERE;
-			}
-			// trace.h:250,677: out of steps
-			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
+#include "trace_walk.inc"
 		} while(ev == 0);
-#undef AUX_HIT
 		// what the ray ended on is read back from the register: without this the compiler keeps
 		// "ev == EV_EXHAUSTED" as a lane mask that it updates in every iteration of the walk
 		// (5 of ~85 instructions per step)

@@ -64,6 +64,9 @@ class Renderer:
         v = {"units": _lib.PWN_SCHED_UNITS, "refill": _lib.PWN_SCHED_REFILL}.get(which, which)
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_SCHEDULER, int(v)), "pwn_set_option")
 
+    def set_refill_limit(self, n):
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_REFILL_LIMIT, int(n)), "pwn_set_option")
+
     def set_counters(self, on):
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_COUNTERS, 1 if on else 0), "pwn_set_option")
 

@@ -15,9 +15,14 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,seed,force_w", [(120, 3, False), (80, 4, True)])
-def test_fuzz_campaign(n, seed, force_w):
+@pytest.mark.parametrize("n,seed,force_w,sched", [(120, 3, False, "units"), (80, 4, True, "units"),
+                                                   (120, 5, False, "refill"), (80, 6, True, "refill")])
+def test_fuzz_campaign(n, seed, force_w, sched):
+    """both trace schedulers (PWN_OPT_SCHEDULER: 16x4 units in step / ballot + prefix refill)"""
     env = dict(os.environ)
+    env["PWN_SCHEDULER"] = sched
+    if sched == "refill":
+        env["PWN_REFILL_LIMIT"] = str(1 + (seed * 37) % 400)
     if force_w:
         env["PWN_DBG_FORCE_HASW"] = "1"
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), str(n), str(seed)],
