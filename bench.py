@@ -156,7 +156,11 @@ def main():
     ap.add_argument("--blur", type=int, default=1)
     ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step block until this many seconds were timed")
     ap.add_argument("--slots", type=int, default=3, help="frames in flight of the d2h_inclusive leg")
+    ap.add_argument("--resident-slots", type=int, default=3, help="N = 1: frames in flight of the resident loop (1 = strictly one after the other)")
     ap.add_argument("--scheduler", choices=["units", "refill"], default=None, help="trace kernel scheduler (default: the library's)")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="N = 1: HIP events around the trace kernel of every N-th frame of the timed region (an event between two "
+                         "kernels costs ~4 us of pipeline; 1 = every launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="N > 1: finish each frame before starting the next")
     ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
@@ -205,6 +209,7 @@ def main():
     r.set_objects(spheres)
     if args.scheduler:
         r.set_scheduler(args.scheduler)
+    r.set_frame_timing(max(1, args.time_every))
     _, _, spawn = r.get_level()
     cam = pwnfps_amd.spawn_camera(spawn)            # main.c:61-64
     sec = 0.0
@@ -238,7 +243,14 @@ def main():
     # are complete (flush) before the closing barrier.
     pipelined = world > 1 and args.blur <= 1 and not args.no_pipeline
     out = None
-    if pipelined:
+    nres = max(1, min(args.resident_slots, 4))
+    if world == 1:
+        r.set_blur_passes(args.blur)
+        r.frames_config(nres, sbuf=False)
+        for i in range(args.warmup):
+            r.submit_frame(cam, sec, 0)
+            r.wait_frame(0)
+    elif pipelined:
         for _ in range(args.warmup):          # same loop as the timed one: second buffer set, RCCL channels
             fr.submit(cam, sec)
         out = fr.flush()
@@ -252,7 +264,23 @@ def main():
         nonlocal out
         barrier()
         t0 = time.perf_counter()
-        if pipelined:
+        if world == 1:
+            # frames back to back, resident (nothing is handed to the host): submit K frames into
+            # the slot ring; the blur of frame i runs beside the trace of frame i+1
+            for i in range(args.steps):
+                k = i % nres
+                if i >= nres:
+                    f = r.wait_frame(k)
+                    if f["timed"]:
+                        launch_ms.append(f["trace_ms"])
+                r.set_objects(spheres)
+                r.submit_frame(cam, sec, k)
+            for i in range(max(0, args.steps - nres), args.steps):
+                last = r.wait_frame(i % nres)
+                if last["timed"]:
+                    launch_ms.append(last["trace_ms"])
+            out = last
+        elif pipelined:
             for i in range(args.steps):
                 slot["i"] = i
                 r.set_objects(spheres)
@@ -275,7 +303,8 @@ def main():
     block_s, launch_ms = [], []
     while True:
         block_s.append(block())
-        launch_ms.extend(a.elapsed_time(b) for a, b in ev)
+        if world > 1:
+            launch_ms.extend(a.elapsed_time(b) for a, b in ev)
         # all ranks see the same (max-reduced) times, so they stop together
         if sum(block_s) >= args.min_time or len(block_s) >= 500:
             break
@@ -293,7 +322,10 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         try:
             import oracle  # checker only: FNV of the frame vs the compiled reference's golden
-            frame_hash = oracle.fnv64(fr.to_host(out))
+            if world == 1:
+                frame_hash = oracle.fnv64(r.read_plane(out["d_sbuf"]))
+            else:
+                frame_hash = oracle.fnv64(fr.to_host(out))
             with open(os.path.join(GOLD, "frames.json")) as f:
                 cases = json.load(f)["cases"]
             want = [c for c in cases if c["level"] == args.level and (c["w"], c["h"]) == (w, h)
@@ -318,6 +350,15 @@ def main():
                     "sphere_tests_per_ray": round(st["sphere_tests"] / max(st["rays"], 1), 4),
                     # lanes doing a cell step / lanes of the wave64s running the walk loop
                     "walk_active_lane_fraction": round(st["steps"] / max(64 * st["wave_steps"], 1), 4)}
+        # share of the kernel's duration the average wave64 is resident: start / end stamps of every
+        # wave (constant 100 MHz clock) in an UNcounted frame of the timed build
+        r.set_wave_log(True)
+        r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
+        sw = r.stats()
+        r.set_wave_log(False)
+        counters["mean_wave_residency"] = round(sw["wave_time"] / max(sw["waves"] * sw["kernel_span"], 1), 4)
+        counters["trace_kernel_span_ms"] = round(sw["kernel_span"] / 1e5, 4)
+        counters["waves"] = sw["waves"]
         blocking_best = 1e9
         for _ in range(5):
             t1 = time.perf_counter()
@@ -378,7 +419,9 @@ def main():
                        "block_ms_p10_p50_p90": [round(float(np.percentile(block_s, q)) * 1e3, 4) for q in (10, 50, 90)],
                        "first_block_ms": round(block_s[0] * 1e3, 4),
                        "trace_launch_ms_p10_p50_p90": [round(float(np.percentile(launch_ms, q)), 4) for q in (10, 50, 90)],
-                       "launches_timed": len(launch_ms)},
+                       "launches_timed": len(launch_ms),
+                       "launches_timed_are": "every %d-th frame of the timed region (HIP events on the launch stream)" % max(1, args.time_every)
+                       if world == 1 else "every launch"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

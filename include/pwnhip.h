@@ -64,6 +64,10 @@ typedef struct pwn_stats
 	/* PWN_SCHED_REFILL: passes of a wave64 through the shade / new-pixel / set-up phase, and the
 	   lanes that had a ray to shade in them (phase_lanes / (64 * phase_passes) = their lane use) */
 	uint64_t phase_passes, phase_lanes;
+	/* PWN_OPT_WAVE_LOG: residency of the trace kernel's wave64s in the last frame, in ticks of the GPU's
+	   constant 100 MHz clock: sum of the waves' lifetimes, first start to last end, number of waves.
+	   wave_time / (waves * kernel_span) = share of the kernel's duration the average wave was resident */
+	uint64_t wave_time, kernel_span, waves;
 } pwn_stats;
 
 /* options for pwn_set_option */
@@ -77,6 +81,11 @@ typedef struct pwn_stats
                                   the batch's other rays before they are shaded and replaced; rays still walking
                                   then walk on beside the next batches */
 #define PWN_REFILL_LIMIT_DEFAULT 256
+#define PWN_OPT_WAVE_LOG     6 /* 1: every wave64 of the trace kernel stamps its start and end (two clock reads and one
+                                  store per wave); pwn_get_stats then fills wave_time / kernel_span / waves */
+#define PWN_OPT_FRAME_TIMING 5 /* frames in flight: record HIP events around the trace and blur kernels of every N-th
+                                  frame (pwn_frame.timed, .trace_ms ...); 1 = every frame (default), 0 = never.  An event
+                                  between two kernels costs a few microseconds of pipeline */
 
 /*
  * Replaces the buffer/global set-up of main.c:26-34,395-400 (rwidth, rheight,
@@ -153,7 +162,8 @@ int pwn_trace_screen_centred(pwn_ctx *ctx, const float cam[16], float sec_curren
  * travels to the library's pinned host buffers on a copy stream while the
  * kernels of frame i+1 run.
  *   pwn_frames_config  nslots (1..PWN_MAX_SLOTS; 0 releases them) and what a frame
- *                      delivers: PWN_FRAME_SBUF the colour plane (main.c:31),
+ *                      delivers to the host (flags 0: nothing, the frame stays on the
+ *                      device, pwn_frame.d_*): PWN_FRAME_SBUF the colour plane (main.c:31),
  *                      PWN_FRAME_ZBUF the depth plane (main.c:33), PWN_FRAME_SURFACE
  *                      the scale x scale upscaled surface (screen_upscale,
  *                      screen.h:126-149; pitch_bytes 0 = width*scale*4; bytes between
@@ -180,14 +190,19 @@ typedef struct pwn_frame
 	const float *zbuf;           /* fp32 depth, pitch = width     (NULL unless PWN_FRAME_ZBUF)    */
 	const uint32_t *surface;     /* upscaled, surface_pitch_bytes (NULL unless PWN_FRAME_SURFACE) */
 	int surface_pitch_bytes;
+	const void *d_sbuf, *d_zbuf, *d_surface;   /* the same planes on the device (d_surface NULL without the flag) */
 	float sec_current;           /* as submitted */
-	float trace_ms, blur_ms, sink_ms;   /* device time of this frame's kernels */
+	float trace_ms, blur_ms, sink_ms;   /* device time of this frame's kernels, if timed (PWN_OPT_FRAME_TIMING) */
+	int timed;
 	uint64_t seq;                /* 1, 2, ... in submission order */
 } pwn_frame;
 int pwn_frames_config(pwn_ctx *ctx, int nslots, int flags, int scale, int pitch_bytes);
 int pwn_submit_frame(pwn_ctx *ctx, const float cam[16], float sec_current, int slot);
 int pwn_wait_frame(pwn_ctx *ctx, int slot, pwn_frame *out);
 int pwn_frame_ready(pwn_ctx *ctx, int slot);
+/* blocking copy of a device plane of a waited-for frame (pwn_frame.d_*) to host memory, for hosts
+   that keep their frames on the device and look at one now and then */
+int pwn_read_plane(pwn_ctx *ctx, const void *d_src, void *dst, size_t bytes);
 
 /*
  * Strip forms for row tiling across GPUs (one process per GPU; the exchange

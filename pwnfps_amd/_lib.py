@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("PWNHIP_LIB") or os.path.join(_HERE, "libpwnhip.so")
 
 PWN_OK, PWN_EINVAL, PWN_ENODEV, PWN_ENOMEM, PWN_EIO, PWN_EHIP, PWN_ENOLEVEL, PWN_ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
 PWN_EBUSY, PWN_ENOTSUP = -8, -9
-PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER, PWN_OPT_REFILL_LIMIT = 1, 2, 3, 4
+PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER, PWN_OPT_REFILL_LIMIT, PWN_OPT_FRAME_TIMING, PWN_OPT_WAVE_LOG = 1, 2, 3, 4, 5, 6
 PWN_SCHED_UNITS, PWN_SCHED_REFILL = 0, 1
 PWN_MAX_SLOTS = 4
 PWN_FRAME_SBUF, PWN_FRAME_ZBUF, PWN_FRAME_SURFACE = 1, 2, 4
@@ -32,12 +32,14 @@ class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("steps", C.c_uint64), ("portals", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("exhausted", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("total_ms", C.c_float), ("reserved_", C.c_float),
-                ("wave_paths", C.c_uint64 * 8), ("phase_passes", C.c_uint64), ("phase_lanes", C.c_uint64)]
+                ("wave_paths", C.c_uint64 * 8), ("phase_passes", C.c_uint64), ("phase_lanes", C.c_uint64),
+                ("wave_time", C.c_uint64), ("kernel_span", C.c_uint64), ("waves", C.c_uint64)]
 
 
 class Frame(C.Structure):
     _fields_ = [("sbuf", C.c_void_p), ("zbuf", C.c_void_p), ("surface", C.c_void_p), ("surface_pitch_bytes", C.c_int),
-                ("sec_current", C.c_float), ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("sink_ms", C.c_float),
+                ("d_sbuf", C.c_void_p), ("d_zbuf", C.c_void_p), ("d_surface", C.c_void_p),
+                ("sec_current", C.c_float), ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("sink_ms", C.c_float), ("timed", C.c_int),
                 ("seq", C.c_uint64)]
 
 
@@ -66,6 +68,7 @@ ABI = [
     ("pwn_submit_frame", _i, [_vp, _vp, _f, _i]),
     ("pwn_wait_frame", _i, [_vp, _i, C.POINTER(Frame)]),
     ("pwn_frame_ready", _i, [_vp, _i]),
+    ("pwn_read_plane", _i, [_vp, _vp, _vp, C.c_size_t]),
     ("pwn_trace_rows_device", _i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
     ("pwn_blur_rows_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("pwn_blur_rows_device_bounded", _i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),

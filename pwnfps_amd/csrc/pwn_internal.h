@@ -43,11 +43,11 @@ extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out
 // one frame in flight (pwn_submit_frame / pwn_wait_frame)
 struct pwn_slot
 {
-	uint32_t *d_out; float *d_z; uint32_t *d_surface;      // device: final colour, depth (PWN_FRAME_ZBUF), upscaled surface
+	uint32_t *d_out; float *d_z; uint32_t *d_surface;      // device: final colour, depth, upscaled surface
 	uint32_t *h_sbuf; float *h_zbuf; uint32_t *h_surface;  // pinned host copies handed to the caller
 	hipEvent_t ev_k[4];                                    // compute stream: start, after trace, after blur, after sink
 	hipEvent_t ev_done;                                    // copy stream: this frame's host buffers are complete
-	bool in_flight;
+	bool in_flight, timed;
 	float sec;
 	uint64_t seq;
 };
@@ -88,16 +88,17 @@ struct pwn_ctx
 	float *d_z;
 	uint2 *d_skip;                   // blur LCG skip-ahead, w/4 entries
 	unsigned long long *d_counters;
+	unsigned long long *d_wave_log; int wave_log_on;   // PWN_OPT_WAVE_LOG
 	uint32_t *d_tickets; unsigned ticket_set;  // two sets of work-queue counters of the trace kernel, used alternately
 	uint32_t *d_scratch; size_t scratch_cap;   // upscale / probe staging
 
 	hipStream_t stream;              // compute
-	hipStream_t copy_stream;         // D2H of finished frames (frames in flight)
+	hipStream_t copy_stream;         // frames in flight: D2H of finished frames
 	hipEvent_t ev[4];
 	pwn_stats stats;
 
 	// frames in flight
-	int nslots, frame_flags, frame_scale, frame_pitch;
+	int nslots, frame_flags, frame_scale, frame_pitch, frame_timing;
 	pwn_slot slot[PWN_MAX_SLOTS];
 	uint64_t frame_seq;
 

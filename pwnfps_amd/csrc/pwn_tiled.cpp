@@ -1,5 +1,572 @@
-// pwn_tiled.cpp -- row tiling of one frame over the GPUs of a node (placeholder until the
-// RCCL choreography lands in this round)
+// pwn_tiled.cpp -- one frame row-tiled over the GPUs of a node, behind the C ABI.
+//
+// One process per GPU, each with its own pwn_ctx; rank r owns the strip of rows
+// [r * rows_per, min((r + 1) * rows_per, h)), rows_per = ceil(h / world) rounded up to 8
+// (the reference parallelises the same two loops with OpenMP over rows, screen.h:63,77).
+// The trace pass needs no exchange.  The blur does: its taps reach 0.002*h*(depth-1) rows
+// (screen.h:100-102), unbounded in depth.  Per frame f and rank:
+//
+//   compute stream   trace strip f -> pre[s], z[s]                                   s = f & 1
+//   comm stream      ONE grouped exchange G(f), a single RCCL launch:
+//                      - the H border rows of strip f to / from the neighbour strips,
+//                        straight out of / into the full-frame plane pre[s] (or, without a
+//                        halo, every strip to everybody: an all-gather by send / recv)
+//                      - the FINISHED strip of frame f-1 to rank 0   (the gather)
+//                      - the miss word of frame f-1 to every rank    (see below)
+//   compute stream   blur strip f from pre[s] rows [y0-H, y1+H) -> out[s]; taps outside
+//                    those rows are counted in the rank's miss word of frame f
+//
+// so the wire carries frame f's halo and frame f-1's result in one launch while the kernels of
+// both run.  Frame f-1 is complete on rank 0 when G(f) is (pwn_tiled_wait issues a group with
+// only the second half when no newer frame was submitted).  Every rank then holds every
+// rank's miss word of frame f-1: if one is non-zero the bounded halo was not enough for that
+// frame and ALL ranks, having the same words, repeat its exchange with whole strips, its blur and
+// its gather before it is delivered, and use whole strips from then on.  A delivered frame is
+// always exact; the host synchronises only at delivery, one frame behind the submissions.
+//
+// The transport is a small interface: RCCL (ncclSend / ncclRecv in a group, loaded with dlopen so
+// that libpwnhip.so has no link-time dependency on it), or -- for tests on a box with one GPU,
+// where RCCL cannot run two ranks -- POSIX shared memory through the host.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <time.h>
+#include <errno.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+
+#include <rccl/rccl.h>          // types only: the entry points are resolved at run time
 #include "pwn_internal.h"
 
-void pwn_tiled_destroy(pwn_ctx *c) { c->tiled = NULL; }
+// ---------------------------------------------------------------- transports ----
+struct pwn_transport
+{
+	virtual ~pwn_transport() {}
+	// a group = sends and receives that progress together; stream-ordered on `stream`
+	virtual int begin(hipStream_t stream) = 0;
+	virtual int send(const void *d_src, size_t bytes, int peer) = 0;
+	virtual int recv(void *d_dst, size_t bytes, int peer) = 0;
+	virtual int end() = 0;
+	virtual const char *name() const = 0;
+	char err[200];
+};
+
+// ---- RCCL over xGMI
+struct rccl_api
+{
+	void *lib;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *);
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
+	ncclResult_t (*CommDestroy)(ncclComm_t);
+	ncclResult_t (*GroupStart)(void);
+	ncclResult_t (*GroupEnd)(void);
+	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
+	const char *(*GetErrorString)(ncclResult_t);
+};
+
+static rccl_api *rccl_load(char *err, size_t errlen)
+{
+	static rccl_api api;
+	static int state = 0;          // 0 untried, 1 ok, -1 failed
+	if(state == 1) return &api;
+	if(state == -1) { snprintf(err, errlen, "librccl could not be loaded"); return NULL; }
+	// a process that already has an RCCL (PyTorch ships its own) gets that one: same soname
+	const char *names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+	for(size_t i = 0; i < sizeof(names) / sizeof(names[0]) && api.lib == NULL; i++) api.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+	if(api.lib == NULL) { state = -1; snprintf(err, errlen, "dlopen(librccl): %s", dlerror()); return NULL; }
+#define SYM(field, name) do { *(void **)&api.field = dlsym(api.lib, name); if(api.field == NULL) { state = -1; \
+	snprintf(err, errlen, "librccl has no %s", name); return NULL; } } while(0)
+	SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
+	SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
+	SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+	state = 1;
+	return &api;
+}
+
+struct rccl_transport : pwn_transport
+{
+	rccl_api *api; ncclComm_t comm; hipStream_t stream;
+	rccl_transport() : api(NULL), comm(NULL), stream(NULL) { err[0] = 0; }
+	~rccl_transport() { if(comm) (void)api->CommDestroy(comm); }
+	int chk(ncclResult_t r, const char *what)
+	{
+		if(r == ncclSuccess) return PWN_OK;
+		snprintf(err, sizeof(err), "%s: %s", what, api->GetErrorString(r));
+		return PWN_EHIP;
+	}
+	int begin(hipStream_t s) { stream = s; return chk(api->GroupStart(), "ncclGroupStart"); }
+	int send(const void *p, size_t n, int peer) { return chk(api->Send(p, n, ncclUint8, peer, comm, stream), "ncclSend"); }
+	int recv(void *p, size_t n, int peer) { return chk(api->Recv(p, n, ncclUint8, peer, comm, stream), "ncclRecv"); }
+	int end() { return chk(api->GroupEnd(), "ncclGroupEnd"); }
+	const char *name() const { return "rccl"; }
+};
+
+// ---- shared memory through the host (tests: several ranks on ONE GPU).  One mailbox per
+// ordered pair of ranks: a ring of SHM_SLOTS messages of at most `slot_bytes`; a sender copies
+// device -> mailbox and publishes the message number, the receiver waits for that number,
+// copies mailbox -> device and frees the slot.  Messages between two ranks are matched in
+// order, like RCCL's.  Host-synchronous by design.
+#define SHM_SLOTS 4
+struct shm_box { volatile unsigned long long sent, taken; unsigned long long pad[6]; };   // 64 B
+struct shm_transport : pwn_transport
+{
+	int rank, world; size_t slot_bytes, total; char shm_name[64]; bool owner;
+	unsigned char *base; hipStream_t stream;
+	struct op { bool is_send; const void *src; void *dst; size_t bytes; int peer; };
+	std::vector<op> ops;
+	shm_transport() : rank(0), world(1), slot_bytes(0), total(0), owner(false), base(NULL), stream(NULL) { err[0] = 0; shm_name[0] = 0; }
+	~shm_transport()
+	{
+		if(base) munmap(base, total);
+		if(owner && shm_name[0]) shm_unlink(shm_name);
+	}
+	shm_box *box(int src, int dst) { return (shm_box *)(base + ((size_t)src * world + dst) * sizeof(shm_box)); }
+	unsigned char *slot(int src, int dst, unsigned long long n)
+	{
+		return base + (size_t)world * world * sizeof(shm_box) + (((size_t)src * world + dst) * SHM_SLOTS + (size_t)(n % SHM_SLOTS)) * slot_bytes;
+	}
+	int open_region(const char *name, int rank_, int world_, size_t slot_bytes_)
+	{
+		rank = rank_; world = world_; slot_bytes = (slot_bytes_ + 63) & ~(size_t)63;
+		snprintf(shm_name, sizeof(shm_name), "%s", name);
+		total = (size_t)world * world * sizeof(shm_box) + (size_t)world * world * SHM_SLOTS * slot_bytes;
+		int fd = -1;
+		if(rank == 0)
+		{
+			fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+			owner = fd >= 0;
+			if(fd >= 0 && ftruncate(fd, (off_t)total) != 0) { close(fd); fd = -1; }
+		}
+		else
+		{
+			// rank 0 creates it and sizes it; wait for both
+			for(int tries = 0; tries < 3000; tries++)
+			{
+				fd = shm_open(shm_name, O_RDWR, 0600);
+				struct stat sb;
+				if(fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= total) break;
+				if(fd >= 0) { close(fd); fd = -1; }
+				struct timespec ts = { 0, 10 * 1000 * 1000 };
+				nanosleep(&ts, NULL);
+			}
+		}
+		if(fd < 0) { snprintf(err, sizeof(err), "shm_open(%s): %s", shm_name, strerror(errno)); return PWN_EIO; }
+		base = (unsigned char *)mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+		close(fd);
+		if(base == (unsigned char *)MAP_FAILED) { base = NULL; snprintf(err, sizeof(err), "mmap(%s): %s", shm_name, strerror(errno)); return PWN_ENOMEM; }
+		return PWN_OK;
+	}
+	int begin(hipStream_t s) { stream = s; ops.clear(); return PWN_OK; }
+	int send(const void *p, size_t n, int peer) { op o = { true, p, NULL, n, peer }; ops.push_back(o); return n <= slot_bytes ? PWN_OK : PWN_EINVAL; }
+	int recv(void *p, size_t n, int peer) { op o = { false, NULL, p, n, peer }; ops.push_back(o); return n <= slot_bytes ? PWN_OK : PWN_EINVAL; }
+	int wait_until(volatile unsigned long long *word, unsigned long long at_least)
+	{
+		// a peer that died must not hang the test: give up after two minutes
+		for(unsigned long long spins = 0; __atomic_load_n(word, __ATOMIC_ACQUIRE) < at_least; spins++)
+		{
+			if(spins > 200ull * 120ull * 50ull) { snprintf(err, sizeof(err), "shm transport: peer did not answer"); return PWN_EIO; }
+			if(spins > 2000) { struct timespec ts = { 0, 100 * 1000 }; nanosleep(&ts, NULL); }
+		}
+		return PWN_OK;
+	}
+	int end()
+	{
+		// what is sent was produced on `stream`
+		if(hipStreamSynchronize(stream) != hipSuccess) { snprintf(err, sizeof(err), "hipStreamSynchronize failed"); return PWN_EHIP; }
+		// all sends first (rings have room for a group's messages), then the receives
+		for(size_t i = 0; i < ops.size(); i++)
+		{
+			const op &o = ops[i];
+			if(!o.is_send) continue;
+			shm_box *b = box(rank, o.peer);
+			const unsigned long long n = b->sent;
+			int rc = wait_until(&b->taken, n + 1 >= SHM_SLOTS ? n + 1 - SHM_SLOTS : 0);
+			if(rc != PWN_OK) return rc;
+			if(o.bytes && hipMemcpy(slot(rank, o.peer, n), o.src, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) { snprintf(err, sizeof(err), "D2H failed"); return PWN_EHIP; }
+			__atomic_store_n(&b->sent, n + 1, __ATOMIC_RELEASE);
+		}
+		for(size_t i = 0; i < ops.size(); i++)
+		{
+			const op &o = ops[i];
+			if(o.is_send) continue;
+			shm_box *b = box(o.peer, rank);
+			const unsigned long long n = b->taken;
+			int rc = wait_until(&b->sent, n + 1);
+			if(rc != PWN_OK) return rc;
+			if(o.bytes && hipMemcpy(o.dst, slot(o.peer, rank, n), o.bytes, hipMemcpyHostToDevice) != hipSuccess) { snprintf(err, sizeof(err), "H2D failed"); return PWN_EHIP; }
+			__atomic_store_n(&b->taken, n + 1, __ATOMIC_RELEASE);
+		}
+		return PWN_OK;
+	}
+	const char *name() const { return "shm"; }
+};
+
+// ---------------------------------------------------------------- state ----
+struct pwn_tiled
+{
+	int rank, world, per, y0, y1;
+	int halo;                           // rows exchanged with each neighbour; 0 = whole strips to everybody
+	pwn_transport *tp;
+	hipStream_t comm;
+	uint32_t *pre[2], *out[2], *fin[2]; float *z[2];       // full-frame planes per frame slot (fin: rank 0)
+	uint32_t *missw[2], *missv[2];      // this rank's miss word of the slot's frame; every rank's (world words)
+	uint32_t *h_missv;                  // pinned
+	uint32_t *h_frame;                  // pinned host copy of a delivered frame (rank 0, PWN_TILED_HOST)
+	hipEvent_t ev_t[2], ev_x[2], ev_b[2];
+	bool has_x[2], has_b[2];
+	unsigned long long submitted, gathered, delivered;
+	pwn_tiled_info info;
+};
+
+#define TPCHK(c, call) do { int rc_ = (call); if(rc_ != PWN_OK) { snprintf((c)->err, sizeof((c)->err), "%s transport: %s", \
+	(c)->tiled->tp->name(), (c)->tiled->tp->err); return rc_; } } while(0)
+
+static int strip_rows(int h, int world)
+{
+	int per = (h + world - 1) / world;
+	return (per + 7) / 8 * 8;
+}
+
+extern "C" int pwn_tiled_unique_id(void *id, int transport)
+{
+	if(id == NULL) return PWN_EINVAL;
+	memset(id, 0, PWN_TILED_ID_BYTES);
+	if(transport == PWN_TRANSPORT_SHM)
+	{
+		struct timespec ts;
+		clock_gettime(CLOCK_REALTIME, &ts);
+		snprintf((char *)id, PWN_TILED_ID_BYTES, "/pwn_tiled_%d_%lx", (int)getpid(), (unsigned long)ts.tv_nsec);
+		return PWN_OK;
+	}
+	if(transport != PWN_TRANSPORT_RCCL) return PWN_EINVAL;
+	char err[200];
+	rccl_api *api = rccl_load(err, sizeof(err));
+	if(api == NULL) return PWN_ENOTSUP;
+	static_assert(sizeof(ncclUniqueId) == PWN_TILED_ID_BYTES, "the id is an ncclUniqueId");
+	return api->GetUniqueId((ncclUniqueId *)id) == ncclSuccess ? PWN_OK : PWN_EHIP;
+}
+
+void pwn_tiled_destroy(pwn_ctx *c)
+{
+	pwn_tiled *t = c->tiled;
+	if(t == NULL) return;
+	(void)hipSetDevice(c->device);
+	(void)hipDeviceSynchronize();
+	delete t->tp;
+	for(int s = 0; s < 2; s++)
+	{
+		(void)hipFree(t->pre[s]); (void)hipFree(t->out[s]); (void)hipFree(t->fin[s]); (void)hipFree(t->z[s]);
+		(void)hipFree(t->missw[s]); (void)hipFree(t->missv[s]);
+		if(t->ev_t[s]) (void)hipEventDestroy(t->ev_t[s]);
+		if(t->ev_x[s]) (void)hipEventDestroy(t->ev_x[s]);
+		if(t->ev_b[s]) (void)hipEventDestroy(t->ev_b[s]);
+	}
+	if(t->h_missv) (void)hipHostFree(t->h_missv);
+	if(t->h_frame) (void)hipHostFree(t->h_frame);
+	if(t->comm) (void)hipStreamDestroy(t->comm);
+	delete t;
+	c->tiled = NULL;
+}
+
+extern "C" void pwn_tiled_shutdown(pwn_ctx *c) { if(c != NULL) pwn_tiled_destroy(c); }
+
+extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, int transport, int halo_rows)
+{
+	if(c == NULL || id == NULL || world < 1 || world > 64 || rank < 0 || rank >= world) return PWN_EINVAL;
+	if(c->tiled != NULL) return PWN_EBUSY;
+	if(c->blur_passes > 1) { snprintf(c->err, sizeof(c->err), "row tiling supports POSTPROC_BLUR 0 or 1"); return PWN_EINVAL; }
+	if(c->blur_passes > 0 && (c->w & 3) != 0) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	pwn_tiled *t = new(std::nothrow) pwn_tiled();
+	if(t == NULL) return PWN_ENOMEM;
+	memset(t, 0, sizeof(*t));
+	t->rank = rank; t->world = world;
+	t->per = strip_rows(c->h, world);
+	t->y0 = rank * t->per < c->h ? rank * t->per : c->h;
+	t->y1 = t->y0 + t->per < c->h ? t->y0 + t->per : c->h;
+	// bounded halo: H rows per neighbour, possible when every strip has at least H rows; the default
+	// covers depth 24 (taps reach 0.002 * h * (depth - 1) rows, screen.h:100-102)
+	int H = halo_rows < 0 ? (int)(0.002 * c->h * 24.0) + 2 : halo_rows;
+	int shortest = c->h;
+	for(int r = 0; r < world; r++)
+	{
+		int a = r * t->per < c->h ? r * t->per : c->h, b = a + t->per < c->h ? a + t->per : c->h;
+		if(b - a < shortest) shortest = b - a;
+	}
+	if(world == 1 || c->blur_passes == 0 || H > shortest || H <= 0) H = 0;
+	t->halo = H;
+	c->tiled = t;
+
+	int rc = PWN_OK;
+	const size_t n = (size_t)c->w * (size_t)c->h;
+	const size_t strip_bytes = (size_t)c->w * (size_t)t->per * 4;
+	do
+	{
+		if(transport == PWN_TRANSPORT_RCCL)
+		{
+			rccl_api *api = rccl_load(c->err, sizeof(c->err));
+			if(api == NULL) { rc = PWN_ENOTSUP; break; }
+			rccl_transport *rt = new(std::nothrow) rccl_transport();
+			if(rt == NULL) { rc = PWN_ENOMEM; break; }
+			rt->api = api;
+			t->tp = rt;
+			ncclUniqueId uid;
+			memcpy(&uid, id, sizeof(uid));
+			ncclResult_t r = api->CommInitRank(&rt->comm, world, uid, rank);
+			if(r != ncclSuccess) { snprintf(c->err, sizeof(c->err), "ncclCommInitRank: %s", api->GetErrorString(r)); rc = PWN_EHIP; break; }
+		}
+		else if(transport == PWN_TRANSPORT_SHM)
+		{
+			shm_transport *st = new(std::nothrow) shm_transport();
+			if(st == NULL) { rc = PWN_ENOMEM; break; }
+			t->tp = st;
+			char name[PWN_TILED_ID_BYTES];
+			memcpy(name, id, sizeof(name)); name[sizeof(name) - 1] = 0;
+			rc = st->open_region(name, rank, world, strip_bytes);
+			if(rc != PWN_OK) { snprintf(c->err, sizeof(c->err), "%s", st->err); break; }
+		}
+		else { rc = PWN_EINVAL; break; }
+
+		if(hipStreamCreateWithFlags(&t->comm, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+		for(int s = 0; s < 2 && rc == PWN_OK; s++)
+		{
+			if(hipMalloc((void **)&t->pre[s], n * 4) != hipSuccess || hipMalloc((void **)&t->out[s], n * 4) != hipSuccess ||
+			   hipMalloc((void **)&t->z[s], n * 4) != hipSuccess || hipMalloc((void **)&t->missw[s], 64) != hipSuccess ||
+			   hipMalloc((void **)&t->missv[s], (size_t)world * 4 + 64) != hipSuccess ||
+			   (rank == 0 && hipMalloc((void **)&t->fin[s], n * 4) != hipSuccess)) { rc = PWN_ENOMEM; break; }
+			if(hipMemset(t->pre[s], 0, n * 4) != hipSuccess || hipMemset(t->out[s], 0, n * 4) != hipSuccess ||
+			   hipMemset(t->z[s], 0, n * 4) != hipSuccess || hipMemset(t->missw[s], 0, 64) != hipSuccess ||
+			   hipMemset(t->missv[s], 0, (size_t)world * 4 + 64) != hipSuccess ||
+			   (rank == 0 && hipMemset(t->fin[s], 0, n * 4) != hipSuccess)) { rc = PWN_EHIP; break; }
+			if(hipEventCreateWithFlags(&t->ev_t[s], hipEventDisableTiming) != hipSuccess ||
+			   hipEventCreateWithFlags(&t->ev_x[s], hipEventDisableTiming) != hipSuccess ||
+			   hipEventCreateWithFlags(&t->ev_b[s], hipEventDisableTiming) != hipSuccess) { rc = PWN_EHIP; break; }
+		}
+		if(rc != PWN_OK) break;
+		if(hipHostMalloc((void **)&t->h_missv, (size_t)world * 4 + 64, hipHostMallocDefault) != hipSuccess) { rc = PWN_ENOMEM; break; }
+	} while(0);
+	if(rc != PWN_OK) { char keep[256]; memcpy(keep, c->err, sizeof(keep)); pwn_tiled_destroy(c); memcpy(c->err, keep, sizeof(keep)); return rc; }
+	t->info.rank = rank; t->info.world = world; t->info.y0 = t->y0; t->info.y1 = t->y1; t->info.rows_per_rank = t->per;
+	t->info.halo_rows = t->halo; t->info.transport = transport;
+	return PWN_OK;
+}
+
+extern "C" int pwn_tiled_get_info(pwn_ctx *c, pwn_tiled_info *out)
+{
+	if(c == NULL || out == NULL || c->tiled == NULL) return PWN_EINVAL;
+	c->tiled->info.halo_rows = c->tiled->halo;
+	*out = c->tiled->info;
+	return PWN_OK;
+}
+
+static void rows_of(pwn_ctx *c, pwn_tiled *t, int r, int *a, int *b)
+{
+	*a = r * t->per < c->h ? r * t->per : c->h;
+	*b = *a + t->per < c->h ? *a + t->per : c->h;
+}
+
+// the second half of a group: frame `g`'s finished strips to rank 0, its miss words to everybody
+static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
+{
+	const int s = (int)(g & 1);
+	const size_t w4 = (size_t)c->w * 4;
+	uint32_t *mine = c->blur_passes ? t->out[s] : t->pre[s];
+	if(t->rank == 0)
+	{
+		for(int r = 1; r < t->world; r++)
+		{
+			int a, b; rows_of(c, t, r, &a, &b);
+			if(b > a) { TPCHK(c, t->tp->recv(t->fin[s] + (size_t)a * c->w, (size_t)(b - a) * w4, r)); t->info.bytes_received += (unsigned long long)(b - a) * w4; }
+		}
+	}
+	else if(t->y1 > t->y0)
+	{
+		TPCHK(c, t->tp->send(mine + (size_t)t->y0 * c->w, (size_t)(t->y1 - t->y0) * w4, 0));
+		t->info.bytes_sent += (unsigned long long)(t->y1 - t->y0) * w4;
+	}
+	if(t->halo)
+		for(int r = 0; r < t->world; r++)
+		{
+			if(r == t->rank) continue;
+			TPCHK(c, t->tp->send(t->missw[s], 4, r));
+			TPCHK(c, t->tp->recv(t->missv[s] + r, 4, r));
+		}
+	return PWN_OK;
+}
+
+// whole strips of pre[s] to everybody (an all-gather by send / recv, in place in the full-frame plane)
+static int add_allgather(pwn_ctx *c, pwn_tiled *t, int s)
+{
+	const size_t w4 = (size_t)c->w * 4;
+	for(int r = 0; r < t->world; r++)
+	{
+		if(r == t->rank) continue;
+		int a, b; rows_of(c, t, r, &a, &b);
+		if(t->y1 > t->y0) { TPCHK(c, t->tp->send(t->pre[s] + (size_t)t->y0 * c->w, (size_t)(t->y1 - t->y0) * w4, r)); t->info.bytes_sent += (unsigned long long)(t->y1 - t->y0) * w4; }
+		if(b > a) { TPCHK(c, t->tp->recv(t->pre[s] + (size_t)a * c->w, (size_t)(b - a) * w4, r)); t->info.bytes_received += (unsigned long long)(b - a) * w4; }
+	}
+	return PWN_OK;
+}
+
+extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
+{
+	if(c == NULL || cam == NULL || c->tiled == NULL) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	if(t->submitted - t->delivered >= 2) return PWN_EBUSY;
+	(void)hipSetDevice(c->device);
+	const unsigned long long f = t->submitted;
+	const int s = (int)(f & 1);
+	const size_t w4 = (size_t)c->w * 4;
+	hipStream_t cs = c->stream;
+	// pre[s] / z[s] / out[s] were last used by frame f-2: its blur ran on this stream; its strips went
+	// out in G(f-1) and in the gather of G(f-1) or of the drain group -- all before ev_x of the other slot
+	if(t->has_x[s ^ 1]) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s ^ 1], 0));
+	if(t->has_x[s]) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
+	uint32_t *plane = c->blur_passes ? t->pre[s] : (t->rank == 0 ? t->fin[s] : t->pre[s]);
+	int rc = pwn_i_launch_trace(c, cam, sec, t->y0, t->y1, plane, t->z[s], cs);
+	if(rc != PWN_OK) return rc;
+	HIPCHK(c, hipMemsetAsync(t->missw[s], 0, 4, cs));
+	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
+
+	// ---- G(f) on the comm stream
+	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
+	const bool gather_prev = t->gathered < f;          // frame f-1 has not been gathered yet
+	if(gather_prev && t->has_b[s ^ 1]) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[s ^ 1], 0));
+	if(t->world > 1)
+	{
+		TPCHK(c, t->tp->begin(t->comm));
+		if(c->blur_passes)
+		{
+			if(t->halo)
+			{
+				const int H = t->halo;
+				if(t->rank > 0)
+				{
+					TPCHK(c, t->tp->send(t->pre[s] + (size_t)t->y0 * c->w, (size_t)H * w4, t->rank - 1));
+					TPCHK(c, t->tp->recv(t->pre[s] + (size_t)(t->y0 - H) * c->w, (size_t)H * w4, t->rank - 1));
+					t->info.bytes_sent += (unsigned long long)H * w4; t->info.bytes_received += (unsigned long long)H * w4;
+				}
+				if(t->rank < t->world - 1 && t->y1 < c->h)
+				{
+					TPCHK(c, t->tp->send(t->pre[s] + (size_t)(t->y1 - H) * c->w, (size_t)H * w4, t->rank + 1));
+					TPCHK(c, t->tp->recv(t->pre[s] + (size_t)t->y1 * c->w, (size_t)H * w4, t->rank + 1));
+					t->info.bytes_sent += (unsigned long long)H * w4; t->info.bytes_received += (unsigned long long)H * w4;
+				}
+			}
+			else { rc = add_allgather(c, t, s); if(rc != PWN_OK) return rc; }
+		}
+		if(gather_prev) { rc = add_gather(c, t, f - 1); if(rc != PWN_OK) return rc; }
+		TPCHK(c, t->tp->end());
+		t->info.groups++;
+	}
+	if(gather_prev) t->gathered = f;
+	HIPCHK(c, hipEventRecord(t->ev_x[s], t->comm));
+	t->has_x[s] = true;
+
+	// ---- blur of strip f
+	if(c->blur_passes)
+	{
+		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
+		uint32_t *dst = t->rank == 0 ? t->fin[s] : t->out[s];
+		if(t->halo)
+		{
+			const int a0 = t->rank > 0 ? t->y0 - t->halo : 0, a1 = (t->rank < t->world - 1 && t->y1 < c->h) ? t->y1 + t->halo : c->h;
+			rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, a0, a1, t->missw[s]);
+		}
+		else rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL);
+		if(rc != PWN_OK) return rc;
+	}
+	HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
+	t->has_b[s] = true;
+	t->submitted = f + 1;
+	return PWN_OK;
+}
+
+extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
+{
+	if(c == NULL || c->tiled == NULL) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	if(t->delivered >= t->submitted) return PWN_EINVAL;          // nothing in flight
+	(void)hipSetDevice(c->device);
+	const unsigned long long d = t->delivered;
+	const int s = (int)(d & 1);
+	const size_t n = (size_t)c->w * (size_t)c->h;
+	if(t->gathered <= d)
+	{
+		// no newer frame carries this one's gather: a group of its own
+		HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[s], 0));
+		if(t->world > 1)
+		{
+			TPCHK(c, t->tp->begin(t->comm));
+			int rc = add_gather(c, t, d);
+			if(rc != PWN_OK) return rc;
+			TPCHK(c, t->tp->end());
+			t->info.groups++;
+		}
+		t->gathered = d + 1;
+		HIPCHK(c, hipEventRecord(t->ev_x[s], t->comm));     // (slot s: what has to be over before trace d+2 reuses it)
+		t->has_x[s] = true;
+		HIPCHK(c, hipEventSynchronize(t->ev_x[s]));
+	}
+	else
+		HIPCHK(c, hipEventSynchronize(t->ev_x[s ^ 1]));      // G(d+1) carried it
+	HIPCHK(c, hipEventSynchronize(t->ev_b[s]));               // (world 1, and rank 0's own strip)
+
+	// ---- was the bounded halo enough for this frame, on every rank?
+	bool miss = false;
+	if(t->halo)
+	{
+		HIPCHK(c, hipMemcpy(t->h_missv, t->missv[s], (size_t)t->world * 4, hipMemcpyDeviceToHost));
+		uint32_t own = 0;
+		HIPCHK(c, hipMemcpy(&own, t->missw[s], 4, hipMemcpyDeviceToHost));
+		t->h_missv[t->rank] = own;
+		for(int r = 0; r < t->world; r++) miss = miss || t->h_missv[r] != 0;
+	}
+	if(miss)
+	{
+		// Every rank sees the same words and comes here together: the frame's exchange again with
+		// whole strips (pre[s] and z[s] still hold this frame), blur, gather; whole strips from now on.
+		t->info.frames_redone++;
+		t->halo = 0;
+		hipStream_t cs = c->stream;
+		TPCHK(c, t->tp->begin(cs));
+		int rc = add_allgather(c, t, s);
+		if(rc != PWN_OK) return rc;
+		TPCHK(c, t->tp->end());
+		uint32_t *dst = t->rank == 0 ? t->fin[s] : t->out[s];
+		rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL);
+		if(rc != PWN_OK) return rc;
+		TPCHK(c, t->tp->begin(cs));
+		rc = add_gather(c, t, d);
+		if(rc != PWN_OK) return rc;
+		TPCHK(c, t->tp->end());
+		t->info.groups += 2;
+		HIPCHK(c, hipStreamSynchronize(cs));
+	}
+	t->delivered = d + 1;
+	t->info.frames++;
+	if(out != NULL)
+	{
+		memset(out, 0, sizeof(*out));
+		out->seq = d + 1;
+		out->redone = miss ? 1 : 0;
+		if(t->rank == 0)
+		{
+			out->d_sbuf = t->fin[s];
+			if(flags & PWN_TILED_HOST)
+			{
+				if(t->h_frame == NULL) HIPCHK(c, hipHostMalloc((void **)&t->h_frame, n * 4, hipHostMallocDefault));
+				HIPCHK(c, hipMemcpy(t->h_frame, t->fin[s], n * 4, hipMemcpyDeviceToHost));
+				out->sbuf = t->h_frame;
+			}
+		}
+	}
+	return PWN_OK;
+}

@@ -90,7 +90,8 @@ struct pwn_trace_params
 	uint32_t *sbuf;                           // full frame, pitch w
 	float *zbuf;                              // full frame, pitch w
 	const uint32_t *blob;
-	unsigned long long *counters;             // 14 x u64 (pwn_stats counters + wave_paths) or NULL
+	unsigned long long *counters;             // 24 x u64 (pwn_stats counters, wave_paths, residency) or NULL
+	unsigned long long *wave_log;             // counting builds, diagnosis: (start, end) of every wave, 100 MHz ticks; or NULL
 	int has_w;                                // camera has w components (general 4-lane path)
 	int scheduler;                            // PWN_SCHED_* (pwnhip.h)
 	int refill_limit;                         // PWN_SCHED_REFILL: walk on while more lanes than this walk (trace_refill.hip)

@@ -131,6 +131,9 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		do
 		{
 #include "trace_walk.inc"
+			// trace.h:250,677: out of steps.  (Leaving the loop on the scalar counter instead and marking the
+			// lanes afterwards trades these 3 VALU for 4 SALU: measured equal, 0.3748 / 0.3731 ms at 4K.)
+			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
 		} while(ev == 0);
 		// what the ray ended on is read back from the register: without this the compiler keeps
 		// "ev == EV_EXHAUSTED" as a lane mask that it updates in every iteration of the walk
@@ -303,6 +306,9 @@ pwn_trace_kernel(pwn_trace_params P)
 	const int l16 = lane & 15;
 
 	Counters cnt = {};
+	// PWN_OPT_WAVE_LOG: when was this wave resident (the GPU's constant 100 MHz clock)
+	unsigned long long t_begin = 0ull;
+	if(P.wave_log != NULL) t_begin = __builtin_amdgcn_s_memrealtime();
 
 	// Work distribution.  A unit is one wave64's 16 x 4 pixels (lane & 15 = column inside one
 	// half of the 32-wide tile of screen.h:6-7 = one DPP row, lane >> 4 = row).  Rays differ in
@@ -341,10 +347,16 @@ pwn_trace_kernel(pwn_trace_params P)
 			// this queue is empty: find one that is not (plain loads; a stale value can only
 			// look fuller than the queue is, and then the atomic below says so)
 			uint32_t seen = 0xffffffffu;
-			if((uint32_t)lane < PWN_QUEUES)
-				seen = __hip_atomic_load(&P.tickets[(uint32_t)lane * PWN_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const uint32_t len_l = (units + PWN_QUEUES - 1u - ((uint32_t)lane & (PWN_QUEUES - 1u))) / PWN_QUEUES;
-			const unsigned long long open = __ballot((uint32_t)lane < PWN_QUEUES && seen < len_l);
+			// (the lane number recomputed and made opaque here: otherwise the address and the queue length
+			// below are computed once at the top of the kernel and live in scratch memory until this rare
+			// block: 20 B per lane written by every wave of every launch, 6.5 MB per 4K frame)
+			uint32_t ql = 0u;
+			asm volatile("" : "+v"(ql));
+			ql = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, ql));     // = lane
+			if(ql < PWN_QUEUES)
+				seen = __hip_atomic_load(&P.tickets[ql * PWN_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t len_l = (units + PWN_QUEUES - 1u - (ql & (PWN_QUEUES - 1u))) / PWN_QUEUES;
+			const unsigned long long open = __ballot(ql < PWN_QUEUES && seen < len_l);
 			if(open == 0ull) break;
 			// the next open queue after q, cyclically: bit i of the shifted double mask is queue q+1+i
 			static_assert(PWN_QUEUES <= 64u && (PWN_QUEUES & (PWN_QUEUES - 1u)) == 0u, "a power of two, one lane per queue");
@@ -433,14 +445,20 @@ pwn_trace_kernel(pwn_trace_params P)
 	if(COUNT)
 	{
 		// wave reduce, one atomic per wave and counter
-		unsigned long long v[14] = { cnt.rays, cnt.steps, cnt.portals, cnt.tests, cnt.exhausted, cnt.wsteps,
-			cnt.wp[0], cnt.wp[1], cnt.wp[2], cnt.wp[3], cnt.wp[4], cnt.wp[5], cnt.wp[6], cnt.wp[7] };
-		for(int i = 0; i < 14; i++)
+		unsigned long long v[16] = { cnt.rays, cnt.steps, cnt.portals, cnt.tests, cnt.exhausted, cnt.wsteps,
+			cnt.wp[0], cnt.wp[1], cnt.wp[2], cnt.wp[3], cnt.wp[4], cnt.wp[5], cnt.wp[6], cnt.wp[7], cnt.apasses, cnt.apass_lanes };
+		for(int i = 0; i < 16; i++)
 		{
 			unsigned long long s = v[i];
 			for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
 			if(lane == 0 && s) atomicAdd(&P.counters[i], s);
 		}
+	}
+	// PWN_OPT_WAVE_LOG: every wave's lifetime (pwn_stats.wave_time ..., tools/wave_log.py)
+	if(P.wave_log != NULL && (threadIdx.x & 63) == 0)
+	{
+		const size_t wid = (size_t)blockIdx.x * (PWN_BLOCK / 64) + (size_t)(threadIdx.x >> 6);
+		P.wave_log[2 * wid] = t_begin; P.wave_log[2 * wid + 1] = __builtin_amdgcn_s_memrealtime();
 	}
 }
 

@@ -71,6 +71,9 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 	float *rtab = (float *)(lds_raw + ((P.blob_bytes + 15u) & ~15u)) + wave * RTAB_FLOATS(HAS_W);
 
 	Counters cnt = {};
+	// PWN_OPT_WAVE_LOG: when was this wave resident (the GPU's constant 100 MHz clock)
+	unsigned long long t_begin = 0ull;
+	if(P.wave_log != NULL) t_begin = __builtin_amdgcn_s_memrealtime();
 
 	// ---- work queues (as in trace_kernel.hip: PWN_QUEUES counters 128 B apart, queue q holds the
 	// units u = q (mod PWN_QUEUES); a wave drains its home queue, then helps with the others, and
@@ -267,10 +270,14 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 							// whatever the loads return.
 							if(++misses > 2 * (int)PWN_QUEUES) break;
 							uint32_t seen = 0xffffffffu;
-							if((uint32_t)lane < PWN_QUEUES)
-								seen = __hip_atomic_load(&P.tickets[(uint32_t)lane * PWN_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-							const uint32_t len_l = (units + PWN_QUEUES - 1u - ((uint32_t)lane & (PWN_QUEUES - 1u))) / PWN_QUEUES;
-							const unsigned long long open = __ballot((uint32_t)lane < PWN_QUEUES && seen < len_l);
+							// = lane, opaque: keeps the address below out of the kernel's prologue (trace_kernel.hip)
+							uint32_t ql = 0u;
+							asm volatile("" : "+v"(ql));
+							ql = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, ql));
+							if(ql < PWN_QUEUES)
+								seen = __hip_atomic_load(&P.tickets[ql * PWN_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							const uint32_t len_l = (units + PWN_QUEUES - 1u - (ql & (PWN_QUEUES - 1u))) / PWN_QUEUES;
+							const unsigned long long open = __ballot(ql < PWN_QUEUES && seen < len_l);
 							if(open == 0ull) break;
 							static_assert(PWN_QUEUES <= 64u && (PWN_QUEUES & (PWN_QUEUES - 1u)) == 0u, "a power of two, one lane per queue");
 							if constexpr(PWN_QUEUES == 64u)
@@ -442,7 +449,11 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 				const unsigned long long w = __ballot(ev == EV_NONE);
 				waited += (int)__builtin_popcountll(walking0 & ~w);
 				on = (w & fresh) != 0ull && waited < limit;
-			} while(ev == EV_NONE && on);
+				maxsteps--;
+			} while(ev == EV_NONE && maxsteps != 0 && on);
+			asm volatile("" : "+v"(ev), "+v"(maxsteps));
+			// trace.h:250,677: out of steps
+			if(ev == EV_NONE && maxsteps == 0) ev = EV_EXHAUSTED;
 			// what the ray ended on is read back from the register (see trace_kernel.hip)
 			asm volatile("" : "+v"(ev));
 		}
@@ -459,6 +470,12 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 			for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
 			if(lane == 0 && s) atomicAdd(&P.counters[i], s);
 		}
+	}
+	// PWN_OPT_WAVE_LOG: every wave's lifetime (pwn_stats.wave_time ..., tools/wave_log.py)
+	if(P.wave_log != NULL && (threadIdx.x & 63) == 0)
+	{
+		const size_t wid = (size_t)blockIdx.x * (PWN_BLOCK / 64) + (size_t)(threadIdx.x >> 6);
+		P.wave_log[2 * wid] = t_begin; P.wave_log[2 * wid + 1] = __builtin_amdgcn_s_memrealtime();
 	}
 }
 

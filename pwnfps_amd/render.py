@@ -64,6 +64,14 @@ class Renderer:
         v = {"units": _lib.PWN_SCHED_UNITS, "refill": _lib.PWN_SCHED_REFILL}.get(which, which)
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_SCHEDULER, int(v)), "pwn_set_option")
 
+    def set_frame_timing(self, every):
+        """HIP events around the kernels of every N-th frame in flight (0: never, 1: all)."""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_FRAME_TIMING, int(every)), "pwn_set_option")
+
+    def set_wave_log(self, on):
+        """stats()["wave_time"] / (["waves"] * ["kernel_span"]) = mean wave residency of the last frame"""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_WAVE_LOG, 1 if on else 0), "pwn_set_option")
+
     def set_refill_limit(self, n):
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_REFILL_LIMIT, int(n)), "pwn_set_option")
 
@@ -168,7 +176,9 @@ class Renderer:
         library's pinned buffers (valid until the next submit on that slot) and device times."""
         fr = _lib.Frame()
         self._chk(lib.pwn_wait_frame(self._ctx, int(slot), C.byref(fr)), "pwn_wait_frame")
-        out = {"seq": fr.seq, "sec": fr.sec_current, "trace_ms": fr.trace_ms, "blur_ms": fr.blur_ms, "sink_ms": fr.sink_ms}
+        out = {"seq": fr.seq, "sec": fr.sec_current, "timed": bool(fr.timed),
+               "trace_ms": fr.trace_ms, "blur_ms": fr.blur_ms, "sink_ms": fr.sink_ms,
+               "d_sbuf": fr.d_sbuf, "d_zbuf": fr.d_zbuf, "d_surface": fr.d_surface}
         n = self.w * self.h
 
         def view(ptr, ctype, count, shape):
@@ -180,6 +190,12 @@ class Renderer:
         if fr.surface:
             pw = fr.surface_pitch_bytes // 4
             out["surface"] = view(fr.surface, C.c_uint32, pw * self.h * self._frame_scale, (self.h * self._frame_scale, pw))
+        return out
+
+    def read_plane(self, d_ptr, dtype=np.uint32):
+        """Host copy of a (h, w) device plane of a waited-for frame (wait_frame()["d_sbuf"] ...)."""
+        out = np.empty((self.h, self.w), dtype)
+        self._chk(lib.pwn_read_plane(self._ctx, C.c_void_p(d_ptr), out.ctypes.data, out.nbytes), "pwn_read_plane")
         return out
 
     def trace_rows_device(self, cam, sec_current, y0, y1, d_sbuf, d_zbuf, stream=0):
