@@ -7,12 +7,13 @@
 A step = one frame of the workload BASELINE.json quotes the metric on: the
 reference's level.txt scene (its 14 game.lua spheres, camera at the spawn
 pose, sec_current = 0) at 3840x2160 with the post-process blur on, i.e. one
-level_prepare_render() + trace_screen_centred() (main.c:95,107; screen.h:31-124).  With N > 1 the frame is row-tiled:
-rank r traces rows [r*H/N, (r+1)*H/N), the pre-blur strips are all-gathered
-(RCCL), each rank blurs its strip, and the strips are gathered on rank 0
-(pwnfps_amd/dist.py).  Level/sphere tables and all frame buffers are resident
-in HBM before the timed region; in the timed region of `value` the frame stays
-on the device.  The rate with every frame handed over to the host (what
+level_prepare_render() + trace_screen_centred() (main.c:95,107; screen.h:31-124).  With N > 1 the frame is row-tiled
+behind the C ABI (pwn_tiled_*, pwnfps_amd/csrc/pwn_tiled.cpp): rank r traces rows
+[r*per, (r+1)*per), one grouped RCCL send/recv launch per frame carries this frame's
+pre-blur halo rows between neighbour strips and the previous frame's finished
+strips to rank 0, each rank blurs its strip; two frames are in flight.  Level/sphere
+tables and all frame buffers are resident in HBM before the timed region; in the
+timed region of `value` the frame stays on the device (rank 0's for N > 1).  The rate with every frame handed over to the host (what
 trace_screen_centred does with sbuf, main.c:107) is measured in the same run
 through the frames-in-flight API and reported as `d2h_inclusive`.
 
@@ -159,18 +160,15 @@ def main():
     ap.add_argument("--resident-slots", type=int, default=3, help="N = 1: frames in flight of the resident loop (1 = strictly one after the other)")
     ap.add_argument("--scheduler", choices=["units", "refill"], default=None, help="trace kernel scheduler (default: the library's)")
     ap.add_argument("--time-every", type=int, default=8,
-                    help="N = 1: HIP events around the trace kernel of every N-th frame of the timed region (an event between two "
+                    help="HIP events around the trace kernel of every N-th frame of the timed region (an event between two "
                          "kernels costs ~4 us of pipeline; 1 = every launch)")
+    ap.add_argument("--halo", type=int, default=-1, help="N > 1: pre-blur rows exchanged with each neighbour strip (-1 default, 0 whole strips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="N > 1: finish each frame before starting the next")
-    ap.add_argument("--exchange", choices=["halo", "allgather"], default="halo",
-                    help="N > 1: pre-blur rows each rank receives (dist.py): a bounded halo with an exactness check, or every strip")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import pwnfps_amd
-    from pwnfps_amd.dist import HipStripBackend, RowTiledFrame
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -181,21 +179,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libpwnhip.so has no CPU fallback")
-    # test hooks (a 1-GPU box cannot run RCCL with 2 ranks): PWN_BENCH_ONE_DEVICE=1 puts every
-    # rank on device 0 and PWN_BENCH_BACKEND=gloo swaps the transport; the driver sets neither
+    # test hooks (a 1-GPU box cannot run RCCL with 2 ranks): PWN_BENCH_ONE_DEVICE=1 puts every rank on
+    # device 0 and PWN_BENCH_TRANSPORT=shm moves the messages through shared memory; the driver sets neither
     if os.environ.get("PWN_BENCH_ONE_DEVICE"):
         local = 0
-    backend = os.environ.get("PWN_BENCH_BACKEND", "nccl")
+    transport = os.environ.get("PWN_BENCH_TRANSPORT", "rccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
+        # control plane (the group id, barriers, the max over ranks): gloo.  The data path is the
+        # library's own RCCL communicator (ncclSend / ncclRecv over xGMI), not torch's.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        tmo = datetime.timedelta(seconds=180)       # a stuck collective should fail the run, not hang it
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
 
     w, h = args.width, args.height
     level_file = os.path.join(GOLD, "levels", args.level + ".txt")
@@ -207,6 +203,7 @@ def main():
     r = pwnfps_amd.Renderer(w, h, device=local)
     r.level_load(level_file)
     r.set_objects(spheres)
+    r.set_blur_passes(args.blur)
     if args.scheduler:
         r.set_scheduler(args.scheduler)
     r.set_frame_timing(max(1, args.time_every))
@@ -214,118 +211,90 @@ def main():
     cam = pwnfps_amd.spawn_camera(spawn)            # main.c:61-64
     sec = 0.0
 
-    fr = RowTiledFrame(w, h, HipStripBackend(r), dev, rank=rank, world=world, blur_passes=args.blur, exchange=args.exchange)
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # per-launch timing of the dominant (trace) kernel: HIP events on the stream
-    # the kernel is launched on (torch's current stream), inside the timed region
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    be = fr.backend
-    real_trace = be.trace_rows
-    slot = {"i": -1}
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    def timed_trace(*a):
-        i = slot["i"]
-        if i >= 0:
-            ev[i][0].record()
-        real_trace(*a)
-        if i >= 0:
-            ev[i][1].record()
-    be.trace_rows = timed_trace
-
-    # N = 1: frames back to back.  N > 1: frames in flight (dist.py): the RCCL
-    # all-gather / gather of frame i overlap the kernels of frame i+1; all K frames
-    # are complete (flush) before the closing barrier.
-    pipelined = world > 1 and args.blur <= 1 and not args.no_pipeline
-    out = None
     nres = max(1, min(args.resident_slots, 4))
+    tinfo = None
     if world == 1:
-        r.set_blur_passes(args.blur)
         r.frames_config(nres, sbuf=False)
-        for i in range(args.warmup):
-            r.submit_frame(cam, sec, 0)
-            r.wait_frame(0)
-    elif pipelined:
-        for _ in range(args.warmup):          # same loop as the timed one: second buffer set, RCCL channels
-            fr.submit(cam, sec)
-        out = fr.flush()
     else:
-        for _ in range(args.warmup):
-            out = fr.render(cam, sec)
-    # every step re-bins and re-uploads the spheres first, like the reference's frame loop does
-    # (level_prepare_render, main.c:95), although this benchmark's spheres do not move
-    def block():
-        """exactly K steps between barrier + synchronize; seconds, max over ranks"""
-        nonlocal out
-        barrier()
-        t0 = time.perf_counter()
+        uid = [pwnfps_amd.Renderer.tiled_unique_id(transport) if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        r.tiled_init(rank, world, uid[0], transport, args.halo)
+        tinfo = r.tiled_info()
+
+    launch_ms = []
+    last = {"f": None}
+
+    # Every step re-bins and re-uploads the spheres first, like the reference's frame loop does
+    # (level_prepare_render, main.c:95), although this benchmark's spheres do not move.
+    def run(n):
+        """n frames back to back; nothing is handed to the host"""
+        def note(f):
+            if f["timed"]:
+                launch_ms.append(f["trace_ms"])
+            last["f"] = f
         if world == 1:
-            # frames back to back, resident (nothing is handed to the host): submit K frames into
-            # the slot ring; the blur of frame i runs beside the trace of frame i+1
-            for i in range(args.steps):
+            # N = 1: the slot ring of the frames API, frames stay on the device
+            for i in range(n):
                 k = i % nres
                 if i >= nres:
-                    f = r.wait_frame(k)
-                    if f["timed"]:
-                        launch_ms.append(f["trace_ms"])
+                    note(r.wait_frame(k))
                 r.set_objects(spheres)
                 r.submit_frame(cam, sec, k)
-            for i in range(max(0, args.steps - nres), args.steps):
-                last = r.wait_frame(i % nres)
-                if last["timed"]:
-                    launch_ms.append(last["trace_ms"])
-            out = last
-        elif pipelined:
-            for i in range(args.steps):
-                slot["i"] = i
-                r.set_objects(spheres)
-                fr.submit(cam, sec)
-            slot["i"] = -1
-            out = fr.flush()
+            for i in range(max(0, n - nres), n):
+                note(r.wait_frame(i % nres))
         else:
-            for i in range(args.steps):
-                slot["i"] = i
+            # N > 1: two frames in flight; the exchange of frame i carries the result of frame i-1
+            for i in range(n):
                 r.set_objects(spheres)
-                out = fr.render(cam, sec)
-            slot["i"] = -1
-        barrier()
-        dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        return float(tmax.item())
+                r.tiled_submit(cam, sec)
+                if i >= 1:
+                    note(r.tiled_wait())
+            if n:
+                note(r.tiled_wait())
 
-    block_s, launch_ms = [], []
+    def block():
+        """exactly K steps between barrier + synchronize; seconds, max over ranks"""
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps)
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    run(args.warmup)
+    launch_ms.clear()
+    block_s = []
     while True:
         block_s.append(block())
-        if world > 1:
-            launch_ms.extend(a.elapsed_time(b) for a, b in ev)
         # all ranks see the same (max-reduced) times, so they stop together
         if sum(block_s) >= args.min_time or len(block_s) >= 500:
             break
     dt = float(np.median(block_s))
-    trace_ms = float(np.mean(launch_ms)) if launch_ms else 0.0
-    tr = torch.tensor([trace_ms], dtype=torch.float64, device=dev)
+    trace_ms = max_over_ranks(float(np.mean(launch_ms)) if launch_ms else 0.0)
     if world > 1:
-        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
-    trace_ms = float(tr.item())
+        tinfo = r.tiled_info()
+        redone = max_over_ranks(float(tinfo["frames_redone"]))
 
     # ---- outside the timed region: parity of the last frame, work counters ----
     parity = None
     frame_hash = None
-    if rank == 0 and out is not None:
+    oracle = None
+    if rank == 0 and last["f"] is not None:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         try:
             import oracle  # checker only: FNV of the frame vs the compiled reference's golden
-            if world == 1:
-                frame_hash = oracle.fnv64(r.read_plane(out["d_sbuf"]))
-            else:
-                frame_hash = oracle.fnv64(fr.to_host(out))
+            frame_hash = oracle.fnv64(r.read_plane(last["f"]["d_sbuf"]))
             with open(os.path.join(GOLD, "frames.json")) as f:
                 cases = json.load(f)["cases"]
             want = [c for c in cases if c["level"] == args.level and (c["w"], c["h"]) == (w, h)
@@ -337,9 +306,9 @@ def main():
 
     counters = None
     pcie = None
+    kernel_ms = None
     if world == 1:
         r.set_counters(True)
-        r.set_blur_passes(args.blur)
         sb = np.empty((h, w), np.uint32)
         r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
         st = r.stats()
@@ -365,20 +334,20 @@ def main():
             r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
             blocking_best = min(blocking_best, time.perf_counter() - t1)
         st = r.stats()                     # kernel times of an uncounted frame
+        kernel_ms = {"trace": round(st["trace_ms"], 4), "blur": round(st["blur_ms"], 4)}
         # The metric as SURVEY.md 8(d) words it: every frame handed over to the host.  Same
         # step as above (re-bin + upload, trace, blur) plus the D2H into the library's pinned
         # sbuf, `slots` frames in flight; the same K-step blocks, median block.
         nsl = max(2, min(args.slots, 4))
         r.frames_config(nsl, sbuf=True)
-        last = None
+        held = {"f": None}
 
         def d2h_block(n):
-            nonlocal last
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for f in range(n + nsl - 1):
                 if f >= nsl - 1:
-                    last = r.wait_frame((f - nsl + 1) % nsl)
+                    held["f"] = r.wait_frame((f - nsl + 1) % nsl)
                 if f < n:
                     r.set_objects(spheres)
                     r.submit_frame(cam, sec, f % nsl)
@@ -389,8 +358,8 @@ def main():
             d2h_s.append(d2h_block(args.steps))
         d2h_dt = float(np.median(d2h_s))
         d2h_ok = None
-        if parity is not None:
-            d2h_ok = bool(oracle.fnv64(last["sbuf"]) == frame_hash)
+        if oracle is not None and frame_hash is not None:
+            d2h_ok = bool(oracle.fnv64(held["f"]["sbuf"]) == frame_hash)
         pcie = {"value": round(w * h * args.steps / d2h_dt / 1e6, 3), "unit": "Mpixels/s",
                 "ms_per_step": round(d2h_dt / args.steps * 1e3, 4), "frames_in_flight": nsl,
                 "blocks": len(d2h_s), "block_ms_p10_p50_p90": [round(float(np.percentile(d2h_s, q)) * 1e3, 3) for q in (10, 50, 90)],
@@ -401,13 +370,15 @@ def main():
                 "what": "set_objects + pwn_submit_frame / pwn_wait_frame: trace + blur + D2H of sbuf into pinned host memory; "
                         "blocking_call = one pwn_trace_screen_centred into pageable memory at a time"}
         r.frames_config(0)
-        kernel_ms = {"trace": round(st["trace_ms"], 4), "blur": round(st["blur_ms"], 4)}
-    else:
-        kernel_ms = None
 
     if rank == 0:
         pix = w * h
-        strip_pix = (fr.y1 - fr.y0) * w
+        if world == 1:
+            strip_pix, par = pix, "rows/1, %d frames in flight" % nres
+        else:
+            strip_pix = (tinfo["y1"] - tinfo["y0"]) * w
+            par = "rows/%d, one grouped %s send/recv per frame (%s + gather of the previous frame's strips), 2 frames in flight" % (
+                world, transport.upper(), ("%d halo rows per neighbour" % tinfo["halo_rows"]) if tinfo["halo_rows"] else "whole pre-blur strips to every rank")
         achieved = TRACE_BYTES_PER_PIXEL * strip_pix / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         line = {
             "metric": "Mpixels/s at 3840x2160 (level.txt scene, trace + blur), mean steps/ray alongside",
@@ -418,10 +389,9 @@ def main():
             "timing": {"blocks_of_k_steps": len(block_s), "value_is": "median block",
                        "block_ms_p10_p50_p90": [round(float(np.percentile(block_s, q)) * 1e3, 4) for q in (10, 50, 90)],
                        "first_block_ms": round(block_s[0] * 1e3, 4),
-                       "trace_launch_ms_p10_p50_p90": [round(float(np.percentile(launch_ms, q)), 4) for q in (10, 50, 90)],
+                       "trace_launch_ms_p10_p50_p90": [round(float(np.percentile(launch_ms, q)), 4) for q in (10, 50, 90)] if launch_ms else None,
                        "launches_timed": len(launch_ms),
-                       "launches_timed_are": "every %d-th frame of the timed region (HIP events on the launch stream)" % max(1, args.time_every)
-                       if world == 1 else "every launch"},
+                       "launches_timed_are": "every %d-th frame of the timed region (HIP events on the launch stream)" % max(1, args.time_every)},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -430,12 +400,8 @@ def main():
             "config": {"workload": "pwnfps level.txt scene (14 game.lua spheres, spawn pose, sec_current=0), "
                                    "%dx%d, POSTPROC_BLUR=%d, one frame per step" % (w, h, args.blur),
                        "level": args.level, "width": w, "height": h, "blur_passes": args.blur,
-                       "parallelism": "rows/%d" % world + ("" if world == 1 else
-                                                            (" + RCCL %sgather(strips)" % ("" if not args.blur else
-                                                                                          "halo exchange (%d rows, all-to-all) + " % fr.halo if fr.halo
-                                                                                          else "all-gather(pre-blur) + "))
-                                                            + (", 2 frames in flight" if pipelined else "")),
-                       "halo_fallbacks": fr.halo_misses},
+                       "parallelism": par,
+                       "frames_repeated_with_whole_strips": int(redone) if world > 1 else 0},
             "roofline": {"bound": "hbm", "kernel": "pwn_trace_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic("pwn_trace_kernel", w, h) if world == 1 else None,
@@ -457,6 +423,9 @@ def main():
             "parity_vs_reference_golden": parity,
             "frame_fnv64": frame_hash,
         }
+        if world > 1:
+            line["tiling"] = {k: tinfo[k] for k in ("rows_per_rank", "halo_rows", "groups", "frames", "frames_redone", "bytes_sent", "bytes_received")}
+            line["tiling"]["transport"] = transport
         if counters:
             line["work"] = counters
         if kernel_ms:
@@ -467,6 +436,9 @@ def main():
             line["cpu_baseline"] = cpu_baseline(w, h, cam, spheres, level_file)
         print(json.dumps(line), flush=True)
 
+    if world > 1:
+        barrier()
+        r.tiled_shutdown()
     r.close()
     if world > 1:
         dist.destroy_process_group()

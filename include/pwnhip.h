@@ -228,6 +228,57 @@ int pwn_blur_rows_device(pwn_ctx *ctx, int y0, int y1, const void *d_pre,
 int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre,
 	const void *d_zbuf, void *d_out, int avail_y0, int avail_y1, void *d_miss, void *stream);
 
+/*
+ * Row tiling behind the ABI: the choreography of the strip forms with the exchange done by
+ * the library -- RCCL over xGMI, one grouped ncclSend/ncclRecv launch per frame.  One
+ * process per GPU, each with its own context of the FULL frame size; every rank makes the
+ * same calls in the same order (level and sphere uploads included: tables are per rank).
+ *   pwn_tiled_unique_id  rank 0: the id of the group (an ncclUniqueId for PWN_TRANSPORT_RCCL);
+ *                        the host hands its 128 bytes to the other ranks (a file, a pipe, MPI ...)
+ *   pwn_tiled_init       collective.  Rank r owns rows [r*per, (r+1)*per), per = ceil(h/world)
+ *                        rounded up to 8 (the OpenMP loops of screen.h:63,77 split by rows).
+ *                        halo_rows: pre-blur rows exchanged with each neighbour strip; < 0 = default
+ *                        (depth 24: 0.002*h*24 + 2 rows, screen.h:100-102), 0 = every strip to
+ *                        everybody (an all-gather).  The blur counts taps that leave the halo; a frame
+ *                        with such a tap is repeated with whole strips before it is delivered, and
+ *                        whole strips are used from then on: delivered frames are always exact.
+ *                        POSTPROC_BLUR 0 or 1.
+ *   pwn_tiled_submit     enqueue one frame on every rank: trace own strip, ONE grouped exchange
+ *                        (this frame's halo rows + the previous frame's finished strips to rank 0 +
+ *                        its miss words), blur own strip.  At most two frames in flight (PWN_EBUSY).
+ *   pwn_tiled_wait       every rank: block until the oldest frame in flight is complete; on rank 0
+ *                        out->d_sbuf is the full frame on the device (valid until two more frames
+ *                        were submitted) and, with PWN_TILED_HOST, out->sbuf a pinned host copy.
+ *   pwn_tiled_shutdown   collective; pwn_destroy does it too.
+ * PWN_TRANSPORT_SHM moves the same messages through POSIX shared memory instead: for tests
+ * on a box with one GPU, where RCCL cannot run two ranks; the ranks may share a device.
+ */
+#define PWN_TILED_ID_BYTES 128
+#define PWN_TRANSPORT_RCCL 0
+#define PWN_TRANSPORT_SHM  1
+#define PWN_TILED_HOST     1
+typedef struct pwn_tiled_frame
+{
+	const void *d_sbuf;          /* rank 0: the frame on the device, BGRA8, pitch = width; NULL elsewhere */
+	const uint32_t *sbuf;        /* rank 0 with PWN_TILED_HOST: pinned host copy                          */
+	uint64_t seq;                /* 1, 2, ... in submission order */
+	int redone;                  /* 1: a tap left the halo and the frame was repeated with whole strips */
+	int timed;                   /* PWN_OPT_FRAME_TIMING sampled this frame: */
+	float trace_ms, frame_ms;    /*   this rank's trace kernel; its trace .. blur incl. waiting for the exchange */
+} pwn_tiled_frame;
+typedef struct pwn_tiled_info
+{
+	int rank, world, y0, y1, rows_per_rank, halo_rows, transport;
+	uint64_t frames, frames_redone, groups;        /* delivered frames; repeated ones; grouped exchanges launched */
+	uint64_t bytes_sent, bytes_received;           /* by this rank */
+} pwn_tiled_info;
+int pwn_tiled_unique_id(void *id128, int transport);
+int pwn_tiled_init(pwn_ctx *ctx, int rank, int world, const void *id128, int transport, int halo_rows);
+int pwn_tiled_submit(pwn_ctx *ctx, const float cam[16], float sec_current);
+int pwn_tiled_wait(pwn_ctx *ctx, int flags, pwn_tiled_frame *out);
+int pwn_tiled_get_info(pwn_ctx *ctx, pwn_tiled_info *out);
+void pwn_tiled_shutdown(pwn_ctx *ctx);
+
 /* screen_upscale (screen.h:126-149): replicate every pixel scale x scale into
    a surface of `pitch_bytes` per row (SDL_Surface->pitch / ->pixels).
    Host form (uploads sbuf... uses the last frame on the device if src is NULL)

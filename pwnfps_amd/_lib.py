@@ -43,6 +43,20 @@ class Frame(C.Structure):
                 ("seq", C.c_uint64)]
 
 
+class TiledFrame(C.Structure):
+    _fields_ = [("d_sbuf", C.c_void_p), ("sbuf", C.c_void_p), ("seq", C.c_uint64), ("redone", C.c_int),
+                ("timed", C.c_int), ("trace_ms", C.c_float), ("frame_ms", C.c_float)]
+
+
+class TiledInfo(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("rank", "world", "y0", "y1", "rows_per_rank", "halo_rows", "transport")] + \
+               [(n, C.c_uint64) for n in ("frames", "frames_redone", "groups", "bytes_sent", "bytes_received")]
+
+
+PWN_TILED_ID_BYTES = 128
+PWN_TRANSPORT_RCCL, PWN_TRANSPORT_SHM = 0, 1
+PWN_TILED_HOST = 1
+
 # every symbol include/pwnhip.h declares: (name, restype, argtypes)
 _vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
 ABI = [
@@ -72,6 +86,12 @@ ABI = [
     ("pwn_trace_rows_device", _i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
     ("pwn_blur_rows_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("pwn_blur_rows_device_bounded", _i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    ("pwn_tiled_unique_id", _i, [_vp, _i]),
+    ("pwn_tiled_init", _i, [_vp, _i, _i, _vp, _i, _i]),
+    ("pwn_tiled_submit", _i, [_vp, _vp, _f]),
+    ("pwn_tiled_wait", _i, [_vp, _i, C.POINTER(TiledFrame)]),
+    ("pwn_tiled_get_info", _i, [_vp, C.POINTER(TiledInfo)]),
+    ("pwn_tiled_shutdown", None, [_vp]),
     ("pwn_screen_upscale", _i, [_vp, _vp, _i, _i, _vp]),
     ("pwn_upscale_device", _i, [_vp, _vp, _i, _i, _vp, _vp]),
     ("pwn_get_stats", _i, [_vp, C.POINTER(Stats)]),

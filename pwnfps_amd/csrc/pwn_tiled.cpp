@@ -213,6 +213,7 @@ struct pwn_tiled
 {
 	int rank, world, per, y0, y1;
 	int halo;                           // rows exchanged with each neighbour; 0 = whole strips to everybody
+	int fhalo[2];                       // ... as used for the frame in that slot (the mode changes after a miss)
 	pwn_transport *tp;
 	hipStream_t comm;
 	uint32_t *pre[2], *out[2], *fin[2]; float *z[2];       // full-frame planes per frame slot (fin: rank 0)
@@ -220,7 +221,8 @@ struct pwn_tiled
 	uint32_t *h_missv;                  // pinned
 	uint32_t *h_frame;                  // pinned host copy of a delivered frame (rank 0, PWN_TILED_HOST)
 	hipEvent_t ev_t[2], ev_x[2], ev_b[2];
-	bool has_x[2], has_b[2];
+	hipEvent_t ev_k0[2], ev_k1[2], ev_k2[2];      // timing (PWN_OPT_FRAME_TIMING): around the trace, behind the blur
+	bool has_x[2], has_b[2], timed[2];
 	unsigned long long submitted, gathered, delivered;
 	pwn_tiled_info info;
 };
@@ -267,6 +269,9 @@ void pwn_tiled_destroy(pwn_ctx *c)
 		if(t->ev_t[s]) (void)hipEventDestroy(t->ev_t[s]);
 		if(t->ev_x[s]) (void)hipEventDestroy(t->ev_x[s]);
 		if(t->ev_b[s]) (void)hipEventDestroy(t->ev_b[s]);
+		if(t->ev_k0[s]) (void)hipEventDestroy(t->ev_k0[s]);
+		if(t->ev_k1[s]) (void)hipEventDestroy(t->ev_k1[s]);
+		if(t->ev_k2[s]) (void)hipEventDestroy(t->ev_k2[s]);
 	}
 	if(t->h_missv) (void)hipHostFree(t->h_missv);
 	if(t->h_frame) (void)hipHostFree(t->h_frame);
@@ -347,10 +352,32 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 			   (rank == 0 && hipMemset(t->fin[s], 0, n * 4) != hipSuccess)) { rc = PWN_EHIP; break; }
 			if(hipEventCreateWithFlags(&t->ev_t[s], hipEventDisableTiming) != hipSuccess ||
 			   hipEventCreateWithFlags(&t->ev_x[s], hipEventDisableTiming) != hipSuccess ||
-			   hipEventCreateWithFlags(&t->ev_b[s], hipEventDisableTiming) != hipSuccess) { rc = PWN_EHIP; break; }
+			   hipEventCreateWithFlags(&t->ev_b[s], hipEventDisableTiming) != hipSuccess ||
+			   hipEventCreate(&t->ev_k0[s]) != hipSuccess || hipEventCreate(&t->ev_k1[s]) != hipSuccess ||
+			   hipEventCreate(&t->ev_k2[s]) != hipSuccess) { rc = PWN_EHIP; break; }
 		}
 		if(rc != PWN_OK) break;
 		if(hipHostMalloc((void **)&t->h_missv, (size_t)world * 4 + 64, hipHostMallocDefault) != hipSuccess) { rc = PWN_ENOMEM; break; }
+		// one round trip through the transport before the first frame depends on it: every rank sends a
+		// word to its right-hand neighbour (to itself when alone) and checks what arrives from the left
+		{
+			const int to = (rank + 1) % world, from = (rank + world - 1) % world;
+			const uint32_t mine = 0x50574e00u + (uint32_t)rank, want = 0x50574e00u + (uint32_t)from;
+			uint32_t got = 0;
+			if(hipMemcpy(t->missw[0], &mine, 4, hipMemcpyHostToDevice) != hipSuccess) { rc = PWN_EHIP; break; }
+			if(t->tp->begin(t->comm) != PWN_OK || t->tp->send(t->missw[0], 4, to) != PWN_OK ||
+			   t->tp->recv(t->missv[0], 4, from) != PWN_OK || t->tp->end() != PWN_OK)
+			{
+				snprintf(c->err, sizeof(c->err), "%s transport: %s", t->tp->name(), t->tp->err); rc = PWN_EHIP; break;
+			}
+			if(hipStreamSynchronize(t->comm) != hipSuccess || hipMemcpy(&got, t->missv[0], 4, hipMemcpyDeviceToHost) != hipSuccess ||
+			   hipMemset(t->missw[0], 0, 4) != hipSuccess || hipMemset(t->missv[0], 0, 4) != hipSuccess) { rc = PWN_EHIP; break; }
+			if(got != want)
+			{
+				snprintf(c->err, sizeof(c->err), "%s transport: the test word from rank %d arrived as %08x", t->tp->name(), from, got);
+				rc = PWN_EHIP; break;
+			}
+		}
 	} while(0);
 	if(rc != PWN_OK) { char keep[256]; memcpy(keep, c->err, sizeof(keep)); pwn_tiled_destroy(c); memcpy(c->err, keep, sizeof(keep)); return rc; }
 	t->info.rank = rank; t->info.world = world; t->info.y0 = t->y0; t->info.y1 = t->y1; t->info.rows_per_rank = t->per;
@@ -391,7 +418,7 @@ static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 		TPCHK(c, t->tp->send(mine + (size_t)t->y0 * c->w, (size_t)(t->y1 - t->y0) * w4, 0));
 		t->info.bytes_sent += (unsigned long long)(t->y1 - t->y0) * w4;
 	}
-	if(t->halo)
+	if(t->fhalo[s])
 		for(int r = 0; r < t->world; r++)
 		{
 			if(r == t->rank) continue;
@@ -425,13 +452,17 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	const int s = (int)(f & 1);
 	const size_t w4 = (size_t)c->w * 4;
 	hipStream_t cs = c->stream;
+	t->fhalo[s] = t->halo;
 	// pre[s] / z[s] / out[s] were last used by frame f-2: its blur ran on this stream; its strips went
 	// out in G(f-1) and in the gather of G(f-1) or of the drain group -- all before ev_x of the other slot
 	if(t->has_x[s ^ 1]) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s ^ 1], 0));
 	if(t->has_x[s]) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
 	uint32_t *plane = c->blur_passes ? t->pre[s] : (t->rank == 0 ? t->fin[s] : t->pre[s]);
+	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
+	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
 	int rc = pwn_i_launch_trace(c, cam, sec, t->y0, t->y1, plane, t->z[s], cs);
 	if(rc != PWN_OK) return rc;
+	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
 	HIPCHK(c, hipMemsetAsync(t->missw[s], 0, 4, cs));
 	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
 
@@ -483,6 +514,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 		else rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL);
 		if(rc != PWN_OK) return rc;
 	}
+	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k2[s], cs));
 	HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
 	t->has_b[s] = true;
 	t->submitted = f + 1;
@@ -521,7 +553,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 
 	// ---- was the bounded halo enough for this frame, on every rank?
 	bool miss = false;
-	if(t->halo)
+	if(t->fhalo[s])
 	{
 		HIPCHK(c, hipMemcpy(t->h_missv, t->missv[s], (size_t)t->world * 4, hipMemcpyDeviceToHost));
 		uint32_t own = 0;
@@ -534,7 +566,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		// Every rank sees the same words and comes here together: the frame's exchange again with
 		// whole strips (pre[s] and z[s] still hold this frame), blur, gather; whole strips from now on.
 		t->info.frames_redone++;
-		t->halo = 0;
+		t->halo = 0; t->fhalo[s] = 0;
 		hipStream_t cs = c->stream;
 		TPCHK(c, t->tp->begin(cs));
 		int rc = add_allgather(c, t, s);
@@ -557,6 +589,12 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		memset(out, 0, sizeof(*out));
 		out->seq = d + 1;
 		out->redone = miss ? 1 : 0;
+		out->timed = t->timed[s] ? 1 : 0;
+		if(t->timed[s])
+		{
+			(void)hipEventElapsedTime(&out->trace_ms, t->ev_k0[s], t->ev_k1[s]);
+			(void)hipEventElapsedTime(&out->frame_ms, t->ev_k0[s], t->ev_k2[s]);      // trace .. blur, the exchange in between
+		}
 		if(t->rank == 0)
 		{
 			out->d_sbuf = t->fin[s];

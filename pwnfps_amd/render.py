@@ -216,6 +216,44 @@ class Renderer:
                                                    C.c_void_p(d_out), int(avail_y0), int(avail_y1), C.c_void_p(d_miss),
                                                    C.c_void_p(stream)), "pwn_blur_rows_device_bounded")
 
+    # -- row tiling over the GPUs of a node (one process per GPU; RCCL inside the library) ----
+    @staticmethod
+    def tiled_unique_id(transport="rccl"):
+        """rank 0: 128 bytes to hand to the other ranks"""
+        buf = C.create_string_buffer(_lib.PWN_TILED_ID_BYTES)
+        rc = lib.pwn_tiled_unique_id(buf, _lib.PWN_TRANSPORT_SHM if transport == "shm" else _lib.PWN_TRANSPORT_RCCL)
+        if rc != 0:
+            raise PwnError(rc, "pwn_tiled_unique_id(%s)" % transport)
+        return buf.raw
+
+    def tiled_init(self, rank, world, uid, transport="rccl", halo_rows=-1):
+        self._chk(lib.pwn_tiled_init(self._ctx, int(rank), int(world), C.c_char_p(uid),
+                                     _lib.PWN_TRANSPORT_SHM if transport == "shm" else _lib.PWN_TRANSPORT_RCCL, int(halo_rows)),
+                  "pwn_tiled_init(rank %d of %d, %s)" % (rank, world, transport))
+
+    def tiled_submit(self, cam, sec_current=0.0):
+        cam = np.ascontiguousarray(cam, np.float32).reshape(16)
+        self._chk(lib.pwn_tiled_submit(self._ctx, cam.ctypes.data, float(sec_current)), "pwn_tiled_submit")
+
+    def tiled_wait(self, host=False):
+        """Oldest frame in flight.  Rank 0: dict with d_sbuf (device pointer) and, with host=True,
+        sbuf (numpy view of the pinned copy); other ranks: dict without them."""
+        fr = _lib.TiledFrame()
+        self._chk(lib.pwn_tiled_wait(self._ctx, _lib.PWN_TILED_HOST if host else 0, C.byref(fr)), "pwn_tiled_wait")
+        out = {"seq": fr.seq, "redone": bool(fr.redone), "d_sbuf": fr.d_sbuf, "timed": bool(fr.timed),
+               "trace_ms": fr.trace_ms, "frame_ms": fr.frame_ms}
+        if fr.sbuf:
+            out["sbuf"] = np.ctypeslib.as_array(C.cast(fr.sbuf, C.POINTER(C.c_uint32)), shape=(self.w * self.h,)).reshape(self.h, self.w)
+        return out
+
+    def tiled_info(self):
+        inf = _lib.TiledInfo()
+        self._chk(lib.pwn_tiled_get_info(self._ctx, C.byref(inf)), "pwn_tiled_get_info")
+        return {n: getattr(inf, n) for n, _ in _lib.TiledInfo._fields_}
+
+    def tiled_shutdown(self):
+        lib.pwn_tiled_shutdown(self._ctx)
+
     # -- sink (screen.h:126-149) ----------------------------------------------
     def screen_upscale(self, sbuf, scale, pitch_bytes=None, pixels=None):
         scale = int(scale)

@@ -1,0 +1,48 @@
+"""bench.py with 2 and 3 ranks, the way the driver starts it (torch.distributed.run, one process per
+rank), on the one GPU of the test box: PWN_BENCH_ONE_DEVICE=1 puts every rank on device 0 and
+PWN_BENCH_TRANSPORT=shm replaces RCCL (which cannot run two ranks on one device) by the shared
+memory transport; process group, id broadcast, pwn_tiled_* with HIP strip kernels, frames in
+flight and the JSON line are the real thing.  The last frame of the timed loop must be the
+compiled reference's golden frame."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,size,golden", [(2, (3840, 2160), "a95833dac9624326"), (3, (1280, 720), "078fb94a5cd068f5")])
+def test_bench_with_ranks_on_one_device(world, size, golden):
+    env = dict(os.environ)
+    env.update(PWN_BENCH_ONE_DEVICE="1", PWN_BENCH_TRANSPORT="shm", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--min-time", "0.2",
+           "--width", str(size[0]), "--height", str(size[1])]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 6 and d["value"] > 0
+    assert d["frame_fnv64"] == golden
+    if size == (3840, 2160):
+        assert d["parity_vs_reference_golden"] is True
+    t = d["tiling"]
+    assert t["transport"] == "shm" and t["frames_redone"] == 0 and t["halo_rows"] > 0
+    assert d["config"]["frames_repeated_with_whole_strips"] == 0
+    assert d["roofline"]["pixels_per_launch"] == t["rows_per_rank"] * size[0]

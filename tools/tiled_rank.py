@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""One rank of a row-tiled run through the C ABI (pwn_tiled_*): the program the multi-process
+tests and experiments start once per rank.
+
+    python3 tools/tiled_rank.py RANK WORLD IDFILE TRANSPORT W H LEVEL FRAMES [HALO [DEVICE]]
+
+Rank 0 creates the group id and writes it to IDFILE (.tmp + rename); the others wait for the
+file.  Every frame has its own camera, sec_current and sphere set (tools/tiled_rank.scene), so a
+frame that is delivered late or from the wrong buffers shows.  Rank 0 prints one line per frame:
+    frame K fnv64 HASH redone R
+and every rank a line `info {...}` (pwn_tiled_info)."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def scene(k, base, spawn):
+    """frame k of the test sequence: camera, sec_current, spheres"""
+    import pwnfps_amd
+    sph = base.copy()
+    sph["x"] += np.float32(0.09 * k)
+    if k:                                   # frame 0 is the reference's own scene at t = 0 (golden hashes exist)
+        sph["cb"] = np.float32(0.3 + 0.1 * (k % 4))
+    if k % 3 == 1:
+        sph = sph[:max(1, len(sph) - 2)]
+    return pwnfps_amd.spawn_camera(spawn, ang_y=0.21 * k, ang_x=0.03 * k), 0.1 * k, sph
+
+
+def main():
+    rank, world = int(sys.argv[1]), int(sys.argv[2])
+    idfile, transport = sys.argv[3], sys.argv[4]
+    w, h, level, frames = int(sys.argv[5]), int(sys.argv[6]), sys.argv[7], int(sys.argv[8])
+    halo = int(sys.argv[9]) if len(sys.argv) > 9 else -1
+    device = int(sys.argv[10]) if len(sys.argv) > 10 else 0
+    import pwnfps_amd
+    import oracle  # checker: the frame hash only
+    gold = os.path.join(ROOT, "tests", "golden")
+    r = pwnfps_amd.Renderer(w, h, device=device)
+    r.level_load(os.path.join(gold, "levels", level + ".txt"))
+    base = np.load(os.path.join(gold, "spheres_t0.npy" if level == "pwnfps_level" else os.path.join("levels", level + "_spheres.npy")))
+    _, _, spawn = r.get_level()
+    if os.environ.get("TILED_BLUR") is not None:
+        r.set_blur_passes(int(os.environ["TILED_BLUR"]))
+    if rank == 0:
+        uid = pwnfps_amd.Renderer.tiled_unique_id(transport)
+        with open(idfile + ".tmp", "wb") as f:
+            f.write(uid)
+        os.rename(idfile + ".tmp", idfile)
+    else:
+        t0 = time.time()
+        while not os.path.exists(idfile):
+            if time.time() - t0 > 120:
+                sys.exit("rank %d: no id file" % rank)
+            time.sleep(0.01)
+        uid = open(idfile, "rb").read()
+    r.tiled_init(rank, world, uid, transport, halo)
+
+    def deliver(k):
+        fr = r.tiled_wait(host=True)
+        assert fr["seq"] == k + 1
+        if rank == 0:
+            print("frame %d fnv64 %s redone %d" % (k, oracle.fnv64(fr["sbuf"]), int(fr["redone"])), flush=True)
+    for k in range(frames):
+        cam, sec, sph = scene(k, base, spawn)
+        r.set_objects(sph)
+        r.tiled_submit(cam, sec)
+        if k >= 1:
+            deliver(k - 1)
+    deliver(frames - 1)
+    print("info " + json.dumps(r.tiled_info()), flush=True)
+    r.tiled_shutdown()
+    r.close()
+
+
+if __name__ == "__main__":
+    main()
