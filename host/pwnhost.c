@@ -18,6 +18,10 @@
  *
  * -t fixes the clock step (the reference uses wall time, main.c:112-114), which
  * makes a run reproducible; -v 1 prints every frame's hash.
+ * -W WORLD -R RANK -I IDFILE [-T rccl|shm] row-tiles every frame over WORLD processes, one per
+ * GPU (pwn_tiled_*: RCCL inside the library): start the same command once per rank with its
+ * -R (and -d DEVICE); rank 0 writes the group id to IDFILE, the others wait for it; rank 0
+ * presents the frames.  -H ROWS sets the halo (default -1 = depth 24, 0 = whole strips).
  * -q SLOTS (2..4) keeps that many frames in flight (pwn_submit_frame /
  * pwn_wait_frame): the frame and its upscaled surface arrive in the library's
  * pinned host buffers while the next frame's kernels run; frame f is presented
@@ -123,6 +127,8 @@ int main(int argc, char **argv)
 {
 	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL;
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
+	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL;
+	const char *idfile = NULL;
 	float turn = 0.0f, fixed_dt = -1.0f;
 	for(int i = 1; i < argc; i++)
 	{
@@ -144,13 +150,24 @@ int main(int argc, char **argv)
 			case 'o': out = argv[++i]; break;
 			case 'd': device = atoi(argv[++i]); break;
 			case 'q': slots = atoi(argv[++i]); break;
+			case 'W': world = atoi(argv[++i]); break;
+			case 'R': rank = atoi(argv[++i]); break;
+			case 'I': idfile = argv[++i]; break;
+			case 'H': halo = atoi(argv[++i]); break;
+			case 'T': transport = strcmp(argv[++i], "shm") == 0 ? PWN_TRANSPORT_SHM : PWN_TRANSPORT_RCCL; break;
 			default: fprintf(stderr, "unknown option %s\n", argv[i]); return 2;
 		}
 	}
 	if(level == NULL)
 	{
 		fprintf(stderr, "usage: pwnhost level.txt [-s spheres.txt | -g game_objects.txt] [-w W] [-h H] [-x SCALE] "
-			"[-n FRAMES] [-t SEC_PER_FRAME] [-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE] [-v 1] [-q SLOTS]\n");
+			"[-n FRAMES] [-t SEC_PER_FRAME] [-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE] [-v 1] [-q SLOTS]\n"
+			"       [-W WORLD -R RANK -I IDFILE [-T rccl|shm] [-H HALO_ROWS]]\n");
+		return 2;
+	}
+	if(world < 1 || rank < 0 || rank >= world || (world > 1 && idfile == NULL))
+	{
+		fprintf(stderr, "-W WORLD needs -R RANK (0..WORLD-1) and -I IDFILE\n");
 		return 2;
 	}
 	if(slots != 0 && (slots < 2 || slots > PWN_MAX_SLOTS)) { fprintf(stderr, "-q takes 2..%d\n", PWN_MAX_SLOTS); return 2; }
@@ -191,6 +208,86 @@ int main(int argc, char **argv)
 
 	float ang = 0.0f;
 	double t_first = 0.0, t_rest = 0.0;
+	if(world > 1)
+	{
+		/* the frame loop of main.c:93-140 with every frame row-tiled over `world` processes; two frames in
+		   flight, the present step one frame behind; every rank runs the same loop (and the same script) */
+		unsigned char id[PWN_TILED_ID_BYTES];
+		if(rank == 0)
+		{
+			CHK(pwn_tiled_unique_id(id, transport));
+			char tmp[1024];
+			snprintf(tmp, sizeof(tmp), "%s.tmp", idfile);
+			FILE *fp = fopen(tmp, "wb");
+			if(fp == NULL || fwrite(id, 1, sizeof(id), fp) != sizeof(id)) { fprintf(stderr, "cannot write %s\n", tmp); pwn_destroy(ctx); return 1; }
+			fclose(fp);
+			rename(tmp, idfile);
+		}
+		else
+		{
+			FILE *fp = NULL;
+			for(int tries = 0; tries < 12000 && (fp = fopen(idfile, "rb")) == NULL; tries++)
+			{
+				struct timespec ts = { 0, 10 * 1000 * 1000 };
+				nanosleep(&ts, NULL);
+			}
+			if(fp == NULL || fread(id, 1, sizeof(id), fp) != sizeof(id)) { fprintf(stderr, "rank %d: no group id in %s\n", rank, idfile); pwn_destroy(ctx); return 1; }
+			fclose(fp);
+		}
+		CHK(pwn_tiled_init(ctx, rank, world, id, transport, halo));
+		if(fixed_dt < 0.0f) fixed_dt = 0.0f;
+		pwn_tiled_frame tf;
+		memset(&tf, 0, sizeof(tf));
+		double t0 = now_s(), t1 = t0;
+		for(int f = 0; f <= frames; f++)
+		{
+			if(f < frames)
+			{
+				float cam[16];
+				cam_identity(cam);
+				if(ang != 0.0f) cam_roty(cam, ang);
+				cam[12] = 0.5f + (float)spawn[0]; cam[13] = 0.5f; cam[14] = 0.5f + (float)spawn[1];
+				CHK(pwn_prepare_render(ctx));                                           /* main.c:95 */
+				CHK(pwn_tiled_submit(ctx, cam, sec_current));                          /* main.c:107 */
+			}
+			if(f >= 1)
+			{
+				CHK(pwn_tiled_wait(ctx, PWN_TILED_HOST, &tf));
+				if(rank == 0 && verbose)
+					printf("frame %d sec %.9g fnv64 %016llx\n", f - 1, (double)(fixed_dt * (float)(f - 1)), (unsigned long long)fnv64(tf.sbuf, npix));
+				if(f == 1) t1 = now_s();
+			}
+			if(f < frames)
+			{
+				sec_current += fixed_dt;                                                /* main.c:112-114 */
+				if(gamefile != NULL)
+					CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)fixed_dt));   /* main.c:127-140 */
+				ang += turn;
+			}
+		}
+		double t2 = now_s();
+		pwn_tiled_info inf;
+		CHK(pwn_tiled_get_info(ctx, &inf));
+		printf("rank %d of %d: rows [%d,%d), halo %d rows, %llu frames (%llu repeated with whole strips), %llu grouped exchanges, sent %.1f MB, received %.1f MB\n",
+			inf.rank, inf.world, inf.y0, inf.y1, inf.halo_rows, (unsigned long long)inf.frames, (unsigned long long)inf.frames_redone,
+			(unsigned long long)inf.groups, (double)inf.bytes_sent / 1e6, (double)inf.bytes_received / 1e6);
+		if(rank == 0)
+		{
+			CHK(pwn_screen_upscale(ctx, tf.sbuf, rscale, surface.pitch, surface.pixels));      /* main.c:108 */
+			printf("frame %dx%d x%d: sbuf fnv64 %016llx, surface fnv64 %016llx\n", rwidth, rheight, rscale,
+				(unsigned long long)fnv64(tf.sbuf, npix),
+				(unsigned long long)fnv64(surface.pixels, (size_t)(pitch / 4) * (size_t)rheight * (size_t)rscale));
+			if(frames > 1)
+				printf("tiled loop: %.2f Mpixels/s over %d frames (first frame %.1f ms)\n",
+					(double)npix * (frames - 1) / (t2 - t1) / 1e6, frames - 1, (t1 - t0) * 1e3);
+			if(out != NULL && write_ppm(out, surface.pixels, rwidth * rscale, rheight * rscale, pitch / 4) != 0)
+				fprintf(stderr, "cannot write %s\n", out);
+		}
+		pwn_tiled_shutdown(ctx);
+		pwn_destroy(ctx);
+		free(sph); free(sbuf); free(zbuf); free(surface.pixels);
+		return 0;
+	}
 	if(slots > 0)
 	{
 		/* frames in flight: the loop of main.c:93-140 with the present step SLOTS-1 frames behind */

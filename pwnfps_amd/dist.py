@@ -1,43 +1,49 @@
-"""Row-tiled frames across the GPUs of one node.
+"""Row-tiled frames across the GPUs of a node: the choreography of
+``pwnfps_amd/csrc/pwn_tiled.cpp`` restated over ``torch.distributed`` point-to-point
+operations.
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).
-The reference parallelises the same loops with OpenMP over rows
-(screen.h:63,77); here rank r owns the contiguous strip of rows
+The product path is the C one: ``Renderer.tiled_init / tiled_submit / tiled_wait``
+(``include/pwnhip.h``, RCCL inside the library); ``bench.py --gpus N`` and ``host/pwnhost -n N``
+use it.  This module is the same state machine, statement for statement, with
 
-    [r * rows_per, min((r + 1) * rows_per, h))        rows_per = 8-row multiple
+* the transport = one ``batch_isend_irecv`` per grouped exchange (gloo on CPU, nccl = RCCL on
+  GPUs), and
+* the strip work delegated to a backend with ``trace_rows / blur_rows / blur_rows_bounded``
+  on torch tensors: ``HipStripBackend`` (libpwnhip.so on this rank's GPU) or, in the CPU
+  tests, a checker backend supplied by the test,
 
-The trace pass is independent per pixel.  The blur pass is not strip-local:
-its taps reach +-0.002*h*(depth-1) rows (screen.h:86,100-102), unbounded in
-depth, so every rank needs the whole pre-blur colour frame.  Per frame:
+so that the protocol -- what goes into which group, which buffers a frame owns, when a frame
+whose blur taps left the halo is repeated, and that every rank decides the same -- is covered
+by world_size 2 / 3 / 8 tests without a GPU (tests/test_dist_gloo.py).
 
-    1. trace own strip          -> pre[strip], z[strip]            (HIP kernel)
-    2. exchange pre-blur rows                                      (RCCL)
-         "halo" (default): H rows with each neighbour strip, one all-to-all
-             with zero-length parts for all other ranks; the blur kernel
-             counts taps that land outside [y0-H, y1+H) and, if any rank saw
-             one, the frame is repeated with the whole frame gathered
-         "allgather": every strip to everyone, 4 B/pixel, in place
-    3. blur own strip           -> out[strip]                      (HIP kernel)
-    4. gather out strips to rank 0                                 (RCCL)
+One process per rank; rank r owns rows [r*per, min((r+1)*per, h)), per = ceil(h/world) rounded
+up to 8 (the reference parallelises the same loops with OpenMP over rows, screen.h:63,77).  The
+trace pass needs no exchange.  The blur does: its taps reach 0.002*h*(depth-1) rows
+(screen.h:100-102), unbounded in depth.  Per frame f (slot s = f & 1):
 
-With the blur disabled steps 2-3 vanish.  Why the halo: xGMI is point to point,
-so with 2 GPUs the all-gather and the gather share ONE link and move 2 x 16.6 MB
-per 4K frame - more time than tracing the frame on one GPU; with 8, rank 0 takes
-in 58 MB per frame.  At 4K the taps of level.txt reach 32 rows; H covers depth 24
-(104 rows).  The collectives are the only data exchanged; level and sphere tables
-are uploaded by every rank itself (13 KB).
+    trace strip f -> pre[s], z[s]
+    ONE grouped exchange G(f):
+        the H border rows of strip f to / from the neighbour strips (or, without a halo,
+            every strip to everybody)
+        the FINISHED strip of frame f-1 to rank 0
+        the miss word of frame f-1 to every rank
+    blur strip f from pre[s] rows [y0-H, y1+H) -> out[s]; taps outside those rows are
+        counted in the rank's miss word of frame f
 
-The strip work is delegated to a backend with trace_rows()/blur_rows() on
-torch tensors: HipStripBackend (the product: libpwnhip.so on this rank's GPU)
-or, in the CPU tests, a checker backend supplied by the test itself.
+Frame f-1 is complete on rank 0 when G(f) is (``wait`` issues a group with only the second
+half when no newer frame was submitted).  Every rank then holds every rank's miss word of frame
+f-1: if one is non-zero ALL ranks repeat that frame's exchange with whole strips, its blur and
+its gather before it is delivered, and use whole strips from then on.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
+TAG_HALO, TAG_STRIP, TAG_GATHER, TAG_MISS = 1, 2, 3, 4
+
 
 def strip_rows(h, world):
-    """Rows per strip: h/world rounded up to the 8-row tile height of the trace kernel."""
+    """Rows per strip: h/world rounded up to the 8-row multiple the trace kernel tiles by."""
     per = -(-h // world)
     return -(-per // 8) * 8
 
@@ -46,6 +52,11 @@ def strip_range(h, world, rank):
     per = strip_rows(h, world)
     y0 = min(rank * per, h)
     return y0, min(y0 + per, h)
+
+
+def default_halo(h):
+    """rows that cover blur taps up to depth 24 (pwn_tiled_init's default)"""
+    return int(0.002 * h * 24.0) + 2
 
 
 class HipStripBackend:
@@ -75,13 +86,10 @@ class HipStripBackend:
                                         miss.data_ptr(), self._stream())
 
 
-class RowTiledFrame:
-    """Frame buffers + choreography for one rank.  Buffers are padded to
-    world * rows_per rows so that all strips have equal size for the
-    collectives; rows >= h are never written by the kernels."""
+class TiledFrames:
+    """pwn_tiled_init / _submit / _wait of pwn_tiled.cpp, restated.  Names follow the C code."""
 
-    def __init__(self, w, h, backend, device, rank=None, world=None, blur_passes=1, group=None,
-                 exchange="halo", halo_depth=24.0):
+    def __init__(self, w, h, backend, device, rank=None, world=None, blur_passes=1, halo_rows=-1, group=None):
         self.w, self.h = int(w), int(h)
         self.group = group
         if world is None:
@@ -90,224 +98,155 @@ class RowTiledFrame:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.rank, self.world = rank, world
         self.blur_passes = int(blur_passes)
+        if self.blur_passes > 1:
+            raise ValueError("row tiling supports POSTPROC_BLUR 0 or 1")
         if self.blur_passes > 0 and (self.w & 3):
             raise ValueError("blur needs a width divisible by 4 (screen.h:88)")
         self.backend = backend
         self.per = strip_rows(self.h, world)
-        self.hpad = self.per * world
         self.y0, self.y1 = strip_range(self.h, world, rank)
+        H = default_halo(self.h) if halo_rows < 0 else int(halo_rows)
+        shortest = min(strip_range(self.h, world, r)[1] - strip_range(self.h, world, r)[0] for r in range(world))
+        if world == 1 or self.blur_passes == 0 or H > shortest or H <= 0:
+            H = 0
+        self.halo = H                       # rows exchanged with each neighbour; 0 = whole strips to everybody
+        self.fhalo = [0, 0]                 # ... as used for the frame in that slot
         kw = dict(device=device)
-        # int32 views of the uint32 BGRA pixels (collectives do not care)
-        self.pre = torch.zeros((self.hpad, self.w), dtype=torch.int32, **kw)
-        self.out = torch.zeros((self.hpad, self.w), dtype=torch.int32, **kw)
-        self.z = torch.zeros((self.hpad, self.w), dtype=torch.float32, **kw)
-        self.final = torch.zeros((self.hpad, self.w), dtype=torch.int32, **kw) if rank == 0 else None
-        self.final_z = None
-        # bounded exchange: H rows per neighbour, possible when every strip has at least H rows
-        self.halo = 0
-        self.halo_misses = 0       # frames (render) / flushes (submit) that had to fall back to the all-gather
-        if exchange == "halo" and world > 1 and self.blur_passes == 1:
-            H = int(np.ceil(0.002 * self.h * float(halo_depth))) + 1
-            shortest = min(strip_range(self.h, world, r)[1] - strip_range(self.h, world, r)[0] for r in range(world))
-            if 0 < H <= shortest:
-                self.halo = H
-        elif exchange not in ("halo", "allgather"):
-            raise ValueError("exchange must be 'halo' or 'allgather'")
-        if self.halo:
-            H = self.halo
-            up, dn = rank > 0, rank < world - 1
-            self._peers = (up, dn)
-            self._in_split = [H if (r == rank - 1 or r == rank + 1) else 0 for r in range(world)]
-            self._nrows = H * (int(up) + int(dn))
-            self.avail = (self.y0 - H if up else 0, self.y1 + H if dn else self.h)
-            self._hx = [self._halo_bufs(kw) for _ in range(2)]
+        mk = lambda dt: [torch.zeros((self.h, self.w), dtype=dt, **kw) for _ in range(2)]   # noqa: E731
+        # int32 views of the uint32 BGRA pixels (the transport does not care)
+        self.pre, self.out, self.z = mk(torch.int32), mk(torch.int32), mk(torch.float32)
+        self.fin = mk(torch.int32) if rank == 0 else [None, None]
+        self.missw = [torch.zeros(1, dtype=torch.int32, **kw) for _ in range(2)]
+        self.missv = [torch.zeros(world, dtype=torch.int32, **kw) for _ in range(2)]
+        self.submitted = self.gathered = self.delivered = 0
+        self.info = dict(frames=0, frames_redone=0, groups=0, bytes_sent=0, bytes_received=0)
 
-    def _halo_bufs(self, kw):
-        return dict(send=torch.zeros((max(self._nrows, 1), self.w), dtype=torch.int32, **kw),
-                    recv=torch.zeros((max(self._nrows, 1), self.w), dtype=torch.int32, **kw),
-                    miss=torch.zeros(1, dtype=torch.int32, **kw))
+    # ---- the transport: a group = operations that progress together -----------------------
+    def _begin(self):
+        self._ops = []
 
-    def _halo_start(self, pre, hx, async_op):
-        """Send this strip's border rows to the neighbours (ascending rank order: the upper
-        neighbour gets my top rows, the lower one my bottom rows); returns the work handle."""
-        H, (up, dn) = self.halo, self._peers
-        k = 0
-        if up:
-            hx["send"][0:H].copy_(pre[self.y0:self.y0 + H]); k = H
-        if dn:
-            hx["send"][k:k + H].copy_(pre[self.y1 - H:self.y1])
-        n = self._nrows
-        return dist.all_to_all_single(hx["recv"][:n], hx["send"][:n], output_split_sizes=self._in_split,
-                                      input_split_sizes=self._in_split, group=self.group, async_op=async_op)
+    def _send(self, t, peer, tag):
+        self._ops.append(dist.P2POp(dist.isend, t, peer, group=self.group, tag=tag))
+        self.info["bytes_sent"] += t.numel() * 4
 
-    def _halo_finish(self, pre, hx):
-        """Place the received rows: the upper neighbour's bottom rows above my strip, the
-        lower neighbour's top rows below it."""
-        H, (up, dn) = self.halo, self._peers
-        k = 0
-        if up:
-            pre[self.y0 - H:self.y0].copy_(hx["recv"][0:H]); k = H
-        if dn:
-            pre[self.y1:self.y1 + H].copy_(hx["recv"][k:k + H])
+    def _recv(self, t, peer, tag):
+        self._ops.append(dist.P2POp(dist.irecv, t, peer, group=self.group, tag=tag))
+        self.info["bytes_received"] += t.numel() * 4
 
-    def _any_miss(self, miss):
-        """Collective: did any rank count a tap outside its halo?  (host sync)"""
-        m = miss.clone()
-        dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group)
-        return int(m.item()) != 0
+    def _end(self):
+        if self._ops:
+            for req in dist.batch_isend_irecv(self._ops):
+                req.wait()
+        self.info["groups"] += 1
 
-    def _strip(self, t, rank=None):
-        rank = self.rank if rank is None else rank
-        return t[rank * self.per:(rank + 1) * self.per]
+    def _rows_of(self, r):
+        return strip_range(self.h, self.world, r)
 
-    def render(self, cam, sec=0.0, gather_depth=False):
-        """One frame.  Returns the device tensor holding the final frame on rank 0
-        (rows [0,h) valid), None elsewhere."""
-        b = self.backend
-        cam = np.ascontiguousarray(cam, np.float32).reshape(16)
-        b.trace_rows(cam, float(sec), self.y0, self.y1, self.pre, self.z)
-        cur, other = self.pre, self.out
-        done = False
-        if self.halo:
-            hx = self._hx[0]
-            hx["miss"].zero_()
-            self._halo_start(cur, hx, False)
-            self._halo_finish(cur, hx)
-            b.blur_rows_bounded(self.y0, self.y1, cur, self.z, other, self.avail[0], self.avail[1], hx["miss"])
-            if self._any_miss(hx["miss"]):
-                self.halo_misses += 1          # some tap left the halo: repeat with the whole frame
-            else:
-                cur, other = other, cur
-                done = True
-        for _ in range(0 if done else self.blur_passes):
-            if self.world > 1:
-                # in place: this rank's strip is already at its slot in `cur`
-                dist.all_gather_into_tensor(cur, self._strip(cur), group=self.group)
-            b.blur_rows(self.y0, self.y1, cur, self.z, other)
-            cur, other = other, cur
-        if self.world == 1:
-            self.final_z = self.z
-            return cur
+    # ---- pieces of a group (add_gather / add_allgather of pwn_tiled.cpp) ------------------
+    def _add_gather(self, g):
+        s = g & 1
+        mine = self.out[s] if self.blur_passes else self.pre[s]
         if self.rank == 0:
-            parts = [self._strip(self.final, r) for r in range(self.world)]
-            dist.gather(self._strip(cur), parts, dst=0, group=self.group)
-            if gather_depth:
-                if self.final_z is None:
-                    self.final_z = torch.zeros_like(self.z)
-                zparts = [self._strip(self.final_z, r) for r in range(self.world)]
-                dist.gather(self._strip(self.z), zparts, dst=0, group=self.group)
-            return self.final
-        dist.gather(self._strip(cur), None, dst=0, group=self.group)
-        if gather_depth:
-            dist.gather(self._strip(self.z), None, dst=0, group=self.group)
-        return None
+            for r in range(1, self.world):
+                a, b = self._rows_of(r)
+                if b > a:
+                    self._recv(self.fin[s][a:b], r, TAG_GATHER)
+        elif self.y1 > self.y0:
+            self._send(mine[self.y0:self.y1], 0, TAG_GATHER)
+        if self.fhalo[s]:
+            for r in range(self.world):
+                if r == self.rank:
+                    continue
+                self._send(self.missw[s], r, TAG_MISS)
+                self._recv(self.missv[s][r:r + 1], r, TAG_MISS)
 
-    # -- frames in flight ------------------------------------------------------
-    # With world > 1 a frame is trace -> all-gather -> blur -> gather, and at 4K the
-    # two collectives take longer than the kernels.  A renderer presents frames in
-    # a stream, so consecutive frames are overlapped: while the collectives of
-    # frame i are on the wire (RCCL's own stream), the kernels of frame i+1 run.
-    # Every buffer exists twice (slot = frame & 1); hazards:
-    #   pre[s]  trace_i writes own strip -> all-gather_i fills the rest -> blur_i reads;
-    #           next writer trace_{i+2} is issued after blur_i on the same stream
-    #   out[s]  blur_i writes own strip -> gather_i reads; next writer blur_{i+2}
-    #           waits for gather_i first
-    #           (with the blur off the gather reads pre[s]: trace_{i+2} waits for gather_i)
-    #   z[s]    trace_i writes, blur_i reads (same stream)
-    #   final[s] (rank 0) gather_i writes; one per slot, so two gathers never share a target
-    # All ranks issue the collectives in the same order: AG_0, AG_1, G_0, AG_2, G_1, ...
-    def _slots(self):
-        if getattr(self, "_slot", None) is None:
-            mk = lambda t: torch.zeros_like(t)
-            fin = self.final
-            self._slot = [dict(pre=self.pre, out=self.out, z=self.z, fin=fin, ag=None, g=None, hx=None),
-                          dict(pre=mk(self.pre), out=mk(self.out), z=mk(self.z),
-                               fin=(mk(fin) if fin is not None else None), ag=None, g=None, hx=None)]
-            if self.halo:
-                for i in (0, 1):
-                    self._slot[i]["hx"] = self._hx[i]
-                self._miss_run = torch.zeros(1, dtype=torch.int32, device=self.pre.device)
-            self._last = None      # (cam, sec) of the newest frame, for the fallback in flush()
-            self._n = 0            # frames submitted
-            self._pending = None   # slot index of the frame traced but not yet blurred
-        return self._slot
+    def _add_allgather(self, s):
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            a, b = self._rows_of(r)
+            if self.y1 > self.y0:
+                self._send(self.pre[s][self.y0:self.y1], r, TAG_STRIP)
+            if b > a:
+                self._recv(self.pre[s][a:b], r, TAG_STRIP)
 
-    def _finish(self, k):
-        """blur + gather of the frame in slot k (its all-gather is in flight)."""
-        sl = self._slot[k]
-        if sl["g"] is not None:            # gather of the frame that used out[k] two submits ago
-            sl["g"].wait()
-            sl["g"] = None
-        cur = sl["pre"]
-        if self.blur_passes:
-            if sl["ag"] is not None:
-                sl["ag"].wait()
-                sl["ag"] = None
-            if self.halo:
-                self._halo_finish(sl["pre"], sl["hx"])
-                self.backend.blur_rows_bounded(self.y0, self.y1, sl["pre"], sl["z"], sl["out"],
-                                               self.avail[0], self.avail[1], self._miss_run)
-            else:
-                self.backend.blur_rows(self.y0, self.y1, sl["pre"], sl["z"], sl["out"])
-            cur = sl["out"]
-        if self.world == 1:
-            return cur
-        if self.rank == 0:
-            parts = [self._strip(sl["fin"], r) for r in range(self.world)]
-            sl["g"] = dist.gather(self._strip(cur), parts, dst=0, group=self.group, async_op=True)
-        else:
-            sl["g"] = dist.gather(self._strip(cur), None, dst=0, group=self.group, async_op=True)
-        return sl["fin"]
-
+    # ---- pwn_tiled_submit ---------------------------------------------------------------------
     def submit(self, cam, sec=0.0):
-        """Enqueue one frame (POSTPROC_BLUR 0 or 1).  Returns None; the frame is
-        complete after the next submit() or after flush()."""
-        if self.blur_passes > 1:
-            raise ValueError("frames in flight support blur_passes 0 or 1")
-        slots = self._slots()
-        k = self._n & 1
-        sl = slots[k]
+        if self.submitted - self.delivered >= 2:
+            raise RuntimeError("two frames are in flight: wait() first (PWN_EBUSY)")
+        f = self.submitted
+        s = f & 1
+        self.fhalo[s] = self.halo
         cam = np.ascontiguousarray(cam, np.float32).reshape(16)
-        if sl["g"] is not None:            # the gather two frames back read this slot's buffers
-            sl["g"].wait()
-            sl["g"] = None
-        self.backend.trace_rows(cam, float(sec), self.y0, self.y1, sl["pre"], sl["z"])
-        self._last = (cam.copy(), float(sec))
-        if self.halo:
-            sl["ag"] = self._halo_start(sl["pre"], sl["hx"], True)
-        elif self.world > 1 and self.blur_passes:
-            sl["ag"] = dist.all_gather_into_tensor(sl["pre"], self._strip(sl["pre"]), group=self.group, async_op=True)
-        if self._pending is not None:
-            self._finish(self._pending)
-        self._pending = k
-        self._n += 1
+        plane = self.pre[s] if self.blur_passes else (self.fin[s] if self.rank == 0 else self.pre[s])
+        self.backend.trace_rows(cam, float(sec), self.y0, self.y1, plane, self.z[s])
+        self.missw[s].zero_()
+        gather_prev = self.gathered < f
+        if self.world > 1:
+            self._begin()
+            if self.blur_passes:
+                if self.halo:
+                    H = self.halo
+                    if self.rank > 0:
+                        self._send(self.pre[s][self.y0:self.y0 + H], self.rank - 1, TAG_HALO)
+                        self._recv(self.pre[s][self.y0 - H:self.y0], self.rank - 1, TAG_HALO)
+                    if self.rank < self.world - 1 and self.y1 < self.h:
+                        self._send(self.pre[s][self.y1 - H:self.y1], self.rank + 1, TAG_HALO)
+                        self._recv(self.pre[s][self.y1:self.y1 + H], self.rank + 1, TAG_HALO)
+                else:
+                    self._add_allgather(s)
+            if gather_prev:
+                self._add_gather(f - 1)
+            self._end()
+        if gather_prev:
+            self.gathered = f
+        if self.blur_passes:
+            dst = self.fin[s] if self.rank == 0 else self.out[s]
+            if self.halo:
+                a0 = self.y0 - self.halo if self.rank > 0 else 0
+                a1 = self.y1 + self.halo if (self.rank < self.world - 1 and self.y1 < self.h) else self.h
+                self.backend.blur_rows_bounded(self.y0, self.y1, self.pre[s], self.z[s], dst, a0, a1, self.missw[s])
+            else:
+                self.backend.blur_rows(self.y0, self.y1, self.pre[s], self.z[s], dst)
+        self.submitted = f + 1
 
-    def flush(self):
-        """Complete everything in flight.  Returns the last frame on rank 0 (device
-        tensor, rows [0,h) valid; for world == 1 on that one rank), None elsewhere."""
-        slots = self._slots()
-        res = None
-        if self._pending is not None:
-            res = self._finish(self._pending)
-            self._pending = None
-        for sl in slots:
-            if sl["g"] is not None:
-                sl["g"].wait()
-                sl["g"] = None
-        if self.halo and self._last is not None:
-            # taps outside the halo anywhere since the last flush?  Then the frames in flight were
-            # not exact; the one handed back is rendered again with the whole frame gathered.
-            miss = self._any_miss(self._miss_run)
-            self._miss_run.zero_()
-            if miss:
-                self.halo_misses += 1
-                H, self.halo = self.halo, 0
-                try:
-                    res = self.render(*self._last)
-                finally:
-                    self.halo = H
-        return res if (self.rank == 0) else None
+    # ---- pwn_tiled_wait -------------------------------------------------------------------------
+    def wait(self):
+        """Oldest frame in flight, on every rank.  Returns (frame, redone): frame = the full frame
+        tensor on rank 0 (valid until two more frames were submitted), None elsewhere."""
+        if self.delivered >= self.submitted:
+            raise RuntimeError("nothing in flight")
+        d = self.delivered
+        s = d & 1
+        if self.gathered <= d:
+            # no newer frame carries this one's gather: a group of its own
+            if self.world > 1:
+                self._begin()
+                self._add_gather(d)
+                self._end()
+            self.gathered = d + 1
+        miss = False
+        if self.fhalo[s]:
+            words = self.missv[s].clone()
+            words[self.rank] = self.missw[s][0]
+            miss = bool((words != 0).any().item())
+        if miss:
+            # every rank sees the same words and comes here together
+            self.info["frames_redone"] += 1
+            self.halo = 0
+            self.fhalo[s] = 0
+            self._begin()
+            self._add_allgather(s)
+            self._end()
+            dst = self.fin[s] if self.rank == 0 else self.out[s]
+            self.backend.blur_rows(self.y0, self.y1, self.pre[s], self.z[s], dst)
+            self._begin()
+            self._add_gather(d)
+            self._end()
+        self.delivered = d + 1
+        self.info["frames"] += 1
+        return (self.fin[s] if self.rank == 0 else None), miss
 
     def to_host(self, t):
-        """uint32 numpy view of rows [0,h) of a frame tensor."""
-        return t[:self.h].cpu().numpy().view(np.uint32)
+        """uint32 numpy copy of a frame tensor."""
+        return t.cpu().numpy().view(np.uint32)

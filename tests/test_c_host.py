@@ -85,6 +85,32 @@ def test_host_frames_in_flight_present_the_same_frames(host_bin):
 
 
 @pytest.mark.gpu
+def test_host_row_tiled_over_three_processes(host_bin, tmp_path):
+    """host/pwnhost -W 3: three processes of the plain-C host, one per rank (all on the one GPU here, over
+    the shared-memory transport), present the frames of the blocking single-process loop: scripted
+    spheres, a turning camera."""
+    base = [host_bin, level_path("pwnfps_level"), "-g", os.path.join(ROOT, "pwnfps_amd", "data", "game_objects.txt"),
+            "-w", "640", "-h", "360", "-x", "1", "-n", "8", "-t", "0.05", "-a", "0.07", "-v", "1"]
+    a = subprocess.run(base, capture_output=True, timeout=300)
+    assert a.returncode == 0, a.stderr.decode()
+    fa = re.findall(r"frame (\d+) sec \S+ fnv64 ([0-9a-f]{16})", a.stdout.decode())
+    idfile = str(tmp_path / "group.id")
+    procs = [subprocess.Popen(base + ["-W", "3", "-R", str(r), "-I", idfile, "-T", "shm"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(3)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e.decode()
+        outs.append(o.decode())
+    fb = re.findall(r"frame (\d+) sec \S+ fnv64 ([0-9a-f]{16})", outs[0])
+    assert len(fa) == 8 and fa == fb
+    assert "rank 0 of 3: rows [0,120), halo 19 rows, 8 frames (0 repeated" in outs[0]
+    assert "rank 2 of 3: rows [240,360)" in outs[2]
+    sa = re.search(r"surface fnv64 ([0-9a-f]{16})", a.stdout.decode()).group(1)
+    assert re.search(r"surface fnv64 ([0-9a-f]{16})", outs[0]).group(1) == sa
+
+
+@pytest.mark.gpu
 def test_host_missing_level_reports_eio(host_bin):
     p = subprocess.run([host_bin, "/nonexistent/level.txt"], capture_output=True, timeout=120)
     assert p.returncode == 1 and b"level file could not be read" in p.stderr

@@ -1,8 +1,9 @@
-"""The row-tiling choreography of pwnfps_amd/dist.py (strip ranges, in-place
-all-gather of pre-blur colour, per-strip blur, gather to rank 0) on CPU with
-the gloo backend, world_size 2 and 3.  The strip work is done by a CHECKER
-backend built on the oracle, so what is under test here is the host logic;
-the GPU strip kernels are tested by test_gpu_parity.py."""
+"""The row-tiling choreography (pwnfps_amd/csrc/pwn_tiled.cpp, restated statement for statement in
+pwnfps_amd/dist.py over torch.distributed point-to-point operations) on CPU with the gloo
+backend, world_size 2, 3 and 8: what goes into which grouped exchange, which buffers a frame
+owns with two frames in flight, the repeat of a frame whose blur taps left the halo, and that
+every rank decides the same.  The strip work is done by a CHECKER backend built on the oracle;
+the C implementation with the HIP kernels runs the same frame sequence in tests/test_gpu_tiled.py."""
 import os
 import socket
 
@@ -61,107 +62,131 @@ class OracleStripBackend:
         self.o.L.pwno_blur_rows(self.w, self.h, y0, y1, 1, pre.data_ptr(), z.data_ptr(), out.data_ptr())
 
 
-def _worker(rank, world, port, w, h, case, blur, q, exchange="halo", halo_depth=24.0):
+def _worker(rank, world, port, w, h, level, frames, blur, halo, q):
     import sys
     sys.path.insert(0, HERE)
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from pwnfps_amd.dist import RowTiledFrame, strip_range
-        be = OracleStripBackend(w, h, level_path(case["level"]), load_spheres(case["spheres"]))
-        fr = RowTiledFrame(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur,
-                           exchange=exchange, halo_depth=halo_depth)
+        import oracle
+        import tiled_rank                      # the frame sequence of the GPU test of the C implementation
+        from pwnfps_amd.dist import TiledFrames, strip_range
+        key = "t0" if level == "pwnfps_level" else level
+        base = load_spheres(key)
+        be = OracleStripBackend(w, h, level_path(level), base)
+        _, _, spawn = be.o.get_level()
+        fr = TiledFrames(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur, halo_rows=halo)
         assert (fr.y0, fr.y1) == strip_range(h, world, rank)
-        out = fr.render(np.array(case["cam"], np.float32), case["sec"], gather_depth=True)
-        # second frame with the same inputs must be identical (buffers are reused)
-        out = fr.render(np.array(case["cam"], np.float32), case["sec"], gather_depth=True)
-        if rank == 0:
-            import oracle
-            res = [oracle.fnv64(fr.to_host(out)), oracle.fnv64(fr.final_z[:h].numpy())]
-        else:
-            assert out is None
-        # frames in flight: five different frames through the two slots; the last one
-        # and (by flushing in the middle) the third one are checked on rank 0
-        cams = [np.array(case["cam"], np.float32).reshape(4, 4).copy() for _ in range(5)]
-        for i, c in enumerate(cams):
-            c[3, 0] += 0.05 * (i % 3)            # frames 0 and 3 are the golden pose
-        hashes = []
-        for i, c in enumerate(cams):
-            fr.submit(c, case["sec"])
-            if i in (3, 4):
-                o = fr.flush()
-                if rank == 0:
-                    hashes.append(oracle.fnv64(fr.to_host(o)))
-        if rank == 0:
-            # reference for frame 4 (pose index 1): a plain render of the same camera
-            want4 = oracle.fnv64(fr.to_host(fr.render(cams[4], case["sec"])))
-            q.put(tuple(res) + (hashes[0], hashes[1] == want4, fr.halo, fr.halo_misses))
-        else:
-            fr.render(cams[4], case["sec"])
+        halo0 = fr.halo
+        got = []
+
+        def deliver(k):
+            frame, redone = fr.wait()
+            assert (frame is not None) == (rank == 0)
+            got.append((oracle.fnv64(fr.to_host(frame)) if rank == 0 else None, redone))
+        for k in range(frames):
+            cam, sec, sph = tiled_rank.scene(k, base, spawn)
+            be.o.set_spheres(sph)
+            fr.submit(cam, sec)
+            if k >= 1:
+                deliver(k - 1)
+        # at most two frames in flight
+        cam, sec, sph = tiled_rank.scene(frames, base, spawn)
+        be.o.set_spheres(sph)
+        fr.submit(cam, sec)
+        with pytest.raises(RuntimeError, match="in flight"):
+            fr.submit(cam, sec)
+        deliver(frames - 1)
+        deliver(frames)
+        with pytest.raises(RuntimeError, match="nothing in flight"):
+            fr.wait()
+        q.put((rank, got, halo0, fr.halo, dict(fr.info)))
     finally:
         dist.destroy_process_group()
 
 
-# exchange / halo depth: the default halo (depth 24: 13 rows at h = 240, never missed by this
-# scene), a halo of 1 row that IS missed (every frame falls back to the all-gather), and the
-# plain all-gather
-@pytest.mark.parametrize("world,blur,exchange,depth", [(2, 1, "halo", 24.0), (2, 0, "halo", 24.0), (3, 1, "halo", 24.0),
-                                                       (2, 1, "halo", 0.0), (3, 1, "halo", 0.0), (2, 1, "allgather", 24.0)])
-def test_row_tiled_frame_matches_golden(cases, world, blur, exchange, depth):
-    case = next(c for c in cases if c["name"] == "level_pose1_320x240")
+def _run(world, w, h, level, frames, blur, halo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case["w"], case["h"], case, blur, q, exchange, depth))
-             for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, level, frames, blur, halo, q)) for r in range(world)]
     for p in procs:
         p.start()
+    res = {}
+    for _ in range(world):
+        r = q.get(timeout=600)
+        res[r[0]] = r[1:]
     for p in procs:
-        p.join(180)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    col, z, piped3, piped4_ok, halo, misses = q.get(timeout=5)
-    if exchange == "halo" and blur == 1:
-        assert halo == int(np.ceil(0.002 * case["h"] * depth)) + 1
-        assert (misses > 0) == (depth < 1.0), (halo, misses)     # the 1-row halo must have been caught
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def _want(w, h, level, frames, blur):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import oracle
+    import tiled_rank
+    O = oracle.Oracle()
+    O.load_level(level_path(level))
+    base = load_spheres("t0" if level == "pwnfps_level" else level)
+    _, _, spawn = O.get_level()
+    out = []
+    for k in range(frames):
+        cam, sec, sph = tiled_rank.scene(k, base, spawn)
+        O.set_spheres(sph)
+        out.append(oracle.fnv64(O.render(w, h, cam, sec=sec, blur=blur)[0]))
+    return out
+
+
+# halo: -1 = the default (depth 24: 13 rows at h = 240, never left by this scene), 0 = whole strips to
+# everybody, 1 = one row, which the blur's taps leave: the frame is repeated with whole strips
+@pytest.mark.parametrize("world,blur,halo", [(2, 1, -1), (3, 1, -1), (8, 1, -1), (2, 1, 0), (3, 1, 1), (8, 1, 1), (2, 0, -1), (3, 0, -1)])
+def test_tiled_frames_are_the_oracles_frames(world, blur, halo):
+    w, h, frames = 320, 240, 5
+    want = _want(w, h, "pwnfps_level", frames + 1, blur)
+    res = _run(world, w, h, "pwnfps_level", frames, blur, halo)
+    got, halo0, halo1, info0 = res[0]
+    assert [g[0] for g in got] == want
+    redone = [g[1] for g in got]
+    for r in range(world):
+        g, h0, h1, info = res[r]
+        # every rank made the same decisions
+        assert [x[1] for x in g] == redone and (h0, h1) == (halo0, halo1)
+        assert info["frames"] == frames + 1 and info["frames_redone"] == sum(redone)
+    if blur == 0 or halo == 0:
+        assert halo0 == 0 and sum(redone) == 0
+    elif halo == -1:
+        assert halo0 == 13 and halo1 == 13 and sum(redone) == 0
+        # one grouped exchange per frame, one to drain the last frame
+        assert info0["groups"] == frames + 2
     else:
-        assert halo == 0 and misses == 0
-    assert col == (case["post"] if blur else case["pre"])
-    assert z == case["z"]
-    assert piped3 == (case["post"] if blur else case["pre"])     # frame 3 of the pipeline = the golden pose
-    assert piped4_ok
+        # the first frame whose taps leave the one-row halo is repeated -- and so is the frame that was
+        # already in flight with that halo if its taps leave it too; whole strips from then on
+        assert halo0 == 1 and halo1 == 0 and 1 <= sum(redone) <= 2 and redone[0]
+    if world > 1 and blur and halo == -1:
+        # a strip's neighbours send it 13 rows each, rank 0 takes in every other strip
+        per = res[0][3]["bytes_received"] / (frames + 1)
+        assert per >= (h - 32) * w * 4 if world == 8 else per > 0
 
 
-def test_eight_ranks_uneven_last_strip(cases):
-    """World size 8 at 1280x720: strips of 96 rows, the last one 48; the 36-row halo fits the
-    shortest strip, so the bounded exchange runs with the geometry of the 8-GPU bench."""
-    case = next(c for c in cases if c["name"] == "level_pose1_1280x720")
-    world = 8
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, case["w"], case["h"], case, 1, q, "halo", 24.0))
-             for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(600)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    col, z, piped3, piped4_ok, halo, misses = q.get(timeout=5)
-    assert halo == 36 and misses == 0
-    assert col == case["post"] and z == case["z"] and piped3 == case["post"] and piped4_ok
+def test_uneven_strips_and_a_strip_shorter_than_the_halo():
+    # 100 rows over 3 ranks: 40 + 40 + 20; the default halo of 100 rows is 6
+    w, h, frames = 128, 100, 4
+    want = _want(w, h, "synth64", frames + 1, 1)
+    res = _run(3, w, h, "synth64", frames, 1, -1)
+    assert [g[0] for g in res[0][0]] == want and res[0][1] == 6
+    # a halo taller than the shortest strip cannot be exchanged with neighbours only: whole strips
+    res = _run(3, w, h, "synth64", frames, 1, 30)
+    assert [g[0] for g in res[0][0]] == want and res[0][1] == 0
 
 
-def test_strip_ranges():
-    from pwnfps_amd.dist import strip_range, strip_rows
-    for h in (200, 240, 720, 1080, 2160, 4320, 7, 8, 9):
-        for world in (1, 2, 3, 4, 8):
-            per = strip_rows(h, world)
-            assert per % 8 == 0 and per * world >= h
-            rows = []
-            for r in range(world):
-                y0, y1 = strip_range(h, world, r)
-                assert 0 <= y0 <= y1 <= h and (y0 % 8 == 0 or y0 == h)
-                rows += list(range(y0, y1))
-            assert rows == list(range(h))
+def test_strip_geometry():
+    from pwnfps_amd.dist import default_halo, strip_range, strip_rows
+    assert strip_rows(2160, 8) == 272 and strip_rows(4320, 8) == 544 and strip_rows(240, 3) == 80
+    assert [strip_range(2160, 8, r) for r in (0, 6, 7)] == [(0, 272), (1632, 1904), (1904, 2160)]
+    assert strip_range(100, 3, 2) == (80, 100) and strip_range(16, 4, 3) == (16, 16)
+    assert default_halo(2160) == 105 and default_halo(4320) == 209 and default_halo(240) == 13

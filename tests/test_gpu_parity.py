@@ -207,32 +207,33 @@ def test_strip_forms_equal_full_frame(oracle_lib, cases):
 
 
 def test_single_rank_row_tiled_frame(oracle_lib, cases):
+    """pwnfps_amd/dist.py's restatement of the tiling choreography over the HIP strip kernels
+    (torch tensors, torch's stream), one rank: two frames in flight, alternating poses."""
     import torch
-    from pwnfps_amd.dist import HipStripBackend, RowTiledFrame
+    from pwnfps_amd.dist import HipStripBackend, TiledFrames
     c = next(x for x in cases if x["name"] == "level_pose2_320x240")
     r = _renderer(c["w"], c["h"])
     r.level_load(level_path(c["level"]))
     r.set_objects(load_spheres(c["spheres"]))
-    fr = RowTiledFrame(c["w"], c["h"], HipStripBackend(r), torch.device("cuda:0"), rank=0, world=1)
-    out = fr.render(np.array(c["cam"], np.float32), c["sec"])
-    torch.cuda.synchronize()
-    assert _fnv(oracle_lib, fr.to_host(out)) == c["post"]
-    # frames in flight (the N > 1 bench loop) on the GPU kernels: two slots, six
-    # frames of alternating poses, each checked against a plain render
+    fr = TiledFrames(c["w"], c["h"], HipStripBackend(r), torch.device("cuda:0"), rank=0, world=1)
     cams = [np.array(c["cam"], np.float32).reshape(4, 4).copy() for _ in range(2)]
     cams[1][3, 0] += 0.25
     want = []
     for cam in cams:
-        o = fr.render(cam, c["sec"])
-        torch.cuda.synchronize()
-        want.append(_fnv(oracle_lib, fr.to_host(o)))
+        sb, _ = r.trace_screen_centred(cam, c["sec"])
+        want.append(_fnv(oracle_lib, sb))
     assert want[0] == c["post"] and want[1] != want[0]
+    got = []
     for i in range(6):
         fr.submit(cams[i & 1], c["sec"])
-        if i in (2, 5):
-            o = fr.flush()
+        if i >= 1:
+            o, redone = fr.wait()
             torch.cuda.synchronize()
-            assert _fnv(oracle_lib, fr.to_host(o)) == want[i & 1], i
+            got.append(_fnv(oracle_lib, fr.to_host(o)))
+    o, _ = fr.wait()
+    torch.cuda.synchronize()
+    got.append(_fnv(oracle_lib, fr.to_host(o)))
+    assert got == [want[i & 1] for i in range(6)]
     r.close()
 
 
