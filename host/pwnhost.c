@@ -16,6 +16,8 @@
  *           [-x SCALE] [-n FRAMES] [-t SECONDS_PER_FRAME] [-a TURN_PER_FRAME]
  *           [-p PITCH] [-b BLUR_PASSES] [-o out.ppm] [-d DEVICE] [-v 1] [-q SLOTS]
  *
+ * -l game.lua (hosts built with Lua 5.1: host/Makefile) runs a script by path in a Lua VM whose
+ * obj_new / obj_set / obj_free / level_get act on the library's object table (script.h:1-103).
  * -t fixes the clock step (the reference uses wall time, main.c:112-114), which
  * makes a run reproducible; -v 1 prints every frame's hash.
  * -W WORLD -R RANK -I IDFILE [-T rccl|shm] row-tiles every frame over WORLD processes, one per
@@ -38,6 +40,9 @@
 
 #include "pwnhip.h"
 #include "game_script.h"
+#ifdef HAVE_LUA
+#include "lua_host.h"
+#endif
 
 /* the globals a reference host owns (main.c:26-34) */
 static int rwidth = 320, rheight = 200, rscale = 3;
@@ -125,7 +130,7 @@ static uint64_t fnv64(const uint32_t *p, size_t n)
 
 int main(int argc, char **argv)
 {
-	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL;
+	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL, *luafile = NULL;
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
 	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL;
 	const char *idfile = NULL;
@@ -138,6 +143,7 @@ int main(int argc, char **argv)
 		{
 			case 's': sphfile = argv[++i]; break;
 			case 'g': gamefile = argv[++i]; break;
+			case 'l': luafile = argv[++i]; break;
 			case 't': fixed_dt = (float)atof(argv[++i]); break;
 			case 'v': verbose = atoi(argv[++i]); break;
 			case 'w': rwidth = atoi(argv[++i]); break;
@@ -171,6 +177,9 @@ int main(int argc, char **argv)
 		return 2;
 	}
 	if(slots != 0 && (slots < 2 || slots > PWN_MAX_SLOTS)) { fprintf(stderr, "-q takes 2..%d\n", PWN_MAX_SLOTS); return 2; }
+#ifndef HAVE_LUA
+	if(luafile != NULL) { fprintf(stderr, "-l %s: this pwnhost was built without Lua 5.1 (host/Makefile); use -g\n", luafile); return 2; }
+#endif
 	if(slots != 0 && fixed_dt < 0.0f) fixed_dt = 0.0f;       /* frames in flight run on a fixed clock step (-t) */
 	if(rscale < 1) rscale = 1;
 	if(pitch == 0) pitch = rwidth * rscale * 4;
@@ -196,8 +205,22 @@ int main(int argc, char **argv)
 	pwn_sphere *sph = NULL;
 	int nsph = 0;
 	if(sphfile != NULL && (nsph = load_spheres(sphfile, &sph)) < 0) { fprintf(stderr, "cannot read %s\n", sphfile); pwn_destroy(ctx); return 1; }
+#ifdef HAVE_LUA
+	lua_host *vm = NULL;
+	char luaerr[512];
+	if(luafile != NULL)                                                          /* script_newvm, main.c:56 */
+	{
+		vm = lua_host_new(ctx, luafile, luaerr, sizeof(luaerr));
+		if(vm == NULL) { fprintf(stderr, "ERROR: %s\n", luaerr); pwn_destroy(ctx); return 1; }
+	}
+#define TICK(sec, dt) do { if(vm != NULL && lua_host_on_tick(vm, (sec), (dt), luaerr, sizeof(luaerr)) != 0) { \
+	fprintf(stderr, "ERROR: %s\n", luaerr); pwn_destroy(ctx); return 1; } } while(0)
+#else
+#define TICK(sec, dt) do { } while(0)
+#endif
 	game_script game;
-	if(gamefile != NULL)                                                         /* script_newvm, main.c:56 */
+	if(luafile != NULL) { /* the script created its objects */ }
+	else if(gamefile != NULL)                                                    /* script_newvm, main.c:56 */
 	{
 		rc = game_script_init(&game, ctx, gamefile);
 		if(rc == -100) { fprintf(stderr, "cannot read %s\n", gamefile); pwn_destroy(ctx); return 1; }
@@ -262,6 +285,7 @@ int main(int argc, char **argv)
 				sec_current += fixed_dt;                                                /* main.c:112-114 */
 				if(gamefile != NULL)
 					CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)fixed_dt));   /* main.c:127-140 */
+				TICK((double)sec_current, (double)fixed_dt);
 				ang += turn;
 			}
 		}
@@ -316,6 +340,7 @@ int main(int argc, char **argv)
 				sec_current += fixed_dt;                                                /* main.c:112-114 */
 				if(gamefile != NULL)
 					CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)fixed_dt));   /* main.c:127-140 */
+				TICK((double)sec_current, (double)fixed_dt);
 				ang += turn;
 			}
 		}
@@ -353,6 +378,7 @@ int main(int argc, char **argv)
 		sec_current += tdiff;                                                    /* main.c:112-114 */
 		if(gamefile != NULL)
 			CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)tdiff));   /* main.c:127-140 */
+		TICK((double)sec_current, (double)tdiff);
 		ang += turn;
 	}
 

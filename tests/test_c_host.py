@@ -39,6 +39,22 @@ def test_host_usage_and_bad_option(host_bin):
     assert p.returncode == 2 and b"-q takes 2.." in p.stderr
 
 
+def test_lua_leg_is_conditional(host_bin):
+    """host/lua_host.c (script.h:71-103 over the ABI's object calls) is built in where Lua 5.1 is found;
+    elsewhere -l says so instead of silently doing something else."""
+    out = subprocess.check_output(["make", "-s", "-C", os.path.join(ROOT, "host"), "lua-leg"]).decode()
+    syms = subprocess.check_output(["nm", "-D", "--undefined-only", host_bin]).decode()
+    if "not found" in out:
+        assert "lua_pcall" not in syms
+        p = subprocess.run([host_bin, level_path("pwnfps_level"), "-l", "game.lua"], capture_output=True)
+        assert p.returncode == 2 and b"built without Lua" in p.stderr
+    else:
+        assert "lua_pcall" in syms and "luaL_loadfile" in syms
+    src = open(os.path.join(ROOT, "host", "lua_host.c")).read()
+    for name in ("obj_new", "obj_set", "obj_free", "level_get", "level_set", "on_tick", "luaL_openlibs", "luaL_loadfile"):
+        assert name in src
+
+
 @pytest.mark.gpu
 def test_host_frame_is_the_reference_frame(host_bin, cases, tmp_path, oracle_lib):
     # the reference's shipped configuration: 320x200, x3 upscale (defs.h:11-15)

@@ -6,6 +6,11 @@ table it drives (script.h:1-64, level.h:41-81), without a GPU:
   * a scripted run reproduces the sphere tables in tests/golden/anim.npz, and the
     oracle renders those frames to the hashes the COMPILED REFERENCE produced
     (tools/gen_anim_golden.py)
+  * THE PIN of the restated logic: tests/golden/script_ticks.npz holds what the reference's own
+    game.lua does, tick by tick -- its text executed by tools/minilua.py, a generic interpreter
+    for the Lua subset it uses (tools/gen_script_golden.py; the image has no Lua).  The
+    restatement must leave the same sphere table and the same obx / obz / obvx / obvz after
+    every one of 1500 ticks of a patrol that turns at walls in all four directions.
 """
 import os
 
@@ -132,3 +137,32 @@ def test_oracle_renders_the_scripted_frames_like_the_reference(run, anim, oracle
         assert int((~np.isfinite(z)).sum()) == nonfinite[f]
         if nonfinite[f]:
             assert got[2] == anim[run + "_hashes"][f][2]     # depth agrees under both builds
+
+
+@pytest.fixture(scope="module")
+def ticks():
+    return np.load(os.path.join(GOLD, "script_ticks.npz"))
+
+
+@pytest.mark.parametrize("run", ["static", "chase", "patrol"])
+def test_restatement_does_what_game_lua_does(run, ticks, level_cells):
+    """pwnfps_amd/script.py against the script's own text run by the interpreter: every tick,
+    bit for bit (sphere floats as obj_set stores them, the script's globals as doubles)."""
+    T = ObjectTable(level_cells)
+    g = GameScript(T)
+    n = len(ticks[run + "_sec"])
+    secs, tk = frame_times(n, float(ticks[run + "_dt"]))
+    assert (bits(np.array(secs, np.float32)) == bits(ticks[run + "_sec"])).all()
+    for f in range(n):
+        assert (bits(T.live()) == bits(ticks[run + "_spheres"][f])).all(), (run, f)
+        assert (g.obx, g.obz, g.obvx, g.obvz) == tuple(ticks[run + "_centre"][f]), (run, f)
+        g.on_tick(*tk[f])
+    if run == "patrol":
+        assert len({tuple(c[2:]) for c in ticks[run + "_centre"]}) == 4
+
+
+def test_anim_fixture_holds_the_interpreters_tables(anim, ticks):
+    """the sphere tables the rendered goldens (anim.npz) were made with are game.lua's"""
+    for run in ("static", "chase"):
+        assert (bits(anim[run + "_spheres"]) == bits(ticks[run + "_spheres"])).all()
+        assert (anim[run + "_centre"] == ticks[run + "_centre"]).all()
