@@ -16,6 +16,10 @@
  *           [-x SCALE] [-n FRAMES] [-t SECONDS_PER_FRAME] [-a TURN_PER_FRAME]
  *           [-p PITCH] [-b BLUR_PASSES] [-o out.ppm] [-d DEVICE] [-v 1] [-q SLOTS]
  *
+ * -k keys.txt makes it the interactive loop without a window: the camera is the player's (main.c:188-379:
+ * turning, walking with push-back, gravity, portals), driven by key events from a script
+ * (`FRAME KEY down|up`, keys left right up down w s a d quit; polled after frame FRAME like
+ * SDL_PollEvent at main.c:142).  -a is ignored then.
  * -l game.lua (hosts built with Lua 5.1: host/Makefile) runs a script by path in a Lua VM whose
  * obj_new / obj_set / obj_free / level_get act on the library's object table (script.h:1-103).
  * -t fixes the clock step (the reference uses wall time, main.c:112-114), which
@@ -40,6 +44,7 @@
 
 #include "pwnhip.h"
 #include "game_script.h"
+#include "player.h"
 #ifdef HAVE_LUA
 #include "lua_host.h"
 #endif
@@ -73,6 +78,29 @@ static void cam_roty(float cam[16], float ang)
 	cam[2] = vc * vxz - vs * vxx;
 	cam[8] = vc * vzx + vs * vzz;
 	cam[10] = vc * vzz - vs * vzx;
+}
+
+/* the camera of a frame: the player's (-k), or mainloop's start pose turned about y (-a) */
+static void frame_camera(float cam[16], const pwn_player *player, float ang, const int32_t spawn[2])
+{
+	if(player != NULL) { memcpy(cam, player->cam, 16 * sizeof(float)); return; }
+	cam_identity(cam);
+	if(ang != 0.0f) cam_roty(cam, ang);
+	cam[12] = 0.5f + (float)spawn[0]; cam[13] = 0.5f; cam[14] = 0.5f + (float)spawn[1];
+}
+
+/* main.c:142-379 for the frame just shown: the key events polled now, then the player's tick */
+static int player_tick(pwn_player *player, pwn_keys *keys, const pwn_key_event *ev, int nev, int frame, float tdiff,
+	const uint8_t *cells, const pwn_portal *pmap)
+{
+	for(int i = 0; i < nev; i++)
+		if(ev[i].frame == frame)
+		{
+			if(ev[i].sym == PWN_KEY_QUIT) return 1;
+			pwn_keys_event(keys, ev[i].sym, ev[i].down);
+		}
+	pwn_player_step(player, keys, tdiff, cells, pmap);
+	return 0;
 }
 
 static int load_spheres(const char *path, pwn_sphere **out)
@@ -130,7 +158,7 @@ static uint64_t fnv64(const uint32_t *p, size_t n)
 
 int main(int argc, char **argv)
 {
-	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL, *luafile = NULL;
+	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL, *luafile = NULL, *keyfile = NULL;
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
 	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL;
 	const char *idfile = NULL;
@@ -144,6 +172,7 @@ int main(int argc, char **argv)
 			case 's': sphfile = argv[++i]; break;
 			case 'g': gamefile = argv[++i]; break;
 			case 'l': luafile = argv[++i]; break;
+			case 'k': keyfile = argv[++i]; break;
 			case 't': fixed_dt = (float)atof(argv[++i]); break;
 			case 'v': verbose = atoi(argv[++i]); break;
 			case 'w': rwidth = atoi(argv[++i]); break;
@@ -202,6 +231,22 @@ int main(int argc, char **argv)
 	int32_t spawn[2];
 	CHK(pwn_get_level(ctx, NULL, NULL, spawn));
 	printf("spawn: %d %d\n", spawn[0], spawn[1]);
+	pwn_player player;
+	pwn_keys keys;
+	static pwn_key_event key_ev[4096];
+	static uint8_t cells[4096];
+	static pwn_portal pmap[26];
+	int nkey_ev = 0;
+	memset(&keys, 0, sizeof(keys));
+	pwn_player_init(&player, spawn);
+	if(keyfile != NULL)
+	{
+		nkey_ev = pwn_keys_load(keyfile, key_ev, 4096);
+		if(nkey_ev < 0 || nkey_ev > 4096) { fprintf(stderr, "cannot read the key script %s\n", keyfile); pwn_destroy(ctx); return 1; }
+		CHK(pwn_get_level(ctx, cells, pmap, NULL));
+		if(fixed_dt < 0.0f) fixed_dt = 1.0f / 60.0f;          /* a scripted run is reproducible: a fixed clock step */
+	}
+#define PLAYER(frame, dt) (keyfile != NULL && player_tick(&player, &keys, key_ev, nkey_ev, (frame), (dt), cells, pmap))
 	pwn_sphere *sph = NULL;
 	int nsph = 0;
 	if(sphfile != NULL && (nsph = load_spheres(sphfile, &sph)) < 0) { fprintf(stderr, "cannot read %s\n", sphfile); pwn_destroy(ctx); return 1; }
@@ -267,9 +312,7 @@ int main(int argc, char **argv)
 			if(f < frames)
 			{
 				float cam[16];
-				cam_identity(cam);
-				if(ang != 0.0f) cam_roty(cam, ang);
-				cam[12] = 0.5f + (float)spawn[0]; cam[13] = 0.5f; cam[14] = 0.5f + (float)spawn[1];
+				frame_camera(cam, keyfile != NULL ? &player : NULL, ang, spawn);
 				CHK(pwn_prepare_render(ctx));                                           /* main.c:95 */
 				CHK(pwn_tiled_submit(ctx, cam, sec_current));                          /* main.c:107 */
 			}
@@ -286,6 +329,7 @@ int main(int argc, char **argv)
 				if(gamefile != NULL)
 					CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)fixed_dt));   /* main.c:127-140 */
 				TICK((double)sec_current, (double)fixed_dt);
+				if(PLAYER(f, fixed_dt)) frames = f + 1;                                /* SDL_QUIT, main.c:145 */
 				ang += turn;
 			}
 		}
@@ -332,15 +376,14 @@ int main(int argc, char **argv)
 			if(f < frames)
 			{
 				float cam[16];
-				cam_identity(cam);
-				if(ang != 0.0f) cam_roty(cam, ang);
-				cam[12] = 0.5f + (float)spawn[0]; cam[13] = 0.5f; cam[14] = 0.5f + (float)spawn[1];
+				frame_camera(cam, keyfile != NULL ? &player : NULL, ang, spawn);
 				CHK(pwn_prepare_render(ctx));                                           /* main.c:95 */
 				CHK(pwn_submit_frame(ctx, cam, sec_current, f % slots));                /* main.c:107-108 */
 				sec_current += fixed_dt;                                                /* main.c:112-114 */
 				if(gamefile != NULL)
 					CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)fixed_dt));   /* main.c:127-140 */
 				TICK((double)sec_current, (double)fixed_dt);
+				if(PLAYER(f, fixed_dt)) frames = f + 1;                                /* SDL_QUIT, main.c:145 */
 				ang += turn;
 			}
 		}
@@ -361,9 +404,7 @@ int main(int argc, char **argv)
 	for(int f = 0; f < frames; f++)
 	{
 		float cam[16];
-		cam_identity(cam);
-		if(ang != 0.0f) cam_roty(cam, ang);
-		cam[12] = 0.5f + (float)spawn[0]; cam[13] = 0.5f; cam[14] = 0.5f + (float)spawn[1];
+		frame_camera(cam, keyfile != NULL ? &player : NULL, ang, spawn);
 
 		double t0 = now_s();
 		CHK(pwn_prepare_render(ctx));                                           /* level_prepare_render, main.c:95 */
@@ -379,6 +420,7 @@ int main(int argc, char **argv)
 		if(gamefile != NULL)
 			CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)tdiff));   /* main.c:127-140 */
 		TICK((double)sec_current, (double)tdiff);
+		if(PLAYER(f, tdiff)) frames = f + 1;                                        /* SDL_QUIT, main.c:145 */
 		ang += turn;
 	}
 

@@ -127,6 +127,61 @@ def test_host_row_tiled_over_three_processes(host_bin, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["blocking", "in_flight"])
+def test_host_interactive_walk_every_frame_is_the_oracles(host_bin, mode, oracle_lib):
+    """pwnhost -k: the interactive loop without a window (main.c:93-379): a key script walks and turns the
+    player through the level (through a portal too), the game script moves the spheres, the frame
+    goes through the x2 sink.  Every frame's hash is the oracle's for the camera that host/player.c --
+    driven here from Python over the same key script -- has at that frame."""
+    import ctypes as C
+    import test_player as tp
+    keys = os.path.join(GOLD, "keys_walk.txt")
+    n, dt, w, h = 160, 1.0 / 30.0, 320, 200
+    args = [host_bin, level_path("pwnfps_level"), "-g", os.path.join(ROOT, "pwnfps_amd", "data", "game_objects.txt"),
+            "-k", keys, "-w", str(w), "-h", str(h), "-x", "2", "-n", str(n), "-t", repr(dt), "-v", "1"]
+    if mode == "in_flight":
+        args += ["-q", "3"]
+    p = subprocess.run(args, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()
+    got = re.findall(r"frame (\d+) sec \S+ fnv64 ([0-9a-f]{16})", p.stdout.decode())
+    assert len(got) == n
+    # the same run on the CPU: player library + restated script + oracle
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host"), os.path.join(ROOT, "host", "libpwnplayer.so")])
+    L = C.CDLL(os.path.join(ROOT, "host", "libpwnplayer.so"))
+    L.pwn_player_init.argtypes = [C.POINTER(tp.Player), C.c_void_p]
+    L.pwn_player_step.argtypes = [C.POINTER(tp.Player), C.POINTER(tp.Keys), C.c_float, C.c_void_p, C.c_void_p]
+    L.pwn_keys_event.argtypes = [C.POINTER(tp.Keys), C.c_int, C.c_int]
+    L.pwn_keys_load.argtypes = [C.c_char_p, C.POINTER(tp.KeyEvent), C.c_int]
+    ev = (tp.KeyEvent * 64)()
+    nev = L.pwn_keys_load(keys.encode(), ev, 64)
+    assert nev == 10
+    t = np.load(os.path.join(GOLD, "levels", "pwnfps_level_tables.npz"))
+    data, pmap, spawn = (np.ascontiguousarray(t[k]) for k in ("data", "pmap", "spawn"))
+    from oracle import Oracle
+    from pwnfps_amd.script import GameScript, ObjectTable, frame_times
+    O = Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    T = ObjectTable(data)
+    g = GameScript(T)
+    secs, ticks = frame_times(n, dt)
+    pl, kk = tp.Player(), tp.Keys()
+    L.pwn_player_init(C.byref(pl), spawn.astype(np.int32).ctypes.data)
+    traversed = 0
+    for f in range(n):
+        O.set_spheres(T.live())
+        img, _ = O.render(w, h, np.array(list(pl.cam), np.float32).reshape(4, 4), sec=secs[f], blur=1)
+        assert got[f] == (str(f), oracle_lib.fnv64(img)), (mode, f)
+        g.on_tick(*ticks[f])
+        for e in ev[:nev]:
+            if e.frame == f:
+                L.pwn_keys_event(C.byref(kk), e.sym, e.down)
+        L.pwn_player_step(C.byref(pl), C.byref(kk), np.float32(dt), data.astype(np.uint8).ctypes.data, pmap.astype(np.int32).ctypes.data)
+        traversed = pl.traversals
+    assert len({h_ for _, h_ in got}) > 100                 # the camera does move
+    assert traversed >= 1, "the walk was laid out to go through a portal"
+
+
+@pytest.mark.gpu
 def test_host_missing_level_reports_eio(host_bin):
     p = subprocess.run([host_bin, "/nonexistent/level.txt"], capture_output=True, timeout=120)
     assert p.returncode == 1 and b"level file could not be read" in p.stderr
