@@ -10,8 +10,8 @@ pose, sec_current = 0) at 3840x2160 with the post-process blur on, i.e. one
 level_prepare_render() + trace_screen_centred() (main.c:95,107; screen.h:31-124).  With N > 1 the frame is row-tiled
 behind the C ABI (pwn_tiled_*, pwnfps_amd/csrc/pwn_tiled.cpp): rank r traces rows
 [r*per, (r+1)*per), one grouped RCCL send/recv launch per frame carries this frame's
-pre-blur halo rows between neighbour strips and the previous frame's finished
-strips to rank 0, each rank blurs its strip; two frames are in flight.  Level/sphere
+pre-blur halo rows between neighbour strips and the finished strips of the frame two
+back to rank 0, each rank blurs its strip; three frames are in flight.  Level/sphere
 tables and all frame buffers are resident in HBM before the timed region; in the
 timed region of `value` the frame stays on the device (rank 0's for N > 1).  The rate with every frame handed over to the host (what
 trace_screen_centred does with sbuf, main.c:107) is measured in the same run
@@ -164,6 +164,9 @@ def main():
                          "kernels costs ~4 us of pipeline; 1 = every launch)")
     ap.add_argument("--halo", type=int, default=-1, help="N > 1: pre-blur rows exchanged with each neighbour strip (-1 default, 0 whole strips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-d2h", action="store_true",
+                    help="skip the d2h_inclusive leg: for rocprofv3 --kernel-trace runs, where the profiler serialises the copies of "
+                         "that leg with the kernels and their durations (2.7x) would be averaged into the resident loop's")
     args = ap.parse_args()
 
     import torch
@@ -255,13 +258,13 @@ def main():
             for i in range(max(0, n - nres), n):
                 note(r.wait_frame(i % nres))
         else:
-            # N > 1: two frames in flight; the exchange of frame i carries the result of frame i-1
+            # N > 1: three frames in flight; the exchange of frame i carries the result of frame i-2
             for i in range(n):
                 r.set_objects(spheres)
                 r.tiled_submit(cam, sec)
-                if i >= 1:
+                if i >= 2:
                     note(r.tiled_wait())
-            if n:
+            for _ in range(min(n, 2)):
                 note(r.tiled_wait())
 
     def block():
@@ -335,6 +338,7 @@ def main():
             blocking_best = min(blocking_best, time.perf_counter() - t1)
         st = r.stats()                     # kernel times of an uncounted frame
         kernel_ms = {"trace": round(st["trace_ms"], 4), "blur": round(st["blur_ms"], 4)}
+    if world == 1 and not args.no_d2h:
         # The metric as SURVEY.md 8(d) words it: every frame handed over to the host.  Same
         # step as above (re-bin + upload, trace, blur) plus the D2H into the library's pinned
         # sbuf, `slots` frames in flight; the same K-step blocks, median block.
@@ -377,7 +381,7 @@ def main():
             strip_pix, par = pix, "rows/1, %d frames in flight" % nres
         else:
             strip_pix = (tinfo["y1"] - tinfo["y0"]) * w
-            par = "rows/%d, one grouped %s send/recv per frame (%s + gather of the previous frame's strips), 2 frames in flight" % (
+            par = "rows/%d, one grouped %s send/recv per frame (%s + gather of the strips of the frame two back), 3 frames in flight" % (
                 world, transport.upper(), ("%d halo rows per neighbour" % tinfo["halo_rows"]) if tinfo["halo_rows"] else "whole pre-blur strips to every rank")
         achieved = TRACE_BYTES_PER_PIXEL * strip_pix / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         line = {

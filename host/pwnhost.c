@@ -279,7 +279,7 @@ int main(int argc, char **argv)
 	if(world > 1)
 	{
 		/* the frame loop of main.c:93-140 with every frame row-tiled over `world` processes; two frames in
-		   flight, the present step one frame behind; every rank runs the same loop (and the same script) */
+		   flight (three), the present step two frames behind; every rank runs the same loop (and the same script) */
 		unsigned char id[PWN_TILED_ID_BYTES];
 		if(rank == 0)
 		{
@@ -307,7 +307,7 @@ int main(int argc, char **argv)
 		pwn_tiled_frame tf;
 		memset(&tf, 0, sizeof(tf));
 		double t0 = now_s(), t1 = t0;
-		for(int f = 0; f <= frames; f++)
+		for(int f = 0; f < frames + 2; f++)
 		{
 			if(f < frames)
 			{
@@ -316,12 +316,12 @@ int main(int argc, char **argv)
 				CHK(pwn_prepare_render(ctx));                                           /* main.c:95 */
 				CHK(pwn_tiled_submit(ctx, cam, sec_current));                          /* main.c:107 */
 			}
-			if(f >= 1)
+			if(f >= 2)
 			{
 				CHK(pwn_tiled_wait(ctx, PWN_TILED_HOST, &tf));
 				if(rank == 0 && verbose)
-					printf("frame %d sec %.9g fnv64 %016llx\n", f - 1, (double)(fixed_dt * (float)(f - 1)), (unsigned long long)fnv64(tf.sbuf, npix));
-				if(f == 1) t1 = now_s();
+					printf("frame %d sec %.9g fnv64 %016llx\n", f - 2, (double)(fixed_dt * (float)(f - 2)), (unsigned long long)fnv64(tf.sbuf, npix));
+				if(f == 2) t1 = now_s();
 			}
 			if(f < frames)
 			{

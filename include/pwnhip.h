@@ -243,11 +243,12 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
  *                        with such a tap is repeated with whole strips before it is delivered, and
  *                        whole strips are used from then on: delivered frames are always exact.
  *                        POSTPROC_BLUR 0 or 1.
- *   pwn_tiled_submit     enqueue one frame on every rank: trace own strip, ONE grouped exchange
- *                        (this frame's halo rows + the previous frame's finished strips to rank 0 +
- *                        its miss words), blur own strip.  At most two frames in flight (PWN_EBUSY).
+ *   pwn_tiled_submit     enqueue one frame on every rank: trace own strip, blur the previous frame's
+ *                        strip, ONE grouped exchange (this frame's halo rows + the finished strips of
+ *                        the frame two back to rank 0 + its miss words).  At most three frames in
+ *                        flight (PWN_EBUSY): a frame then costs max(kernels, exchange), not their sum.
  *   pwn_tiled_wait       every rank: block until the oldest frame in flight is complete; on rank 0
- *                        out->d_sbuf is the full frame on the device (valid until two more frames
+ *                        out->d_sbuf is the full frame on the device (valid until three more frames
  *                        were submitted) and, with PWN_TILED_HOST, out->sbuf a pinned host copy.
  *   pwn_tiled_shutdown   collective; pwn_destroy does it too.
  * PWN_TRANSPORT_SHM moves the same messages through POSIX shared memory instead: for tests

@@ -4,25 +4,28 @@
 // [r * rows_per, min((r + 1) * rows_per, h)), rows_per = ceil(h / world) rounded up to 8
 // (the reference parallelises the same two loops with OpenMP over rows, screen.h:63,77).
 // The trace pass needs no exchange.  The blur does: its taps reach 0.002*h*(depth-1) rows
-// (screen.h:100-102), unbounded in depth.  Per frame f and rank:
+// (screen.h:100-102), unbounded in depth.  Per submitted frame f (slot s = f mod 4) a rank enqueues
 //
-//   compute stream   trace strip f -> pre[s], z[s]                                   s = f & 1
-//   comm stream      ONE grouped exchange G(f), a single RCCL launch:
-//                      - the H border rows of strip f to / from the neighbour strips,
-//                        straight out of / into the full-frame plane pre[s] (or, without a
-//                        halo, every strip to everybody: an all-gather by send / recv)
-//                      - the FINISHED strip of frame f-1 to rank 0   (the gather)
-//                      - the miss word of frame f-1 to every rank    (see below)
-//   compute stream   blur strip f from pre[s] rows [y0-H, y1+H) -> out[s]; taps outside
-//                    those rows are counted in the rank's miss word of frame f
+//   compute stream   trace strip f -> pre[s], z[s]
+//   comm stream      ONE grouped exchange G(f), a single RCCL launch, behind that trace:
+//                      - the H border rows of strip f to / from the neighbour strips, straight out
+//                        of / into the full-frame plane pre[s] (or, without a halo, every strip to
+//                        everybody: an all-gather by send / recv)
+//                      - the FINISHED strip of frame f-2 to rank 0   (the gather)
+//                      - the miss word of frame f-2 to every rank    (see below)
+//   compute stream   blur strip f-1 from pre rows [y0-H, y1+H) -> out, behind G(f-1); taps outside
+//                    those rows are counted in the rank's miss word of that frame
 //
-// so the wire carries frame f's halo and frame f-1's result in one launch while the kernels of
-// both run.  Frame f-1 is complete on rank 0 when G(f) is (pwn_tiled_wait issues a group with
-// only the second half when no newer frame was submitted).  Every rank then holds every
-// rank's miss word of frame f-1: if one is non-zero the bounded halo was not enough for that
-// frame and ALL ranks, having the same words, repeat its exchange with whole strips, its blur and
-// its gather before it is delivered, and use whole strips from then on.  A delivered frame is
-// always exact; the host synchronises only at delivery, one frame behind the submissions.
+// The blur of a frame is enqueued one submit late, BEHIND the next frame's trace, so the compute
+// stream does not sit waiting for the exchange: G(f) is on the wire while trace f+1 and blur f-1 run,
+// and a frame costs max(kernels, exchange), not their sum.  Frame f is complete on rank 0 when
+// G(f+2) is (pwn_tiled_wait enqueues the outstanding blur and a group with only the second half
+// when no newer frames were submitted); at most three frames are in flight, four buffer sets.
+// Every rank then holds every rank's miss word of frame f: if one is non-zero the bounded halo was
+// not enough for that frame and ALL ranks, having the same words, repeat its exchange with whole
+// strips, its blur and its gather before it is delivered, and use whole strips from then on.  A
+// delivered frame is always exact; the host synchronises only at delivery, two frames behind the
+// submissions.
 //
 // The transport is a small interface: RCCL (ncclSend / ncclRecv in a group, loaded with dlopen so
 // that libpwnhip.so has no link-time dependency on it), or -- for tests on a box with one GPU,
@@ -209,21 +212,26 @@ struct shm_transport : pwn_transport
 };
 
 // ---------------------------------------------------------------- state ----
+#define NSLOT 4          // buffer sets: three frames in flight and the one being reused
 struct pwn_tiled
 {
 	int rank, world, per, y0, y1;
 	int halo;                           // rows exchanged with each neighbour; 0 = whole strips to everybody
-	int fhalo[2];                       // ... as used for the frame in that slot (the mode changes after a miss)
+	int fhalo[NSLOT];                   // ... as used for the frame in that slot (the mode changes after a miss)
 	pwn_transport *tp;
 	hipStream_t comm;
-	uint32_t *pre[2], *out[2], *fin[2]; float *z[2];       // full-frame planes per frame slot (fin: rank 0)
-	uint32_t *missw[2], *missv[2];      // this rank's miss word of the slot's frame; every rank's (world words)
+	uint32_t *pre[NSLOT], *out[NSLOT], *fin[NSLOT]; float *z[NSLOT];     // full-frame planes per frame slot (fin: rank 0)
+	uint32_t *missw[NSLOT], *missv[NSLOT];   // this rank's miss word of the slot's frame; every rank's (world words)
 	uint32_t *h_missv;                  // pinned
 	uint32_t *h_frame;                  // pinned host copy of a delivered frame (rank 0, PWN_TILED_HOST)
-	hipEvent_t ev_t[2], ev_x[2], ev_b[2];
-	hipEvent_t ev_k0[2], ev_k1[2], ev_k2[2];      // timing (PWN_OPT_FRAME_TIMING): around the trace, behind the blur
-	bool has_x[2], has_b[2], timed[2];
-	unsigned long long submitted, gathered, delivered;
+	// per slot: behind the frame's trace; behind the group G(f) it opened; behind its blur; behind the
+	// group that carried its gather (that is G(f+2)'s event or the drain group's)
+	hipEvent_t ev_t[NSLOT], ev_x[NSLOT], ev_b[NSLOT], ev_d[NSLOT];
+	hipEvent_t ev_k0[NSLOT], ev_k1[NSLOT], ev_k2[NSLOT];      // timing (PWN_OPT_FRAME_TIMING): around the trace, behind the blur
+	hipEvent_t gathered_by[NSLOT];      // which of the above marks the slot's gather as done
+	bool timed[NSLOT];
+	// frames: submitted (traced, group opened), blurred (blur enqueued), gathered (gather in a group), delivered
+	unsigned long long submitted, blurred, gathered, delivered;
 	pwn_tiled_info info;
 };
 
@@ -262,13 +270,14 @@ void pwn_tiled_destroy(pwn_ctx *c)
 	(void)hipSetDevice(c->device);
 	(void)hipDeviceSynchronize();
 	delete t->tp;
-	for(int s = 0; s < 2; s++)
+	for(int s = 0; s < NSLOT; s++)
 	{
 		(void)hipFree(t->pre[s]); (void)hipFree(t->out[s]); (void)hipFree(t->fin[s]); (void)hipFree(t->z[s]);
 		(void)hipFree(t->missw[s]); (void)hipFree(t->missv[s]);
 		if(t->ev_t[s]) (void)hipEventDestroy(t->ev_t[s]);
 		if(t->ev_x[s]) (void)hipEventDestroy(t->ev_x[s]);
 		if(t->ev_b[s]) (void)hipEventDestroy(t->ev_b[s]);
+		if(t->ev_d[s]) (void)hipEventDestroy(t->ev_d[s]);
 		if(t->ev_k0[s]) (void)hipEventDestroy(t->ev_k0[s]);
 		if(t->ev_k1[s]) (void)hipEventDestroy(t->ev_k1[s]);
 		if(t->ev_k2[s]) (void)hipEventDestroy(t->ev_k2[s]);
@@ -340,7 +349,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 		else { rc = PWN_EINVAL; break; }
 
 		if(hipStreamCreateWithFlags(&t->comm, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
-		for(int s = 0; s < 2 && rc == PWN_OK; s++)
+		for(int s = 0; s < NSLOT && rc == PWN_OK; s++)
 		{
 			if(hipMalloc((void **)&t->pre[s], n * 4) != hipSuccess || hipMalloc((void **)&t->out[s], n * 4) != hipSuccess ||
 			   hipMalloc((void **)&t->z[s], n * 4) != hipSuccess || hipMalloc((void **)&t->missw[s], 64) != hipSuccess ||
@@ -353,6 +362,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 			if(hipEventCreateWithFlags(&t->ev_t[s], hipEventDisableTiming) != hipSuccess ||
 			   hipEventCreateWithFlags(&t->ev_x[s], hipEventDisableTiming) != hipSuccess ||
 			   hipEventCreateWithFlags(&t->ev_b[s], hipEventDisableTiming) != hipSuccess ||
+			   hipEventCreateWithFlags(&t->ev_d[s], hipEventDisableTiming) != hipSuccess ||
 			   hipEventCreate(&t->ev_k0[s]) != hipSuccess || hipEventCreate(&t->ev_k1[s]) != hipSuccess ||
 			   hipEventCreate(&t->ev_k2[s]) != hipSuccess) { rc = PWN_EHIP; break; }
 		}
@@ -402,7 +412,7 @@ static void rows_of(pwn_ctx *c, pwn_tiled *t, int r, int *a, int *b)
 // the second half of a group: frame `g`'s finished strips to rank 0, its miss words to everybody
 static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 {
-	const int s = (int)(g & 1);
+	const int s = (int)(g % NSLOT);
 	const size_t w4 = (size_t)c->w * 4;
 	uint32_t *mine = c->blur_passes ? t->out[s] : t->pre[s];
 	if(t->rank == 0)
@@ -442,21 +452,44 @@ static int add_allgather(pwn_ctx *c, pwn_tiled *t, int s)
 	return PWN_OK;
 }
 
+// the blur of frame k, behind the group that brought its halo rows
+static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
+{
+	const int s = (int)(k % NSLOT);
+	hipStream_t cs = c->stream;
+	if(c->blur_passes)
+	{
+		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
+		uint32_t *dst = t->rank == 0 ? t->fin[s] : t->out[s];
+		int rc;
+		if(t->fhalo[s])
+		{
+			const int H = t->fhalo[s];
+			const int a0 = t->rank > 0 ? t->y0 - H : 0, a1 = (t->rank < t->world - 1 && t->y1 < c->h) ? t->y1 + H : c->h;
+			rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, a0, a1, t->missw[s]);
+		}
+		else rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL);
+		if(rc != PWN_OK) return rc;
+	}
+	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k2[s], cs));
+	HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
+	return PWN_OK;
+}
+
 extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 {
 	if(c == NULL || cam == NULL || c->tiled == NULL) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
-	if(t->submitted - t->delivered >= 2) return PWN_EBUSY;
+	if(t->submitted - t->delivered >= NSLOT - 1) return PWN_EBUSY;
 	(void)hipSetDevice(c->device);
 	const unsigned long long f = t->submitted;
-	const int s = (int)(f & 1);
+	const int s = (int)(f % NSLOT);
 	const size_t w4 = (size_t)c->w * 4;
 	hipStream_t cs = c->stream;
 	t->fhalo[s] = t->halo;
-	// pre[s] / z[s] / out[s] were last used by frame f-2: its blur ran on this stream; its strips went
-	// out in G(f-1) and in the gather of G(f-1) or of the drain group -- all before ev_x of the other slot
-	if(t->has_x[s ^ 1]) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s ^ 1], 0));
-	if(t->has_x[s]) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
+	// The slot's buffers were frame f-4's.  Its blur ran on this stream; its strips left in G(f-4) and in
+	// the group that carried its gather, and the frame was delivered (three in flight at most), which
+	// waited for that group on the host: nothing to wait for here.
 	uint32_t *plane = c->blur_passes ? t->pre[s] : (t->rank == 0 ? t->fin[s] : t->pre[s]);
 	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
@@ -466,10 +499,19 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	HIPCHK(c, hipMemsetAsync(t->missw[s], 0, 4, cs));
 	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
 
-	// ---- G(f) on the comm stream
+	// ---- the blur of the frames before this one, behind this frame's trace (normally just f-1)
+	for(; t->blurred < f; t->blurred++)
+	{
+		rc = enqueue_blur(c, t, t->blurred);
+		if(rc != PWN_OK) return rc;
+	}
+
+	// ---- G(f) on the comm stream: this frame's pre-blur rows, and the gather of what is blurred and
+	// not gathered yet except the newest blur (its kernel was enqueued a moment ago: next group), i.e.
+	// normally of frame f-2
 	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
-	const bool gather_prev = t->gathered < f;          // frame f-1 has not been gathered yet
-	if(gather_prev && t->has_b[s ^ 1]) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[s ^ 1], 0));
+	const unsigned long long g_end = f >= 1 ? f - 1 : 0;        // gather frames [gathered, g_end)
+	for(unsigned long long g = t->gathered; g < g_end; g++) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
 	if(t->world > 1)
 	{
 		TPCHK(c, t->tp->begin(t->comm));
@@ -493,30 +535,13 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 			}
 			else { rc = add_allgather(c, t, s); if(rc != PWN_OK) return rc; }
 		}
-		if(gather_prev) { rc = add_gather(c, t, f - 1); if(rc != PWN_OK) return rc; }
+		for(unsigned long long g = t->gathered; g < g_end; g++) { rc = add_gather(c, t, g); if(rc != PWN_OK) return rc; }
 		TPCHK(c, t->tp->end());
 		t->info.groups++;
 	}
-	if(gather_prev) t->gathered = f;
 	HIPCHK(c, hipEventRecord(t->ev_x[s], t->comm));
-	t->has_x[s] = true;
-
-	// ---- blur of strip f
-	if(c->blur_passes)
-	{
-		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
-		uint32_t *dst = t->rank == 0 ? t->fin[s] : t->out[s];
-		if(t->halo)
-		{
-			const int a0 = t->rank > 0 ? t->y0 - t->halo : 0, a1 = (t->rank < t->world - 1 && t->y1 < c->h) ? t->y1 + t->halo : c->h;
-			rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, a0, a1, t->missw[s]);
-		}
-		else rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL);
-		if(rc != PWN_OK) return rc;
-	}
-	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k2[s], cs));
-	HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
-	t->has_b[s] = true;
+	for(unsigned long long g = t->gathered; g < g_end; g++) t->gathered_by[g % NSLOT] = t->ev_x[s];
+	if(g_end > t->gathered) t->gathered = g_end;
 	t->submitted = f + 1;
 	return PWN_OK;
 }
@@ -528,27 +553,30 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	if(t->delivered >= t->submitted) return PWN_EINVAL;          // nothing in flight
 	(void)hipSetDevice(c->device);
 	const unsigned long long d = t->delivered;
-	const int s = (int)(d & 1);
+	const int s = (int)(d % NSLOT);
 	const size_t n = (size_t)c->w * (size_t)c->h;
+	int rc;
+	// no newer frame has enqueued this one's blur / carried its gather: do both now
+	for(; t->blurred <= d; t->blurred++)
+	{
+		rc = enqueue_blur(c, t, t->blurred);
+		if(rc != PWN_OK) return rc;
+	}
 	if(t->gathered <= d)
 	{
-		// no newer frame carries this one's gather: a group of its own
-		HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[s], 0));
+		for(unsigned long long g = t->gathered; g <= d; g++) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
 		if(t->world > 1)
 		{
 			TPCHK(c, t->tp->begin(t->comm));
-			int rc = add_gather(c, t, d);
-			if(rc != PWN_OK) return rc;
+			for(unsigned long long g = t->gathered; g <= d; g++) { rc = add_gather(c, t, g); if(rc != PWN_OK) return rc; }
 			TPCHK(c, t->tp->end());
 			t->info.groups++;
 		}
+		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
+		for(unsigned long long g = t->gathered; g <= d; g++) t->gathered_by[g % NSLOT] = t->ev_d[s];
 		t->gathered = d + 1;
-		HIPCHK(c, hipEventRecord(t->ev_x[s], t->comm));     // (slot s: what has to be over before trace d+2 reuses it)
-		t->has_x[s] = true;
-		HIPCHK(c, hipEventSynchronize(t->ev_x[s]));
 	}
-	else
-		HIPCHK(c, hipEventSynchronize(t->ev_x[s ^ 1]));      // G(d+1) carried it
+	HIPCHK(c, hipEventSynchronize(t->gathered_by[s]));
 	HIPCHK(c, hipEventSynchronize(t->ev_b[s]));               // (world 1, and rank 0's own strip)
 
 	// ---- was the bounded halo enough for this frame, on every rank?
@@ -565,21 +593,27 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	{
 		// Every rank sees the same words and comes here together: the frame's exchange again with
 		// whole strips (pre[s] and z[s] still hold this frame), blur, gather; whole strips from now on.
+		// On the comm stream, behind the groups of the newer frames that are already in it.
 		t->info.frames_redone++;
 		t->halo = 0; t->fhalo[s] = 0;
 		hipStream_t cs = c->stream;
-		TPCHK(c, t->tp->begin(cs));
-		int rc = add_allgather(c, t, s);
+		TPCHK(c, t->tp->begin(t->comm));
+		rc = add_allgather(c, t, s);
 		if(rc != PWN_OK) return rc;
 		TPCHK(c, t->tp->end());
+		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
+		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_d[s], 0));
 		uint32_t *dst = t->rank == 0 ? t->fin[s] : t->out[s];
 		rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL);
 		if(rc != PWN_OK) return rc;
-		TPCHK(c, t->tp->begin(cs));
+		HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
+		HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[s], 0));
+		TPCHK(c, t->tp->begin(t->comm));
 		rc = add_gather(c, t, d);
 		if(rc != PWN_OK) return rc;
 		TPCHK(c, t->tp->end());
 		t->info.groups += 2;
+		HIPCHK(c, hipStreamSynchronize(t->comm));
 		HIPCHK(c, hipStreamSynchronize(cs));
 	}
 	t->delivered = d + 1;
@@ -593,7 +627,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		if(t->timed[s])
 		{
 			(void)hipEventElapsedTime(&out->trace_ms, t->ev_k0[s], t->ev_k1[s]);
-			(void)hipEventElapsedTime(&out->frame_ms, t->ev_k0[s], t->ev_k2[s]);      // trace .. blur, the exchange in between
+			(void)hipEventElapsedTime(&out->frame_ms, t->ev_k0[s], t->ev_k2[s]);      // trace .. blur: the next frame's trace and the exchange in between
 		}
 		if(t->rank == 0)
 		{

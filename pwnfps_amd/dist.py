@@ -3,7 +3,7 @@
 operations.
 
 The product path is the C one: ``Renderer.tiled_init / tiled_submit / tiled_wait``
-(``include/pwnhip.h``, RCCL inside the library); ``bench.py --gpus N`` and ``host/pwnhost -n N``
+(``include/pwnhip.h``, RCCL inside the library); ``bench.py --gpus N`` and ``host/pwnhost -W N``
 use it.  This module is the same state machine, statement for statement, with
 
 * the transport = one ``batch_isend_irecv`` per grouped exchange (gloo on CPU, nccl = RCCL on
@@ -19,27 +19,31 @@ by world_size 2 / 3 / 8 tests without a GPU (tests/test_dist_gloo.py).
 One process per rank; rank r owns rows [r*per, min((r+1)*per, h)), per = ceil(h/world) rounded
 up to 8 (the reference parallelises the same loops with OpenMP over rows, screen.h:63,77).  The
 trace pass needs no exchange.  The blur does: its taps reach 0.002*h*(depth-1) rows
-(screen.h:100-102), unbounded in depth.  Per frame f (slot s = f & 1):
+(screen.h:100-102), unbounded in depth.  Per submitted frame f (slot s = f mod 4):
 
     trace strip f -> pre[s], z[s]
+    blur strip f-1 from pre rows [y0-H, y1+H) -> out (behind the group that brought its halo rows);
+        taps outside those rows are counted in the rank's miss word of that frame
     ONE grouped exchange G(f):
         the H border rows of strip f to / from the neighbour strips (or, without a halo,
             every strip to everybody)
-        the FINISHED strip of frame f-1 to rank 0
-        the miss word of frame f-1 to every rank
-    blur strip f from pre[s] rows [y0-H, y1+H) -> out[s]; taps outside those rows are
-        counted in the rank's miss word of frame f
+        the FINISHED strip of frame f-2 to rank 0
+        the miss word of frame f-2 to every rank
 
-Frame f-1 is complete on rank 0 when G(f) is (``wait`` issues a group with only the second
-half when no newer frame was submitted).  Every rank then holds every rank's miss word of frame
-f-1: if one is non-zero ALL ranks repeat that frame's exchange with whole strips, its blur and
-its gather before it is delivered, and use whole strips from then on.
+(In the C code the blur of a frame sits behind the next frame's trace on the compute stream so
+that the stream never waits for the exchange; here everything is synchronous and only the order
+matters.)  Frame f is complete on rank 0 when G(f+2) is (``wait`` enqueues the outstanding blur and
+a group with only the second half when no newer frames were submitted); three frames in flight at
+most.  Every rank then holds every rank's miss word of frame f: if one is non-zero ALL ranks repeat
+that frame's exchange with whole strips, its blur and its gather before it is delivered, and use
+whole strips from then on.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
 TAG_HALO, TAG_STRIP, TAG_GATHER, TAG_MISS = 1, 2, 3, 4
+NSLOT = 4          # buffer sets: three frames in flight and the one being reused
 
 
 def strip_rows(h, world):
@@ -110,15 +114,15 @@ class TiledFrames:
         if world == 1 or self.blur_passes == 0 or H > shortest or H <= 0:
             H = 0
         self.halo = H                       # rows exchanged with each neighbour; 0 = whole strips to everybody
-        self.fhalo = [0, 0]                 # ... as used for the frame in that slot
+        self.fhalo = [0] * NSLOT            # ... as used for the frame in that slot
         kw = dict(device=device)
-        mk = lambda dt: [torch.zeros((self.h, self.w), dtype=dt, **kw) for _ in range(2)]   # noqa: E731
+        mk = lambda dt: [torch.zeros((self.h, self.w), dtype=dt, **kw) for _ in range(NSLOT)]   # noqa: E731
         # int32 views of the uint32 BGRA pixels (the transport does not care)
         self.pre, self.out, self.z = mk(torch.int32), mk(torch.int32), mk(torch.float32)
-        self.fin = mk(torch.int32) if rank == 0 else [None, None]
-        self.missw = [torch.zeros(1, dtype=torch.int32, **kw) for _ in range(2)]
-        self.missv = [torch.zeros(world, dtype=torch.int32, **kw) for _ in range(2)]
-        self.submitted = self.gathered = self.delivered = 0
+        self.fin = mk(torch.int32) if rank == 0 else [None] * NSLOT
+        self.missw = [torch.zeros(1, dtype=torch.int32, **kw) for _ in range(NSLOT)]
+        self.missv = [torch.zeros(world, dtype=torch.int32, **kw) for _ in range(NSLOT)]
+        self.submitted = self.blurred = self.gathered = self.delivered = 0
         self.info = dict(frames=0, frames_redone=0, groups=0, bytes_sent=0, bytes_received=0)
 
     # ---- the transport: a group = operations that progress together -----------------------
@@ -144,7 +148,7 @@ class TiledFrames:
 
     # ---- pieces of a group (add_gather / add_allgather of pwn_tiled.cpp) ------------------
     def _add_gather(self, g):
-        s = g & 1
+        s = g % NSLOT
         mine = self.out[s] if self.blur_passes else self.pre[s]
         if self.rank == 0:
             for r in range(1, self.world):
@@ -170,18 +174,35 @@ class TiledFrames:
             if b > a:
                 self._recv(self.pre[s][a:b], r, TAG_STRIP)
 
+    def _enqueue_blur(self, k):
+        s = k % NSLOT
+        if self.blur_passes:
+            dst = self.fin[s] if self.rank == 0 else self.out[s]
+            if self.fhalo[s]:
+                H = self.fhalo[s]
+                a0 = self.y0 - H if self.rank > 0 else 0
+                a1 = self.y1 + H if (self.rank < self.world - 1 and self.y1 < self.h) else self.h
+                self.backend.blur_rows_bounded(self.y0, self.y1, self.pre[s], self.z[s], dst, a0, a1, self.missw[s])
+            else:
+                self.backend.blur_rows(self.y0, self.y1, self.pre[s], self.z[s], dst)
+
     # ---- pwn_tiled_submit ---------------------------------------------------------------------
     def submit(self, cam, sec=0.0):
-        if self.submitted - self.delivered >= 2:
-            raise RuntimeError("two frames are in flight: wait() first (PWN_EBUSY)")
+        if self.submitted - self.delivered >= NSLOT - 1:
+            raise RuntimeError("three frames are in flight: wait() first (PWN_EBUSY)")
         f = self.submitted
-        s = f & 1
+        s = f % NSLOT
         self.fhalo[s] = self.halo
         cam = np.ascontiguousarray(cam, np.float32).reshape(16)
         plane = self.pre[s] if self.blur_passes else (self.fin[s] if self.rank == 0 else self.pre[s])
         self.backend.trace_rows(cam, float(sec), self.y0, self.y1, plane, self.z[s])
         self.missw[s].zero_()
-        gather_prev = self.gathered < f
+        # the blur of the frames before this one (normally just f-1)
+        while self.blurred < f:
+            self._enqueue_blur(self.blurred)
+            self.blurred += 1
+        # G(f): this frame's pre-blur rows, and the gather of what is blurred except the newest blur
+        g_end = f - 1 if f >= 1 else 0
         if self.world > 1:
             self._begin()
             if self.blur_passes:
@@ -195,34 +216,29 @@ class TiledFrames:
                         self._recv(self.pre[s][self.y1:self.y1 + H], self.rank + 1, TAG_HALO)
                 else:
                     self._add_allgather(s)
-            if gather_prev:
-                self._add_gather(f - 1)
+            for g in range(self.gathered, g_end):
+                self._add_gather(g)
             self._end()
-        if gather_prev:
-            self.gathered = f
-        if self.blur_passes:
-            dst = self.fin[s] if self.rank == 0 else self.out[s]
-            if self.halo:
-                a0 = self.y0 - self.halo if self.rank > 0 else 0
-                a1 = self.y1 + self.halo if (self.rank < self.world - 1 and self.y1 < self.h) else self.h
-                self.backend.blur_rows_bounded(self.y0, self.y1, self.pre[s], self.z[s], dst, a0, a1, self.missw[s])
-            else:
-                self.backend.blur_rows(self.y0, self.y1, self.pre[s], self.z[s], dst)
+        self.gathered = max(self.gathered, g_end)
         self.submitted = f + 1
 
     # ---- pwn_tiled_wait -------------------------------------------------------------------------
     def wait(self):
         """Oldest frame in flight, on every rank.  Returns (frame, redone): frame = the full frame
-        tensor on rank 0 (valid until two more frames were submitted), None elsewhere."""
+        tensor on rank 0 (valid until three more frames were submitted), None elsewhere."""
         if self.delivered >= self.submitted:
             raise RuntimeError("nothing in flight")
         d = self.delivered
-        s = d & 1
+        s = d % NSLOT
+        # no newer frame has enqueued this one's blur / carried its gather: do both now
+        while self.blurred <= d:
+            self._enqueue_blur(self.blurred)
+            self.blurred += 1
         if self.gathered <= d:
-            # no newer frame carries this one's gather: a group of its own
             if self.world > 1:
                 self._begin()
-                self._add_gather(d)
+                for g in range(self.gathered, d + 1):
+                    self._add_gather(g)
                 self._end()
             self.gathered = d + 1
         miss = False

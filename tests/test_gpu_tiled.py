@@ -75,13 +75,13 @@ def test_tiled_frames_are_the_oracles_frames(world, tmp_path, oracle_lib):
             assert sum(redone) == 0 and all(i["frames_redone"] == 0 for i in infos)
         if world > 1 and halo == 1:
             # the first frame whose taps leave the halo is repeated with whole strips on EVERY rank,
-            # later frames use whole strips: at most two frames were in flight with the small halo
-            assert 1 <= sum(redone) <= 2 and len({i["frames_redone"] for i in infos}) == 1
+            # later frames use whole strips: at most three frames were in flight with the small halo
+            assert 1 <= sum(redone) <= 3 and len({i["frames_redone"] for i in infos}) == 1
             assert all(i["halo_rows"] == 0 for i in infos)
         if world > 1 and halo == -1:
             assert all(i["halo_rows"] == int(0.002 * h * 24) + 2 for i in infos)
-            # one grouped exchange per frame plus the one that drains the last frame
-            assert all(i["groups"] == frames + 1 for i in infos)
+            # one grouped exchange per frame plus two that drain the last two frames
+            assert all(i["groups"] == frames + 2 for i in infos)
 
 
 def test_tiled_without_blur_and_uneven_strips(tmp_path, oracle_lib):

@@ -71,9 +71,10 @@ def main():
         cam, sec, sph = scene(k, base, spawn)
         r.set_objects(sph)
         r.tiled_submit(cam, sec)
-        if k >= 1:
-            deliver(k - 1)
-    deliver(frames - 1)
+        if k >= 2:
+            deliver(k - 2)
+    for k in range(max(0, frames - 2), frames):
+        deliver(k)
     print("info " + json.dumps(r.tiled_info()), flush=True)
     r.tiled_shutdown()
     r.close()
