@@ -20,6 +20,10 @@
  * turning, walking with push-back, gravity, portals), driven by key events from a script
  * (`FRAME KEY down|up`, keys left right up down w s a d quit; polled after frame FRAME like
  * SDL_PollEvent at main.c:142).  -a is ignored then.
+ * -S 1 (hosts built with SDL 1.2: host/Makefile finds sdl-config) opens the reference's window
+ * (main.c:386-394), shows every frame (SDL_Flip, main.c:109) and takes the keys from it (main.c:142-186:
+ * arrows turn, w s a d walk, closing the window quits): the playable loop; the clock is the wall clock
+ * like main.c:112-114 unless -t is given.  The blocking loop only (no -q / -W).
  * -l game.lua (hosts built with Lua 5.1: host/Makefile) runs a script by path in a Lua VM whose
  * obj_new / obj_set / obj_free / level_get act on the library's object table (script.h:1-103).
  * -t fixes the clock step (the reference uses wall time, main.c:112-114), which
@@ -47,6 +51,9 @@
 #include "player.h"
 #ifdef HAVE_LUA
 #include "lua_host.h"
+#endif
+#ifdef HAVE_SDL
+#include <SDL.h>
 #endif
 
 /* the globals a reference host owns (main.c:26-34) */
@@ -160,7 +167,7 @@ int main(int argc, char **argv)
 {
 	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL, *luafile = NULL, *keyfile = NULL;
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
-	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL;
+	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL, window = 0, frames_given = 0;
 	const char *idfile = NULL;
 	float turn = 0.0f, fixed_dt = -1.0f;
 	for(int i = 1; i < argc; i++)
@@ -173,12 +180,13 @@ int main(int argc, char **argv)
 			case 'g': gamefile = argv[++i]; break;
 			case 'l': luafile = argv[++i]; break;
 			case 'k': keyfile = argv[++i]; break;
+			case 'S': window = atoi(argv[++i]); break;
 			case 't': fixed_dt = (float)atof(argv[++i]); break;
 			case 'v': verbose = atoi(argv[++i]); break;
 			case 'w': rwidth = atoi(argv[++i]); break;
 			case 'h': rheight = atoi(argv[++i]); break;
 			case 'x': rscale = atoi(argv[++i]); break;
-			case 'n': frames = atoi(argv[++i]); break;
+			case 'n': frames = atoi(argv[++i]); frames_given = 1; break;
 			case 'a': turn = (float)atof(argv[++i]); break;
 			case 'p': pitch = atoi(argv[++i]); break;
 			case 'b': blur = atoi(argv[++i]); break;
@@ -206,6 +214,11 @@ int main(int argc, char **argv)
 		return 2;
 	}
 	if(slots != 0 && (slots < 2 || slots > PWN_MAX_SLOTS)) { fprintf(stderr, "-q takes 2..%d\n", PWN_MAX_SLOTS); return 2; }
+#ifndef HAVE_SDL
+	if(window) { fprintf(stderr, "-S: this pwnhost was built without SDL 1.2 (host/Makefile)\n"); return 2; }
+#endif
+	if(window && (slots != 0 || world > 1)) { fprintf(stderr, "-S goes with the blocking loop only\n"); return 2; }
+	if(window && !frames_given) frames = 0x7fffffff;          /* a window runs until it is closed (SDL_QUIT, main.c:145) */
 #ifndef HAVE_LUA
 	if(luafile != NULL) { fprintf(stderr, "-l %s: this pwnhost was built without Lua 5.1 (host/Makefile); use -g\n", luafile); return 2; }
 #endif
@@ -239,14 +252,15 @@ int main(int argc, char **argv)
 	int nkey_ev = 0;
 	memset(&keys, 0, sizeof(keys));
 	pwn_player_init(&player, spawn);
+	const int interactive = keyfile != NULL || window;
+	if(interactive) CHK(pwn_get_level(ctx, cells, pmap, NULL));
 	if(keyfile != NULL)
 	{
 		nkey_ev = pwn_keys_load(keyfile, key_ev, 4096);
 		if(nkey_ev < 0 || nkey_ev > 4096) { fprintf(stderr, "cannot read the key script %s\n", keyfile); pwn_destroy(ctx); return 1; }
-		CHK(pwn_get_level(ctx, cells, pmap, NULL));
 		if(fixed_dt < 0.0f) fixed_dt = 1.0f / 60.0f;          /* a scripted run is reproducible: a fixed clock step */
 	}
-#define PLAYER(frame, dt) (keyfile != NULL && player_tick(&player, &keys, key_ev, nkey_ev, (frame), (dt), cells, pmap))
+#define PLAYER(frame, dt) (interactive && player_tick(&player, &keys, key_ev, nkey_ev, (frame), (dt), cells, pmap))
 	pwn_sphere *sph = NULL;
 	int nsph = 0;
 	if(sphfile != NULL && (nsph = load_spheres(sphfile, &sph)) < 0) { fprintf(stderr, "cannot read %s\n", sphfile); pwn_destroy(ctx); return 1; }
@@ -312,7 +326,7 @@ int main(int argc, char **argv)
 			if(f < frames)
 			{
 				float cam[16];
-				frame_camera(cam, keyfile != NULL ? &player : NULL, ang, spawn);
+				frame_camera(cam, interactive ? &player : NULL, ang, spawn);
 				CHK(pwn_prepare_render(ctx));                                           /* main.c:95 */
 				CHK(pwn_tiled_submit(ctx, cam, sec_current));                          /* main.c:107 */
 			}
@@ -376,7 +390,7 @@ int main(int argc, char **argv)
 			if(f < frames)
 			{
 				float cam[16];
-				frame_camera(cam, keyfile != NULL ? &player : NULL, ang, spawn);
+				frame_camera(cam, interactive ? &player : NULL, ang, spawn);
 				CHK(pwn_prepare_render(ctx));                                           /* main.c:95 */
 				CHK(pwn_submit_frame(ctx, cam, sec_current, f % slots));                /* main.c:107-108 */
 				sec_current += fixed_dt;                                                /* main.c:112-114 */
@@ -401,10 +415,23 @@ int main(int argc, char **argv)
 		free(sph); free(sbuf); free(zbuf); free(surface.pixels);
 		return 0;
 	}
+#ifdef HAVE_SDL
+	SDL_Surface *screen = NULL;
+	if(window)                                                                  /* main.c:386-394 */
+	{
+		if(SDL_Init(SDL_INIT_VIDEO | SDL_INIT_TIMER) != 0 || (screen = SDL_SetVideoMode(rwidth * rscale, rheight * rscale, 32, 0)) == NULL)
+		{
+			fprintf(stderr, "SDL: %s\n", SDL_GetError());
+			pwn_destroy(ctx);
+			return 1;
+		}
+		SDL_WM_SetCaption("pwnfps on libpwnhip", NULL);
+	}
+#endif
 	for(int f = 0; f < frames; f++)
 	{
 		float cam[16];
-		frame_camera(cam, keyfile != NULL ? &player : NULL, ang, spawn);
+		frame_camera(cam, interactive ? &player : NULL, ang, spawn);
 
 		double t0 = now_s();
 		CHK(pwn_prepare_render(ctx));                                           /* level_prepare_render, main.c:95 */
@@ -420,9 +447,44 @@ int main(int argc, char **argv)
 		if(gamefile != NULL)
 			CHK(game_script_on_tick(&game, ctx, (double)sec_current, (double)tdiff));   /* main.c:127-140 */
 		TICK((double)sec_current, (double)tdiff);
+#ifdef HAVE_SDL
+		if(window)
+		{
+			/* SDL_Flip, main.c:109: the sink's surface into the window's, row by row (the pitches may differ) */
+			if(SDL_MUSTLOCK(screen)) SDL_LockSurface(screen);
+			for(int y = 0; y < rheight * rscale; y++)
+				memcpy((unsigned char *)screen->pixels + (size_t)y * screen->pitch, (unsigned char *)surface.pixels + (size_t)y * (size_t)surface.pitch,
+					(size_t)rwidth * (size_t)rscale * 4);
+			if(SDL_MUSTLOCK(screen)) SDL_UnlockSurface(screen);
+			SDL_Flip(screen);
+			SDL_Event ev;                                                          /* main.c:142-186 */
+			while(SDL_PollEvent(&ev))
+			{
+				if(ev.type == SDL_QUIT) frames = f + 1;
+				if(ev.type != SDL_KEYDOWN && ev.type != SDL_KEYUP) continue;
+				int sym = PWN_KEY_NONE;
+				switch(ev.key.keysym.sym)
+				{
+					case SDLK_LEFT: sym = PWN_KEY_LEFT; break;
+					case SDLK_RIGHT: sym = PWN_KEY_RIGHT; break;
+					case SDLK_UP: sym = PWN_KEY_UP; break;
+					case SDLK_DOWN: sym = PWN_KEY_DOWN; break;
+					case SDLK_w: sym = PWN_KEY_W; break;
+					case SDLK_s: sym = PWN_KEY_S; break;
+					case SDLK_a: sym = PWN_KEY_A; break;
+					case SDLK_d: sym = PWN_KEY_D; break;
+					default: break;
+				}
+				pwn_keys_event(&keys, sym, ev.type == SDL_KEYDOWN);
+			}
+		}
+#endif
 		if(PLAYER(f, tdiff)) frames = f + 1;                                        /* SDL_QUIT, main.c:145 */
 		ang += turn;
 	}
+#ifdef HAVE_SDL
+	if(window) SDL_Quit();
+#endif
 
 	pwn_stats st;
 	CHK(pwn_get_stats(ctx, &st));

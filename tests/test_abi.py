@@ -47,10 +47,10 @@ def test_no_gpu_is_an_error_not_a_fallback():
 
 
 def test_product_does_not_touch_the_oracle():
-    """Nothing under pwnfps_amd/ or include/ may import, include, link or
-    dlopen anything under oracle/ (or tests/)."""
+    """Nothing under pwnfps_amd/, host/ or include/ may import, include, link or
+    dlopen anything under oracle/ (or tests/, or the test-only interpreter tools/minilua.py)."""
     bad = []
-    for base in ("pwnfps_amd", "include"):
+    for base in ("pwnfps_amd", "include", "host"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
             if "build" in dp or "__pycache__" in dp:
                 continue
@@ -59,7 +59,7 @@ def test_product_does_not_touch_the_oracle():
                     continue
                 src = open(os.path.join(dp, f), errors="replace").read()
                 for pat in (r'#include\s*"[^"]*oracle', r"\boracle[/.]", r"libpwnoracle", r"pwno_", r"import oracle",
-                            r"refharness", r"libpwnref", r"/root/reference"):
+                            r"refharness", r"libpwnref", r"/root/reference", r"import minilua", r"minilua\."):
                     for m in re.finditer(pat, src):
                         line = src[:m.start()].count("\n") + 1
                         bad.append("%s:%d %s" % (os.path.join(dp, f), line, m.group(0)))

@@ -81,6 +81,28 @@ def test_all_golden_cases(oracle_lib, cases):
         r.close()
 
 
+def test_golden_cases_through_the_general_four_lane_variant(oracle_lib, cases, monkeypatch):
+    """The goldens' cameras carry no w components and take the 3-lane specialisation.  The general (HAS_W)
+    kernel variants are only reached by unusual cameras -- and were the ones with the layout-dependent
+    miscompile of round 1 (dev_math.h) -- so the fixed goldens are also rendered through them
+    (PWN_DBG_FORCE_HASW, read at every launch): both schedulers, sizes up to 4K."""
+    monkeypatch.setenv("PWN_DBG_FORCE_HASW", "1")
+    import pwnfps_amd
+    names = ("level_spawn_320x240", "level_pose1_1280x720", "synth64_cam0_1920x1080", "level_spawn_3840x2160", "synth256_cam1_480x272")
+    picked = [c for c in cases if c["name"] in names]
+    assert len(picked) >= 3
+    for sched in ("units", "refill"):
+        for c in picked:
+            r = _renderer(c["w"], c["h"])
+            r.set_scheduler(sched)
+            r.level_load(level_path(c["level"]))
+            r.set_objects(load_spheres(c["spheres"]))
+            post, z = r.trace_screen_centred(np.array(c["cam"], np.float32), c["sec"])
+            assert _fnv(oracle_lib, post) == c["post"], (sched, c["name"])
+            assert _fnv(oracle_lib, z) == c["z"], (sched, c["name"])
+            r.close()
+
+
 def test_depth_with_exhausted_rays_fresh_context(oracle_lib, cases):
     cs = [c for c in cases if c.get("exhausted", 0) > 0 or "exhausted" not in c]
     assert cs
