@@ -114,3 +114,59 @@ def test_tiled_over_rccl_with_one_rank(tmp_path, oracle_lib):
     hashes, infos = run_ranks(1, w, h, "pwnfps_level", frames, -1, tmp_path, transport="rccl")
     assert [x[1] for x in hashes] == want
     assert infos[0]["transport"] == 0 and infos[0]["world"] == 1
+
+
+@pytest.mark.parametrize("name", ["level_spawn_3840x2160", "synth256_cam0_7680x4320"])
+def test_eight_strip_geometry_single_process(name, oracle_lib, cases):
+    """The per-rank kernels of an 8-GPU run at the BASELINE sizes, one process: every strip of the 8-way
+    tiling traced with pwn_trace_rows_device, then blurred with pwn_blur_rows_device_bounded from a
+    plane that holds ONLY the rows that rank would have (its strip and the default halo: 105 rows at 4K,
+    209 at 8K) and poison everywhere else.  The assembled frame is the compiled reference's golden frame,
+    or, where the taps leave the halo (the mirror halls of synth256), the strips say so."""
+    import torch
+    import pwnfps_amd
+    from pwnfps_amd.dist import default_halo, strip_range
+    c = [x for x in cases if x["name"] == name][0]
+    w, h = c["w"], c["h"]
+    r = pwnfps_amd.Renderer(w, h)
+    r.level_load(level_path(c["level"]))
+    key = "t0" if c["level"] == "pwnfps_level" else c["level"]
+    from conftest import load_spheres
+    r.set_objects(load_spheres(key))
+    cam = np.array(c["cam"], np.float32)
+    dev = torch.device("cuda:0")
+    pre = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    z = torch.zeros((h, w), dtype=torch.float32, device=dev)
+    out = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    miss = torch.zeros(8, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    for rank in range(8):
+        y0, y1 = strip_range(h, 8, rank)
+        r.trace_rows_device(cam, c["sec"], y0, y1, pre.data_ptr(), z.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert oracle_lib.fnv64(pre.cpu().numpy()) == c["pre"]
+    H = default_halo(h)
+    assert H == {2160: 105, 4320: 209}[h]
+    for rank in range(8):
+        y0, y1 = strip_range(h, 8, rank)
+        a0, a1 = (y0 - H if rank > 0 else 0), (y1 + H if rank < 7 else h)
+        have = torch.full_like(pre, 0x5EADBEEF - (1 << 32))
+        have[a0:a1] = pre[a0:a1]
+        r.blur_rows_device_bounded(y0, y1, have.data_ptr(), z.data_ptr(), out.data_ptr(), a0, a1, miss[rank:rank + 1].data_ptr(), s)
+    torch.cuda.synchronize()
+    misses = miss.cpu().numpy()
+    if (misses == 0).all():
+        assert oracle_lib.fnv64(out.cpu().numpy()) == c["post"]
+    else:
+        # taps left the halo somewhere: those strips are repeated with whole strips (pwn_tiled_wait);
+        # the strips that reported nothing are already the golden's
+        assert c["level"] == "synth256"
+        for rank in range(8):
+            y0, y1 = strip_range(h, 8, rank)
+            if misses[rank]:
+                r.blur_rows_device(y0, y1, pre.data_ptr(), z.data_ptr(), out.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert oracle_lib.fnv64(out.cpu().numpy()) == c["post"]
+    if c["level"] == "pwnfps_level":
+        assert (misses == 0).all()
+    r.close()
