@@ -150,7 +150,7 @@ def test_eight_strip_geometry_single_process(name, oracle_lib, cases):
     for rank in range(8):
         y0, y1 = strip_range(h, 8, rank)
         a0, a1 = (y0 - H if rank > 0 else 0), (y1 + H if rank < 7 else h)
-        have = torch.full_like(pre, 0x5EADBEEF - (1 << 32))
+        have = torch.full_like(pre, 0x5EADBEEF)
         have[a0:a1] = pre[a0:a1]
         r.blur_rows_device_bounded(y0, y1, have.data_ptr(), z.data_ptr(), out.data_ptr(), a0, a1, miss[rank:rank + 1].data_ptr(), s)
     torch.cuda.synchronize()
