@@ -514,7 +514,7 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	P.wave_log = NULL;
 	if(c->wave_log_on)
 	{
-		const size_t bytes = (size_t)c->num_cus * 8 * 4 * 16;
+		const size_t bytes = ((size_t)c->num_cus * 8 * 4 + 1) * 16;       // entry 0: the number of waves that logged
 		if(c->d_wave_log == NULL) HIPCHK(c, hipMalloc((void **)&c->d_wave_log, bytes));
 		HIPCHK(c, hipMemsetAsync(c->d_wave_log, 0, bytes, stream));
 		P.wave_log = c->d_wave_log;
@@ -815,10 +815,10 @@ extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 	}
 	if(c->wave_log_on && c->d_wave_log != NULL)
 	{
-		std::vector<unsigned long long> log((size_t)c->num_cus * 8 * 4 * 2);
+		std::vector<unsigned long long> log(((size_t)c->num_cus * 8 * 4 + 1) * 2);
 		HIPCHK(c, hipMemcpy(log.data(), c->d_wave_log, log.size() * 8, hipMemcpyDeviceToHost));
 		unsigned long long sum = 0, first = ~0ull, last = 0, n = 0;
-		for(size_t i = 0; i + 1 < log.size(); i += 2)
+		for(size_t i = 2; i + 1 < log.size(); i += 2)
 		{
 			if(log[i + 1] == 0) continue;
 			sum += log[i + 1] - log[i]; n++;

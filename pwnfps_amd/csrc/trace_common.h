@@ -41,6 +41,28 @@ __device__ __forceinline__ uint32_t cellword_at(const Lds &L, int cx, int cz)
 	return L.cellinfo[uz * PWN_GRID_PITCH + ux];
 }
 
+// The walk keeps the cell coordinates as two signed 16-bit fields of ONE register (x low, z high; a ray
+// makes at most 1000 steps from a cell of the 64 x 64 grid, so 16 bits hold them), and its per-axis steps
+// (gx, 0) / (0, gz) the same way.  A cell step is then one packed add, get_cell's per-axis clamp one
+// packed unsigned min (a negative coordinate is a large unsigned one: 64, the repeat of index 0) and
+// the byte offset x*4 + z*260 one v_dot2_u32_u16: 4 VALU where separate ints took 9.
+typedef unsigned short pwn_us2 __attribute__((ext_vector_type(2)));
+typedef short pwn_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cxz_pack(int cx, int cz) { return ((uint32_t)cx & 0xffffu) | ((uint32_t)cz << 16); }
+__device__ __forceinline__ int cxz_x(uint32_t c) { return (int)(int16_t)(uint16_t)(c & 0xffffu); }
+__device__ __forceinline__ int cxz_z(uint32_t c) { return (int)c >> 16; }
+__device__ __forceinline__ uint32_t cxz_add(uint32_t c, uint32_t step)
+{
+	return __builtin_bit_cast(uint32_t, (pwn_s2)(__builtin_bit_cast(pwn_s2, c) + __builtin_bit_cast(pwn_s2, step)));
+}
+__device__ __forceinline__ uint32_t cellword_pk(const Lds &L, uint32_t cxz)
+{
+	const pwn_us2 lim = { 64, 64 }, pitch = { 4, (unsigned short)(PWN_GRID_PITCH * 4u) };
+	const pwn_us2 c = __builtin_elementwise_min(__builtin_bit_cast(pwn_us2, cxz), lim);
+	const uint32_t byte = __builtin_amdgcn_udot2(c, pitch, 0u, false);
+	return *(const uint32_t *)((const unsigned char *)L.cellinfo + byte);
+}
+
 // HAS_W = false: the camera rows x,y,z carry w = 0 and the position w = 1
 // (mat4_iden + rotations, main.c:61-64).  Then every ray has w = +-0 and every
 // position w = 1, sphere-relative vectors have w = 0, and each 4-lane dot

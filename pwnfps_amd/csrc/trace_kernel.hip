@@ -120,8 +120,10 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		uint32_t iay_up_bits = gyp ? __float_as_uint(iay) : 0u;         // +iay when looking up, else +0
 		asm volatile("" : "+v"(iay_up_bits));        // keep it a register, not a select on gyp per step
 		int ldx = (gx < 0 ? FXN : FXP), ldz = (gz < 0 ? FZN : FZP);
+		// cell coordinates and steps in the packed form the walk uses (trace_common.h)
+		uint32_t cxz = cxz_pack(cx, cz), sx = (uint32_t)gx & 0xffffu, sz = (uint32_t)gz << 16;
 
-		uint32_t cw = cellword_at(L, cx, cz);
+		uint32_t cw = cellword_pk(L, cxz);
 		int ldir = FYN;
 		int ev = EV_NONE, base = BASE_ROOM_Y;
 
@@ -455,9 +457,15 @@ pwn_trace_kernel(pwn_trace_params P)
 		}
 	}
 	// PWN_OPT_WAVE_LOG: every wave's lifetime (pwn_stats.wave_time ..., tools/wave_log.py)
-	if(P.wave_log != NULL && (threadIdx.x & 63) == 0)
+	// (Which wave of the workgroup this is comes from the hardware: the four waves of a 256-thread workgroup
+	// sit on the four SIMDs of their CU, HW_ID.simd_id is bits 5:4 of hardware register 4; the lane number
+	// comes from mbcnt.  Keeping threadIdx.x alive to the end of the kernel costs a scratch slot per lane,
+	// and a shared append counter serialises the waves' exits and stretches the very tail it measures.)
+	if(P.wave_log != NULL && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
 	{
-		const size_t wid = (size_t)blockIdx.x * (PWN_BLOCK / 64) + (size_t)(threadIdx.x >> 6);
+		static_assert(PWN_BLOCK == 256, "one wave per SIMD: simd_id tells the waves of a workgroup apart");
+		const unsigned simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11));
+		const size_t wid = 1u + (size_t)blockIdx.x * 4u + simd;
 		P.wave_log[2 * wid] = t_begin; P.wave_log[2 * wid + 1] = __builtin_amdgcn_s_memrealtime();
 	}
 }

@@ -104,7 +104,8 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 	pos.x = pos.y = pos.z = pos.w = 0.0f; ray = pos; aux_pos = pos;
 	float cdist = 0.0f, fog = 0.0f, aux_dist = __builtin_inff(), aux_diff = 0.0f;
 	uint32_t aux_idx = 0u;
-	int cx = 0, cz = 0, gx = 1, gz = 1, ldx = FXP, ldz = FZP, ldy = FYP, ldir = FYN, base = BASE_ROOM_Y, maxsteps = 0;
+	uint32_t cxz = 0u, sx = 1u, sz = 1u << 16;         // cell x | z << 16 and the steps (gx, 0), (0, gz): trace_common.h
+	int ldx = FXP, ldz = FZP, ldy = FYP, ldir = FYN, base = BASE_ROOM_Y, maxsteps = 0;
 	float wx = 0.0f, wy = 0.0f, wz = 0.0f, iax = 0.0f, iay = 0.0f, iaz = 0.0f, iay_dn = 0.0f;
 	uint32_t iay_up_bits = 0u, cw = 0u;
 
@@ -383,13 +384,13 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 			if(COUNT) cnt.rays++;
 			const V iray = ray;
 			ray = vnormalise<HAS_W>(L.rsq, iray);
-			cx = (int)pos.x; cz = (int)pos.z;
+			const int cx = (int)pos.x, cz = (int)pos.z;
 			if(fabsf(ray.x) < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
 			if(fabsf(ray.y) < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
 			if(fabsf(ray.z) < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
 			// signs of the UN-normalised input (trace.h:225-227)
-			gx = (iray.x < 0.0f ? -1 : 1);
-			gz = (iray.z < 0.0f ? -1 : 1);
+			const int gx = (iray.x < 0.0f ? -1 : 1);
+			const int gz = (iray.z < 0.0f ? -1 : 1);
 			const bool gyp = !(iray.y < 0.0f);          // gy > 0
 			{
 				const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
@@ -413,7 +414,8 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 			ldy = gyp ? FYP : FYN;
 			iay_up_bits = gyp ? __float_as_uint(iay) : 0u;         // +iay when looking up, else +0
 			ldx = (gx < 0 ? FXN : FXP); ldz = (gz < 0 ? FZN : FZP);
-			cw = cellword_at(L, cx, cz);
+			cxz = cxz_pack(cx, cz); sx = (uint32_t)gx & 0xffffu; sz = (uint32_t)gz << 16;
+			cw = cellword_pk(L, cxz);
 			ldir = FYN; base = BASE_ROOM_Y;
 			maxsteps = 1000;
 			ev = EV_NONE;
@@ -472,9 +474,15 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 		}
 	}
 	// PWN_OPT_WAVE_LOG: every wave's lifetime (pwn_stats.wave_time ..., tools/wave_log.py)
-	if(P.wave_log != NULL && (threadIdx.x & 63) == 0)
+	// (Which wave of the workgroup this is comes from the hardware: the four waves of a 256-thread workgroup
+	// sit on the four SIMDs of their CU, HW_ID.simd_id is bits 5:4 of hardware register 4; the lane number
+	// comes from mbcnt.  Keeping threadIdx.x alive to the end of the kernel costs a scratch slot per lane,
+	// and a shared append counter serialises the waves' exits and stretches the very tail it measures.)
+	if(P.wave_log != NULL && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
 	{
-		const size_t wid = (size_t)blockIdx.x * (PWN_BLOCK / 64) + (size_t)(threadIdx.x >> 6);
+		static_assert(PWN_BLOCK == 256, "one wave per SIMD: simd_id tells the waves of a workgroup apart");
+		const unsigned simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11));
+		const size_t wid = 1u + (size_t)blockIdx.x * 4u + simd;
 		P.wave_log[2 * wid] = t_begin; P.wave_log[2 * wid + 1] = __builtin_amdgcn_s_memrealtime();
 	}
 }

@@ -33,7 +33,7 @@ r.set_wave_log(True)
 for _ in range(4):
     r.trace_screen_centred(cam, 0.0, want_z=False)
     st = r.stats()
-log = np.fromfile(path, np.uint64).reshape(-1, 2)
+log = np.fromfile(path, np.uint64).reshape(-1, 2)[1:]
 log = log[log[:, 1] != 0]
 t0 = log[:, 0].min()
 b = (log[:, 0] - t0) / 100.0      # us
