@@ -6,7 +6,7 @@
  *
  * Built only where Lua 5.1 development files are found (host/Makefile).  This image has none;
  * there the shipped script runs restated in C (game_script.c), and what the script itself
- * does is pinned by executing its text with tools/minilua.py (tests/golden/script_ticks.npz).
+ * does is pinned by executing its text with the test suite's Lua-subset interpreter (tests/golden/script_ticks.npz).
  *
  * An object handle is what the reference hands to the script: a light userdata.  The reference
  * stores the part's address in it; here it carries the slot index + 1, so that nil / a missing
