@@ -24,7 +24,9 @@
 // spills such as a non-leaf callee's return address in VGPR lanes via v_writelane).
 // With no calls there is nothing of that kind to get wrong (and no scratch);
 // tools/fuzz_parity.py is the regression check.
+#ifndef PWN_LIBM_ATTR
 #define PWN_LIBM_ATTR __forceinline__
+#endif
 
 struct v4 { float x, y, z, w; };
 
