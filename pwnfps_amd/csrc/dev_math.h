@@ -89,15 +89,19 @@ __device__ __forceinline__ float tab_rsqrt(const uint16_t *tab, float x)
 {
 	uint32_t b = __float_as_uint(x);
 	uint32_t r;
-	if(b - 0x00800000u < 0x7f000000u)          // positive normal
-		r = (PWN_RSQ_BASE + ((uint32_t)tab[(b >> 13) & 2047u] << 11)) - (((b + 0x00800000u) >> 1) & 0x7f800000u);
-	else
+	// every lane takes the table path (the index is in range whatever the bits are); the rest is patched in
+	// behind ONE wave-uniform branch
+	r = (PWN_RSQ_BASE + ((uint32_t)tab[(b >> 13) & 2047u] << 11)) - (((b + 0x00800000u) >> 1) & 0x7f800000u);
+	const bool special = !(b - 0x00800000u < 0x7f000000u);
+	if(__builtin_expect(__ballot(special) != 0ull, 0))
 	{
 		uint32_t sign = b & 0x80000000u, e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
-		if(e == 255u && m) r = b | 0x00400000u;
-		else if(e == 0u) r = sign | 0x7f800000u;
-		else if(sign) r = 0xffc00000u;
-		else r = 0u;                               // +inf
+		uint32_t q;
+		if(e == 255u && m) q = b | 0x00400000u;
+		else if(e == 0u) q = sign | 0x7f800000u;
+		else if(sign) q = 0xffc00000u;
+		else q = 0u;                               // +inf
+		r = special ? q : r;
 	}
 	return __uint_as_float(r);
 }
@@ -182,8 +186,40 @@ __device__ __forceinline__ uint32_t inv_pio4_word(int i)
 	return t[i];
 }
 
-// which = 0: sinf, 1: cosf
-__device__ PWN_LIBM_ATTR float glibc_sincosf(float y, int which)
+// The two polynomials without the sign: with s, p = +-1 (they are), sincos_poly(x * s, x2, p, n) is
+// s * sin_poly_pos(x, x2) for even n and p * cos_poly_pos(x2) for odd n exactly -- every product and every
+// fused operation above is odd in s resp. p, and rounding is symmetric -- so the sign is one xor on the result
+// instead of five f64 multiplies and two f64 selects per call.
+__device__ __forceinline__ float sin_poly_pos(double x, double x2)
+{
+	double x3 = x * x2;
+	double s1 = fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+	double x7 = x3 * x2;
+	double s = fma(x3, -0x1.555545995a603p-3, x);
+	return (float)fma(x7, s1, s);
+}
+__device__ __forceinline__ float cos_poly_pos(double x2)
+{
+	double x4 = x2 * x2;
+	double c2 = fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+	double c1 = fma(x2, -0x1.ffffffd0c621cp-2, 0x1p0);
+	double x6 = x4 * x2;
+	double c = fma(x4, 0x1.55553e1068f19p-5, c1);
+	return (float)fma(x6, c2, c);
+}
+// 2^-12 <= |y| < 120 (top 12 bits): glibc's middle path.  It also reproduces its |y| < pi/4 path bit for bit
+// (there n = 0: x = fma(-0.0, hpi, x) = x, s = p = 1), so only |y| < 2^-12, |y| >= 120, inf and NaN are left
+// for the general code, and the callers test that once per wave.
+__device__ __forceinline__ bool sincosf_is_mid(float y)
+{
+	return abstop12(y) - abstop12(0x1p-12f) < abstop12(120.0f) - abstop12(0x1p-12f);
+}
+// s = -1 for n & 3 in {1, 2}; p = -1 for n & 2 (glibc's __sincosf_table signs)
+__device__ __forceinline__ uint32_t sincosf_sign_s(int n) { return (uint32_t)((n ^ (n >> 1)) & 1) << 31; }
+__device__ __forceinline__ uint32_t sincosf_sign_p(int n) { return (uint32_t)((n >> 1) & 1) << 31; }
+
+// which = 0: sinf, 1: cosf -- every input
+__device__ PWN_LIBM_ATTR float glibc_sincosf_general(float y, int which)
 {
 	double x = (double)y;
 	int n;
@@ -225,6 +261,25 @@ __device__ PWN_LIBM_ATTR float glibc_sincosf(float y, int which)
 	return __builtin_nanf("");
 }
 
+// which = 0: sinf, 1: cosf
+__device__ PWN_LIBM_ATTR float glibc_sincosf(float y, int which)
+{
+	if(__builtin_expect(__ballot(!sincosf_is_mid(y)) == 0ull, 1))
+	{
+		double x = (double)y;
+		double r = x * PWN_HPI_INV;
+		const int n = ((int)r + 0x800000) >> 24;
+		x = fma(-(double)n, PWN_HPI, x);
+		const int k = n ^ which;
+		const double x2 = x * x;
+		float pv; uint32_t sign;
+		if(k & 1) { pv = cos_poly_pos(x2); sign = sincosf_sign_p(n); }
+		else { pv = sin_poly_pos(x, x2); sign = sincosf_sign_s(n); }
+		return __uint_as_float(__float_as_uint(pv) ^ sign);
+	}
+	return glibc_sincosf_general(y, which);
+}
+
 // sinf(y) and cosf(y) of the same argument (trace.h:45-46: the rippled floor
 // normal): one range reduction, both polynomials evaluated once and handed out
 // by quadrant.  Bit-identical to glibc_sincosf(y,0) / glibc_sincosf(y,1): in
@@ -232,43 +287,30 @@ __device__ PWN_LIBM_ATTR float glibc_sincosf(float y, int which)
 // choice of polynomial is shared.  x = sin, y = cos.
 __device__ PWN_LIBM_ATTR float2 glibc_sincosf_both(float y)
 {
-	double x = (double)y;
-	if(abstop12(y) < abstop12(0x1.921FB6p-1f))
+	if(__builtin_expect(__ballot(!sincosf_is_mid(y)) == 0ull, 1))
 	{
-		if(abstop12(y) < abstop12(0x1p-12f)) return make_float2(y, 1.0f);
-		double x2 = x * x;
-		return make_float2(sincos_poly(x, x2, 1.0, 0), sincos_poly(x, x2, 1.0, 1));
-	}
-	if(abstop12(y) < abstop12(120.0f))
-	{
+		double x = (double)y;
 		double r = x * PWN_HPI_INV;
-		int n = ((int)r + 0x800000) >> 24;
+		const int n = ((int)r + 0x800000) >> 24;
 		x = fma(-(double)n, PWN_HPI, x);
-		double s = (n & 3) == 0 || (n & 3) == 3 ? 1.0 : -1.0;
-		double cs = (n & 2) ? -1.0 : 1.0;
-		double xs = x * s, x2 = x * x;
-		float ps = sincos_poly(xs, x2, cs, 0), pc = sincos_poly(xs, x2, cs, 1);
+		const double x2 = x * x;
+		const float ps = __uint_as_float(__float_as_uint(sin_poly_pos(x, x2)) ^ sincosf_sign_s(n));
+		const float pc = __uint_as_float(__float_as_uint(cos_poly_pos(x2)) ^ sincosf_sign_p(n));
 		return (n & 1) ? make_float2(pc, ps) : make_float2(ps, pc);
 	}
-	return make_float2(glibc_sincosf(y, 0), glibc_sincosf(y, 1));
+	return make_float2(glibc_sincosf_general(y, 0), glibc_sincosf_general(y, 1));
 }
 
 // ---- glibc 2.35 expf (e_expf.c, N = 32) -------------------------------------
 __device__ __forceinline__ uint64_t exp2f_tab(int i)
 {
-	const uint64_t t[32] = {
-		0x3ff0000000000000, 0x3fefd9b0d3158574, 0x3fefb5586cf9890f, 0x3fef9301d0125b51,
-		0x3fef72b83c7d517b, 0x3fef54873168b9aa, 0x3fef387a6e756238, 0x3fef1e9df51fdee1,
-		0x3fef06fe0a31b715, 0x3feef1a7373aa9cb, 0x3feedea64c123422, 0x3feece086061892d,
-		0x3feebfdad5362a27, 0x3feeb42b569d4f82, 0x3feeab07dd485429, 0x3feea47eb03a5585,
-		0x3feea09e667f3bcd, 0x3fee9f75e8ec5f74, 0x3feea11473eb0187, 0x3feea589994cce13,
-		0x3feeace5422aa0db, 0x3feeb737b0cdc5e5, 0x3feec49182a3f090, 0x3feed503b23e255d,
-		0x3feee89f995ad3ad, 0x3feeff76f2fb5e47, 0x3fef199bdd85529c, 0x3fef3720dcef9069,
-		0x3fef5818dcfba487, 0x3fef7c97337b9b5f, 0x3fefa4afa2a490da, 0x3fefd0765b6e4540 };
+	const uint64_t t[32] = PWN_EXP2F_TAB_INIT;
 	return t[i];
 }
 
-__device__ PWN_LIBM_ATTR float glibc_expf(float x)
+// lds_tab: the 32-entry table in LDS (tables.h PWN_T_EXP2), or NULL for the copy in constant memory (a
+// per-lane global load: fine for the probe kernel, a long stall in the trace kernels)
+__device__ PWN_LIBM_ATTR float glibc_expf(float x, const uint64_t *lds_tab = nullptr)
 {
 	const double N = 32.0;
 	const double InvLn2N = 0x1.71547652b82fep+0 * N;
@@ -281,19 +323,12 @@ __device__ PWN_LIBM_ATTR float glibc_expf(float x)
 	asm volatile("" : "+s"(C1));
 	double xd = (double)x;
 	uint32_t at = (__float_as_uint(x) >> 20) & 0x7ffu;
-	if(at >= ((__float_as_uint(88.0f) >> 20) & 0x7ffu))
-	{
-		if(__float_as_uint(x) == 0xff800000u) return 0.0f;
-		if(at >= 0x7f8u) return x + x;
-		if(x > 0x1.62e42ep6f) return __builtin_inff();
-		if(x < -0x1.9fe368p6f) return 0.0f;
-	}
 	// z = InvLn2N*xd is fused into both of its uses in glibc's FMA build
 	double kd = fma(InvLn2N, xd, SHIFT);
 	uint64_t ki = (uint64_t)__double_as_longlong(kd);
 	kd -= SHIFT;
 	double r = fma(InvLn2N, xd, -kd);
-	uint64_t t = exp2f_tab((int)(ki & 31u));
+	uint64_t t = lds_tab ? lds_tab[ki & 31u] : exp2f_tab((int)(ki & 31u));
 	t += ki << (52 - 5);
 	double s = __longlong_as_double((long long)t);
 	double z = fma(C0, r, C1);
@@ -301,5 +336,19 @@ __device__ PWN_LIBM_ATTR float glibc_expf(float x)
 	double yv = fma(C2, r, 1.0);
 	yv = fma(z, r2, yv);
 	yv = yv * s;
-	return (float)yv;
+	float res = (float)yv;
+	// |x| >= 88, inf, NaN (e_expf.c's early returns): every lane computes the above -- harmless whatever x
+	// is -- and these are patched in behind ONE wave-uniform branch
+	const bool big = at >= ((__float_as_uint(88.0f) >> 20) & 0x7ffu);
+	if(__builtin_expect(__ballot(big) != 0ull, 0))
+	{
+		if(big)
+		{
+			if(__float_as_uint(x) == 0xff800000u) res = 0.0f;
+			else if(at >= 0x7f8u) res = x + x;
+			else if(x > 0x1.62e42ep6f) res = __builtin_inff();
+			else if(x < -0x1.9fe368p6f) res = 0.0f;
+		}
+	}
+	return res;
 }

@@ -237,6 +237,7 @@ static int pack_blob(pwn_ctx *c)
 	for(int x = 0; x <= 64; x++) ci[64 * PWN_GRID_PITCH + x] = ci[x] & ~(PWN_C_SPH | 0x7fff0000u);
 	memcpy(b + PWN_T_RCP, c->tabs, 4096);
 	memcpy(b + PWN_T_RSQ, c->tabs + 2048, 4096);
+	pwn_fill_faces((float *)(b + PWN_T_FACES));
 	uint32_t *pm = (uint32_t *)(b + PWN_T_PMAP);
 	for(int i = 0; i < 26; i++)
 	{

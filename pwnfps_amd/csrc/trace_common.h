@@ -31,6 +31,8 @@ struct Lds
 	const uint32_t *pmap;
 	const uint16_t *binidx;
 	const float *sph;
+	const uint64_t *exp2;         // tables.h PWN_T_EXP2
+	const float4 *faces;          // tables.h PWN_T_FACES: [0..4) wall colours, [4 + 2 * face ..] face constants
 };
 
 // util.h:151-158 (per-axis clamp to 0) -> the packed cell word.  The table has

@@ -53,7 +53,10 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	float sc0x = 0.0f, sc0y = 0.0f, sc0z = 0.0f;
 	float sc1x = 0.0f, sc1y = 0.0f, sc1z = 0.0f;
 #endif
-	int depth = 0;
+	// Every lane still in the segment loop is on the same segment, so the segment number `seg` is one scalar
+	// for the wave (tests on it are scalar branches); `depth`, the number of surfaces a pixel's ray bounced off,
+	// is per lane and set where the lane leaves the loop.
+	int depth = 0, seg = 0;
 	float vx, vy, vz, vw;
 	// The colour's w lane is not carried: every surface colour has w = 0 (defs.h:16-18, spheres'
 	// col.w is never set), so col.w = diffuse * (icol.w * 0) is 0 -- unless the shading factor is
@@ -66,6 +69,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #pragma unroll 1
 	for(;;)
 	{
+		seg = __builtin_amdgcn_readfirstlane(seg);
 		// ------------------------------------------------ trace.h:186-248
 		float cdist = 0.0f, fog = 0.0f;
 		// nearest sphere candidate (trace.h:193-199): distance, hit point, which sphere and
@@ -84,27 +88,31 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		V pos = from;
 		V ray = vnormalise<HAS_W>(L.rsq, iray);
 		int cx = (int)from.x, cz = (int)from.z;
-		if(fabsf(ray.x) < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
-		if(fabsf(ray.y) < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
-		if(fabsf(ray.z) < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
 		// signs of the UN-normalised input (trace.h:225-227)
 		int gx = (iray.x < 0.0f ? -1 : 1);
 		int gz = (iray.z < 0.0f ? -1 : 1);
 		const bool gyp = !(iray.y < 0.0f);          // gy > 0
-		// trace.h:230-231: |ray| >= EPSILON here, so all three reciprocals normally
-		// take the one-subtract table path together (one LDS round trip)
+		// trace.h:220-222 clamp |ray| to EPSILON, trace.h:230-231 take the three reciprocals.  A normalised ray
+		// has all three magnitudes in [EPSILON, 2^126) unless it is degenerate: ONE test on the bit patterns
+		// (a NaN's is above every number's) and one wave-uniform branch; then nothing is clamped and all three
+		// reciprocals are the one-subtract table path (one LDS round trip)
 		float iax, iaz, iay_;
 		{
-			const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
-			const uint32_t ux = __float_as_uint(ax) - 0x00800000u, uy = __float_as_uint(ay) - 0x00800000u,
-				uz = __float_as_uint(az) - 0x00800000u;
-			if(max(max(ux, uy), uz) < 0x7e000000u)
+			const uint32_t EPSB = __float_as_uint(EPS);
+			const uint32_t bx = __float_as_uint(ray.x) & 0x7fffffffu, by = __float_as_uint(ray.y) & 0x7fffffffu,
+				bz = __float_as_uint(ray.z) & 0x7fffffffu;
+			const bool plain = max(max(bx - EPSB, by - EPSB), bz - EPSB) < 0x7e800000u - EPSB;
+			if(__builtin_expect(__ballot(!plain) == 0ull, 1))
 			{
-				iax = tab_rcp_pos(L.rcp, ax); iay_ = tab_rcp_pos(L.rcp, ay); iaz = tab_rcp_pos(L.rcp, az);
+				iax = tab_rcp_pos(L.rcp, __uint_as_float(bx)); iay_ = tab_rcp_pos(L.rcp, __uint_as_float(by));
+				iaz = tab_rcp_pos(L.rcp, __uint_as_float(bz));
 			}
 			else
 			{
-				iax = tab_rcp(L.rcp, ax); iay_ = tab_rcp(L.rcp, ay); iaz = tab_rcp(L.rcp, az);
+				if(fabsf(ray.x) < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
+				if(fabsf(ray.y) < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
+				if(fabsf(ray.z) < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
+				iax = tab_rcp(L.rcp, fabsf(ray.x)); iay_ = tab_rcp(L.rcp, fabsf(ray.y)); iaz = tab_rcp(L.rcp, fabsf(ray.z));
 			}
 		}
 		const float iay = iay_;
@@ -147,36 +155,43 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			// trace.h:677-678: out of steps -- the walked ray is the colour
 			if(COUNT) cnt.exhausted++;
 			vx = ray.x; vy = ray.y; vz = ray.z; vw = HAS_W ? ray.w : 0.0f;
+			depth = seg;
 			break;
 		}
 		if(ev == EV_WALL && base == BASE_ROOM_Y) { ldir = ldy; base = (gyp ? BASE_CEIL : BASE_FLOOR); }
 		// zbuf = the PRIMARY ray's hit distance (trace.h:102-105); a primary ray that ran out of steps
 		// leaves the old depth in place (trace.h:677)
-		if(depth == 0) *zpix = (ev == EV_SPHERE ? aux_dist : cdist);
+		if(seg == 0) *zpix = (ev == EV_SPHERE ? aux_dist : cdist);
 
 		float colx, coly, colz, refl;
 		if(ev == EV_WALL)
 		{
-			// trace.h:108-154
-			float bx, by, bz;
-			if(base == BASE_CEIL) { bx = 30.0f; by = 30.0f; bz = 0.0f; }
-			else if(base == BASE_FLOOR) { bx = 1.0f; by = 1.0f; bz = 1.0f; }
-			else if(base == BASE_WALL) { bx = 0.8f; by = 0.8f; bz = 1.0f; }
-			else { bx = 5.0f; by = 0.0f; bz = 5.0f; }
-			float diffuse;
-			if(ldir >= FYP) diffuse = ray.y; else diffuse = (ldir & 1) ? ray.z : ray.x;
-			if(ldir == FXN || ldir == FZN || ldir == FYN) diffuse = -diffuse;
+			// trace.h:108-154, and the axis-aligned mirrors of trace.h:50-75.  Colour by wall class and what
+			// the face does to the ray are two constant tables in LDS (tables.h PWN_T_FACES): three 16-byte
+			// reads instead of two switch trees (which the compiler builds out of lane masks and branches)
+			const float4 wc = L.faces[base];
+			const float4 fa = L.faces[4 + 2 * ldir], fb = L.faces[5 + 2 * ldir];
+			float diffuse = (ldir & 1) ? ray.z : ray.x;
+			diffuse = ldir >= FYP ? ray.y : diffuse;
+			diffuse = __uint_as_float(__float_as_uint(diffuse) ^ __float_as_uint(fb.w));      // -ray.c on the N faces
 			if(diffuse < 0.0f) diffuse = 0.0f;
 			const float amb = 0.1f;
 			diffuse = (1.0f - amb) * diffuse + amb;
 #ifdef PWN_LDS_STACK
 			// icol of a bounced ray = the colour of the surface it left (trace.h:90): the stack entry below
 			float icx = 1.0f, icy = 1.0f, icz = 1.0f;
-			if(depth > 0) { icx = STK(depth - 1, 2); icy = STK(depth - 1, 3); icz = STK(depth - 1, 4); }
+			if(seg > 0) { icx = STK(seg - 1, 2); icy = STK(seg - 1, 3); icz = STK(seg - 1, 4); }
 #endif
-			colx = diffuse * (icx * bx); coly = diffuse * (icy * by); colz = diffuse * (icz * bz);
+			colx = diffuse * (icx * wc.x); coly = diffuse * (icy * wc.y); colz = diffuse * (icz * wc.z);
 			w_acc = __builtin_fmaf(diffuse, 0.0f, w_acc);
-			refl = (ldir == FYN ? 0.7f : 0.25f);
+			refl = fa.w;
+			// the mirror: flip the ray component along the face normal, step 0.001 off the surface (the other
+			// axes add -0.0f, which changes nothing); the floor (FYN) takes the step here and its ray from
+			// the rippled normal below
+			ray.x = __uint_as_float(__float_as_uint(ray.x) ^ __float_as_uint(fa.x));
+			ray.y = __uint_as_float(__float_as_uint(ray.y) ^ __float_as_uint(fa.y));
+			ray.z = __uint_as_float(__float_as_uint(ray.z) ^ __float_as_uint(fa.z));
+			pos.x += fb.x; pos.y += fb.y; pos.z += fb.z;
 		}
 		else
 		{
@@ -195,12 +210,11 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		}
 
 		// trace.h:3-7
-		if(depth >= REFLECT_MAX || refl == 0.0f) { vx = colx; vy = coly; vz = colz; vw = 0.0f; break; }
+		if(seg >= REFLECT_MAX || refl == 0.0f) { vx = colx; vy = coly; vz = colz; vw = 0.0f; depth = seg; break; }
 
 		// trace.h:9-75
 		if(ldir == FYN)
 		{
-			pos.y -= 0.001f;
 			const float pi = (float)3.14159265358979323846;
 			float ang = (pi * 2.0f) * (
 				(glibc_sincosf((pi * 0.5f) * pos.x, 0) + glibc_sincosf((pi * 0.5f) * pos.z, 1))
@@ -217,11 +231,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			float rmul = -2.0f * ((ray.x * aux_norm.x + ray.y * aux_norm.y) + ray.z * aux_norm.z);
 			ray = vnormalise<HAS_W>(L.rsq, vadd<HAS_W>(vscale<HAS_W>(rmul, aux_norm), ray));
 		}
-		else if(ldir == FXP) { ray.x = -ray.x; pos.x -= 0.001f; }
-		else if(ldir == FXN) { ray.x = -ray.x; pos.x += 0.001f; }
-		else if(ldir == FZP) { ray.z = -ray.z; pos.z -= 0.001f; }
-		else if(ldir == FZN) { ray.z = -ray.z; pos.z += 0.001f; }
-		else { ray.y = -ray.y; pos.y -= 0.001f; }
 
 		// trace.h:77-84: five draws, two discarded
 		ray.x += lcg_fs(seed) * REFLECT_BLUR_F;
@@ -231,12 +240,12 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		lcg_next(seed);
 
 #ifdef PWN_LDS_STACK
-		STK(depth, 0) = refl; STK(depth, 1) = fog; STK(depth, 2) = colx; STK(depth, 3) = coly; STK(depth, 4) = colz;
+		STK(seg, 0) = refl; STK(seg, 1) = fog; STK(seg, 2) = colx; STK(seg, 3) = coly; STK(seg, 4) = colz;
 #else
-		if(depth == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; }
+		if(seg == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; }
 		else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; }
 #endif
-		depth++;
+		seg++;
 #ifndef PWN_LDS_STACK
 		icx = colx; icy = coly; icz = colz;
 #endif
@@ -254,7 +263,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
 		if(st_fog1 != 0.0f)
 		{
-			float f = glibc_expf(-0.6f * st_fog1), g = 1.0f - f;
+			float f = glibc_expf(-0.6f * st_fog1, L.exp2), g = 1.0f - f;
 			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 		}
 	}
@@ -267,7 +276,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw;
 		if(st_fog0 != 0.0f)
 		{
-			float f = glibc_expf(-0.6f * st_fog0), g = 1.0f - f;
+			float f = glibc_expf(-0.6f * st_fog0, L.exp2), g = 1.0f - f;
 			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 		}
 	}
@@ -295,6 +304,8 @@ pwn_trace_kernel(pwn_trace_params P)
 	L.rsq = (const uint16_t *)(lds_raw + PWN_T_RSQ);
 	L.pmap = (const uint32_t *)(lds_raw + PWN_T_PMAP);
 	L.binidx = (const uint16_t *)(lds_raw + PWN_T_BINIDX);
+	L.faces = (const float4 *)(lds_raw + PWN_T_FACES);
+	L.exp2 = (const uint64_t *)(lds_raw + PWN_T_EXP2);
 	L.sph = (const float *)(lds_raw + P.off_sph);
 
 	typedef Vec<HAS_W> V;

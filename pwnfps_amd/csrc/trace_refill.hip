@@ -56,6 +56,8 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 	L.rsq = (const uint16_t *)(lds_raw + PWN_T_RSQ);
 	L.pmap = (const uint32_t *)(lds_raw + PWN_T_PMAP);
 	L.binidx = (const uint16_t *)(lds_raw + PWN_T_BINIDX);
+	L.faces = (const float4 *)(lds_raw + PWN_T_FACES);
+	L.exp2 = (const uint64_t *)(lds_raw + PWN_T_EXP2);
 	L.sph = (const float *)(lds_raw + P.off_sph);
 
 	typedef Vec<HAS_W> V;
@@ -226,7 +228,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 					vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
 					if(st_fog1 != 0.0f)
 					{
-						float f = glibc_expf(-0.6f * st_fog1), g = 1.0f - f;
+						float f = glibc_expf(-0.6f * st_fog1, L.exp2), g = 1.0f - f;
 						vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 					}
 				}
@@ -236,7 +238,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 					vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw;
 					if(st_fog0 != 0.0f)
 					{
-						float f = glibc_expf(-0.6f * st_fog0), g = 1.0f - f;
+						float f = glibc_expf(-0.6f * st_fog0, L.exp2), g = 1.0f - f;
 						vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 					}
 				}

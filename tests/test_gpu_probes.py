@@ -63,6 +63,20 @@ def test_libm_kat_and_oracle(R, oracle_lib):
                    (_lib.PROBE_SIN_OF_PAIR, L.pwno_sinf), (_lib.PROBE_COS_OF_PAIR, L.pwno_cosf)):
         want = np.array([fn(float(v)) for v in x], np.float32).view(np.uint32)
         assert (R.probe(op, x) == want).all()
+    # the device code tests the argument range once per WAVE (dev_math.h): batches in which every argument is in
+    # the middle range 2^-12 <= |y| < 120 take the one-branch path (the batches above almost never do), among
+    # them arguments below pi/4, which glibc sends down another path with -- the claim -- the same result
+    xm = np.concatenate([rng.uniform(-119.9, 119.9, 40000), rng.uniform(-0.8, 0.8, 20000), 2.0 ** rng.uniform(-12, -1, 3936),
+                         [2.0 ** -12, -2.0 ** -12, 0.785398, 0.7853982, -0.7853981, 119.99999, 1.5707964, 3.1415927]]).astype(np.float32)
+    xm = xm[(np.abs(xm) >= np.float32(2.0 ** -12)) & (np.abs(xm) < 120)]
+    xm = xm[:len(xm) // 64 * 64]
+    for op, fn in ((_lib.PROBE_SINF, L.pwno_sinf), (_lib.PROBE_COSF, L.pwno_cosf),
+                   (_lib.PROBE_SIN_OF_PAIR, L.pwno_sinf), (_lib.PROBE_COS_OF_PAIR, L.pwno_cosf)):
+        want = np.array([fn(float(v)) for v in xm], np.float32).view(np.uint32)
+        assert (R.probe(op, xm) == want).all()
+    xf = np.concatenate([-rng.uniform(0, 87.0, 30000), rng.uniform(-1, 1, 2000)]).astype(np.float32)     # |x| < 88 throughout, results normal
+    want = np.array([L.pwno_expf(float(v)) for v in xf], np.float32)
+    assert (R.probe(_lib.PROBE_EXPF, xf) == want.view(np.uint32)).all()
     xe = np.concatenate([-rng.uniform(0, 105, 60000), rng.uniform(-1, 1, 5000), [0.0, -87.0, -88.0, -103.9, -104.0, -1e30]]).astype(np.float32)
     want = np.array([L.pwno_expf(float(v)) for v in xe], np.float32)
     got = R.probe(_lib.PROBE_EXPF, xe).view(np.float32)
