@@ -41,17 +41,22 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	// x * 0.0f (COL_* have a = 0, defs.h:17-19; spheres get b,g,r only, script.h:30-32):
 	// +-0 for any finite input, and the sign of a zero never reaches a pixel, so the
 	// w lanes of icol and of the composite stack are not kept.
-#ifndef PWN_LDS_STACK
-	float icx = 1.0f, icy = 1.0f, icz = 1.0f;
-#endif
+	// (kept in the composite stack below: the top entry's colour)
 #ifdef PWN_LDS_STACK
 	// the composite stack (reflectivity, fog, colour of the two bounced-off surfaces) lives in
 	// LDS, one float per thread and slot (stride PWN_BLOCK: conflict-free), not in registers
 #define STK(level, k) stk[((level) * 5 + (k)) * PWN_BLOCK]
 #else
+	// The composite stack (reflectivity, fog, colour of the surfaces the ray bounced off), two entries, as a
+	// shift register: a bounce moves the top entry down and writes the new one on top (plain moves; indexing by
+	// the segment number made ten selects of it).  The top entry's colour IS the next segment's icol
+	// (trace.h:90), so it starts as 1,1,1 and icol needs no registers of its own.
 	float st_refl0 = 0.0f, st_refl1 = 0.0f, st_fog0 = 0.0f, st_fog1 = 0.0f;
-	float sc0x = 0.0f, sc0y = 0.0f, sc0z = 0.0f;
+	float sc0x = 1.0f, sc0y = 1.0f, sc0z = 1.0f;
 	float sc1x = 0.0f, sc1y = 0.0f, sc1z = 0.0f;
+#define icx sc0x
+#define icy sc0y
+#define icz sc0z
 #endif
 	// Every lane still in the segment loop is on the same segment, so the segment number `seg` is one scalar
 	// for the wave (tests on it are scalar branches); `depth`, the number of surfaces a pixel's ray bounced off,
@@ -242,23 +247,19 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #ifdef PWN_LDS_STACK
 		STK(seg, 0) = refl; STK(seg, 1) = fog; STK(seg, 2) = colx; STK(seg, 3) = coly; STK(seg, 4) = colz;
 #else
-		if(seg == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; }
-		else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; }
+		st_refl1 = st_refl0; st_fog1 = st_fog0; sc1x = sc0x; sc1y = sc0y; sc1z = sc0z;
+		st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz;
 #endif
 		seg++;
-#ifndef PWN_LDS_STACK
-		icx = colx; icy = coly; icz = colz;
-#endif
 		from = pos;
 		iray = ray;
 	}
 
 	// trace.h:91-101, innermost first
+#ifdef PWN_LDS_STACK
 	if(depth >= 2)
 	{
-#ifdef PWN_LDS_STACK
 		const float st_refl1 = STK(1, 0), st_fog1 = STK(1, 1), sc1x = STK(1, 2), sc1y = STK(1, 3), sc1z = STK(1, 4);
-#endif
 		const float r1 = st_refl1, q1 = 1.0f - st_refl1;
 		vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
 		if(st_fog1 != 0.0f)
@@ -269,9 +270,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	}
 	if(depth >= 1)
 	{
-#ifdef PWN_LDS_STACK
 		const float st_refl0 = STK(0, 0), st_fog0 = STK(0, 1), sc0x = STK(0, 2), sc0y = STK(0, 3), sc0z = STK(0, 4);
-#endif
 		const float r0 = st_refl0, q0 = 1.0f - st_refl0;
 		vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw;
 		if(st_fog0 != 0.0f)
@@ -280,6 +279,32 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 		}
 	}
+#else
+	// the top of the stack is the last surface the ray bounced off, the entry below it the one before
+	if(depth >= 1)
+	{
+		const float r0 = st_refl0, q0 = 1.0f - st_refl0;
+		vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw;
+		if(st_fog0 != 0.0f)
+		{
+			float f = glibc_expf(-0.6f * st_fog0, L.exp2), g = 1.0f - f;
+			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
+		}
+	}
+	if(depth >= 2)
+	{
+		const float r1 = st_refl1, q1 = 1.0f - st_refl1;
+		vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
+		if(st_fog1 != 0.0f)
+		{
+			float f = glibc_expf(-0.6f * st_fog1, L.exp2), g = 1.0f - f;
+			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
+		}
+	}
+#undef icx
+#undef icy
+#undef icz
+#endif
 	out_x = vx; out_y = vy; out_z = vz; out_w = vw + w_acc;
 }
 
@@ -392,6 +417,10 @@ pwn_trace_kernel(pwn_trace_params P)
 		if(lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], 1u);
 		// rows from the middle of the strip outwards: the horizon band, where rays run longest,
 		// is started first and the cheap top and bottom edges make up the tail
+		// (this arithmetic is the same for the whole wave, but the compiler does it per lane because q starts
+		// from the wave number, which it derives from threadIdx.  Declaring q uniform and dividing by a multiply-high
+		// with a host-computed reciprocal moves ~35 VALU instructions per unit to the scalar unit: measured 0.8 %
+		// SLOWER at 4K, three runs -- a wave's scalar instructions issue one at a time and in order)
 		const uint32_t ux = unit % units_x, k = unit / units_x;
 		const uint32_t rows_u = ((uint32_t)(P.y1 - P.y0) + 3u) >> 2;
 		const uint32_t mid = rows_u >> 1;
