@@ -35,6 +35,20 @@ __device__ __forceinline__ uint32_t avg_u8x4(uint32_t a, uint32_t b)
 	return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu);
 }
 
+// screen.h:101-106: a tap coordinate goes float -> int with cvttss2si (INT_MIN for NaN and for anything
+// outside int32) and is then clamped to [0, hi - 1].  v_cvt_i32_f32 truncates the same way but saturates (and
+// gives 0 for NaN); the one input class where that ends differently is f >= 2^31 (INT_MAX, which the clamp
+// would send to hi - 1 where the reference ends at 0).  Adding 1 wraps INT_MAX to INT_MIN; the clamp is then
+// done one up, [1, hi], as one v_med3_i32.
+__device__ __forceinline__ int blur_coord(float f, int hi)
+{
+	int t, r;
+	asm("v_cvt_i32_f32 %0, %1" : "=v"(t) : "v"(f));
+	t = (int)((uint32_t)t + 1u);
+	asm("v_med3_i32 %0, %1, 1, %2" : "=v"(r) : "v"(t), "v"(hi));
+	return r - 1;
+}
+
 __global__ void __launch_bounds__(256)
 pwn_blur_kernel(pwn_blur_params P)
 {
@@ -152,17 +166,17 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 #pragma unroll
 		for(int j = 0; j < 4; j++)
 		{
-			// screen.h:101-106, as in pwn_blur_kernel
-			float fx = (float)(cx + j) + (lcg_fs(seed) * fstr) * z[j];
-			float fy = (float)cy + (lcg_fs(seed) * fstr) * z[j];
-			int x = (fx >= -2147483648.0f && fx < 2147483648.0f) ? (int)fx : INT32_MIN;
-			int y = (fy >= -2147483648.0f && fy < 2147483648.0f) ? (int)fy : INT32_MIN;
-			x = max(x, 0); y = max(y, 0);
-			x = min(x, P.w - 1); y = min(y, P.h - 1);
+			// screen.h:101-106
+			const float fx = (float)(cx + j) + (lcg_fs(seed) * fstr) * z[j];
+			const float fy = (float)cy + (lcg_fs(seed) * fstr) * z[j];
+			const int x = blur_coord(fx, P.w), y = blur_coord(fy, P.h);
 			if(CHECK) missed |= (unsigned)(y - P.avail_y0) >= (unsigned)(P.avail_y1 - P.avail_y0);
+			// from the staged rectangle (every lane reads LDS, at a clamped index); a tap outside it is
+			// fetched from the frame afterwards
 			const unsigned tx = (unsigned)(x - lx0), ty = (unsigned)(y - ly0);
-			if(tx < (unsigned)BLUR_LW && ty < (unsigned)BLUR_LH) tap[i][j] = tile[ty * BLUR_PITCH + tx];
-			else tap[i][j] = P.pre[(size_t)y * (size_t)P.w + (size_t)x];
+			uint32_t v = tile[min(ty * BLUR_PITCH + tx, (unsigned)(BLUR_PITCH * BLUR_LH - 1))];
+			if(!(tx < (unsigned)BLUR_LW && ty < (unsigned)BLUR_LH)) v = P.pre[(size_t)y * (size_t)P.w + (size_t)x];
+			tap[i][j] = v;
 		}
 	}
 	uint4 o;

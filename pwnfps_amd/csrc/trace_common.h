@@ -51,6 +51,15 @@ __device__ __forceinline__ uint32_t cellword_at(const Lds &L, int cx, int cz)
 typedef unsigned short pwn_us2 __attribute__((ext_vector_type(2)));
 typedef short pwn_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t cxz_pack(int cx, int cz) { return ((uint32_t)cx & 0xffffu) | ((uint32_t)cz << 16); }
+// The cell a segment STARTS in comes from a float position, which can be anything -- a ray that came back from
+// 10^13 units away, an infinity (the conversion saturates to INT_MIN / INT_MAX): 16 bits would fold such a cell
+// back into or near the grid.  A start further out than 16383 cells is outside the grid for all of the
+// segment's <= 1000 steps whatever its exact number, so it is pinned there.  (Found by lattice scenes of
+// tools/fuzz_parity.py, seeds 9002 / 9004: tests/golden/far_starts.npz.)
+__device__ __forceinline__ uint32_t cxz_pack_start(int cx, int cz)
+{
+	return cxz_pack(max(min(cx, 16383), -16384), max(min(cz, 16383), -16384));
+}
 __device__ __forceinline__ int cxz_x(uint32_t c) { return (int)(int16_t)(uint16_t)(c & 0xffffu); }
 __device__ __forceinline__ int cxz_z(uint32_t c) { return (int)c >> 16; }
 __device__ __forceinline__ uint32_t cxz_add(uint32_t c, uint32_t step)

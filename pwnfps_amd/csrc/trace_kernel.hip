@@ -134,7 +134,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		asm volatile("" : "+v"(iay_up_bits));        // keep it a register, not a select on gyp per step
 		int ldx = (gx < 0 ? FXN : FXP), ldz = (gz < 0 ? FZN : FZP);
 		// cell coordinates and steps in the packed form the walk uses (trace_common.h)
-		uint32_t cxz = cxz_pack(cx, cz), sx = (uint32_t)gx & 0xffffu, sz = (uint32_t)gz << 16;
+		uint32_t cxz = cxz_pack_start(cx, cz), sx = (uint32_t)gx & 0xffffu, sz = (uint32_t)gz << 16;
 
 		uint32_t cw = cellword_pk(L, cxz);
 		int ldir = FYN;

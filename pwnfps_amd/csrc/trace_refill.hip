@@ -416,7 +416,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 			ldy = gyp ? FYP : FYN;
 			iay_up_bits = gyp ? __float_as_uint(iay) : 0u;         // +iay when looking up, else +0
 			ldx = (gx < 0 ? FXN : FXP); ldz = (gz < 0 ? FZN : FZP);
-			cxz = cxz_pack(cx, cz); sx = (uint32_t)gx & 0xffffu; sz = (uint32_t)gz << 16;
+			cxz = cxz_pack_start(cx, cz); sx = (uint32_t)gx & 0xffffu; sz = (uint32_t)gz << 16;
 			cw = cellword_pk(L, cxz);
 			ldir = FYN; base = BASE_ROOM_Y;
 			maxsteps = 1000;

@@ -503,3 +503,63 @@ def test_wave_level_counters_are_consistent(cases):
     r.set_counters(False)
     r.trace_screen_centred(cam, c["sec"], want_z=False)
     r.close()
+
+
+def test_blur_tap_coordinates_with_hostile_depths(oracle_lib):
+    """screen.h:101-106 turns a float tap coordinate into an int with cvttss2si (INT_MIN for NaN and
+    anything outside int32) and clamps it; the kernel does it with a saturating convert and one
+    median-of-three (post_kernels.hip blur_coord).  Depths chosen so that taps are NaN, +-inf, beyond
+    +-2^31 and just inside it, on a random frame; the oracle's blur is the reference's loop."""
+    import torch
+    w, h = 256, 96
+    rng = np.random.default_rng(11)
+    pre = rng.integers(0, 2 ** 32, (h, w), dtype=np.uint64).astype(np.uint32)
+    z = (1.0 + rng.standard_normal((h, w)) * 8.0).astype(np.float32)
+    hostile = np.array([np.nan, np.inf, -np.inf, 3e9, -3e9, 1.2e10, -1.2e10, 2.4e10, 1e30, -1e30, 1e38, -1e38,
+                        1.1184e10, -1.1184e10, 5.5e9, 0.0, -0.0, 1.0, 1e-40], np.float32)
+    idx = rng.integers(0, h * w, 6000)
+    z.reshape(-1)[idx] = hostile[rng.integers(0, len(hostile), len(idx))]
+    O = oracle_lib.Oracle()
+    want = O.blur_rows(0, h, pre, z)
+    r = _renderer(w, h)
+    dev = torch.device("cuda:0")
+    d_pre = torch.from_numpy(pre.view(np.int32)).to(dev)
+    d_z = torch.from_numpy(z).to(dev)
+    d_out = torch.zeros((h, w), dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    r.blur_rows_device(0, h, d_pre.data_ptr(), d_z.data_ptr(), d_out.data_ptr(), s)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.uint32)
+    assert (got == want).all(), int((got != want).sum())
+    r.close()
+
+
+def test_far_start_scenes(oracle_lib):
+    """A bounced ray can start its next segment 10^13 cells away (horizon rays of axis-aligned cameras); the
+    walk packs cell numbers in 16 bits and has to keep such a start outside the grid.  Frames, depths and the
+    path counters (rays, steps, portals, sphere tests, exhausted) against the oracle, both schedulers."""
+    k = np.load(os.path.join(GOLD, "far_starts.npz"))
+    O = oracle_lib.Oracle()
+    for i in range(len(k["names"])):
+        text, cam, sph, sec = str(k["text_%d" % i]), k["cam_%d" % i], k["sph_%d" % i], float(k["sec_%d" % i])
+        w, h = (int(v) for v in k["wh_%d" % i])
+        O.load_level_text(text)
+        O.set_spheres(sph)
+        b, zb, ost = O.render(w, h, cam, sec=sec, blur=0, stats=True)
+        for sched in ("units", "refill"):
+            for counters in (False, True):
+                r = _renderer(w, h)
+                r.level_load_text(text)
+                r.set_objects(sph)
+                r.set_blur_passes(0)
+                r.set_scheduler(sched)
+                r.set_counters(counters)
+                a, za = r.trace_screen_centred(cam, sec)
+                assert (a == b).all(), (k["names"][i], sched, counters, int((a != b).sum()))
+                assert (za.view(np.uint32) == zb.view(np.uint32)).all(), (k["names"][i], sched)
+                if counters:
+                    st = r.stats()
+                    assert (st["rays"], st["steps"], st["portals"], st["sphere_tests"], st["exhausted"]) == \
+                        (ost.rays, ost.steps, ost.portals, ost.sphere_tests, ost.exhausted), (k["names"][i], sched)
+                r.close()
+

@@ -197,3 +197,29 @@ def test_axis_aligned_cameras_and_the_ramp_divide_by_zero(oracle_lib):
             assert not (differ & np.isfinite(zo)).any(), (px, pz, vx, vz)
             seen += int(differ.sum())
     assert seen > 0    # the case is really exercised
+
+
+def test_far_start_scenes(oracle_lib):
+    """tests/golden/far_starts.npz: lattice scenes of tools/fuzz_parity.py (seeds 9002, 9004) in which a bounced
+    ray starts its next segment far outside the grid (its cell number beyond 16 bits).  The oracle against the
+    compiled reference on them; tests/test_gpu_parity.py holds the GPU against the oracle on the same scenes."""
+    import os
+    from conftest import GOLD
+    k = np.load(os.path.join(GOLD, "far_starts.npz"))
+    R = refharness.RefHarness("nf" if refharness.available("nf") else "tab")
+    O = oracle_lib.Oracle()
+    for i in range(len(k["names"])):
+        text, cam, sph, sec = str(k["text_%d" % i]), k["cam_%d" % i], k["sph_%d" % i], float(k["sec_%d" % i])
+        w, h = (int(v) for v in k["wh_%d" % i])
+        import tempfile
+        with tempfile.NamedTemporaryFile("wb", suffix=".txt", delete=False) as f:
+            f.write(text.encode("latin-1"))
+        R.load_level(f.name)
+        os.unlink(f.name)
+        O.load_level_text(text)
+        R.set_spheres(sph); O.set_spheres(sph)
+        a, za = R.render(w, h, cam, sec=sec, blur=0)
+        b, zb = O.render(w, h, cam, sec=sec, blur=0)
+        assert (za.view(np.uint32) == zb.view(np.uint32)).all(), k["names"][i]
+        assert (a == b).all(), (k["names"][i], int((a != b).sum()))
+
