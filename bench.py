@@ -231,6 +231,22 @@ def main():
     if world == 1:
         r.frames_config(nres, sbuf=False)
     else:
+        # Every rank first checks that it can load the transport at all (a rank without librccl would leave the
+        # others waiting inside ncclCommInitRank).  If one cannot, all ranks agree on the shared-memory test
+        # transport instead -- the same kernels and messages, through the host -- and the line says so.
+        transport_note = None
+        if transport == "rccl":
+            try:
+                pwnfps_amd.Renderer.tiled_unique_id("rccl")
+                mine = 1.0
+            except Exception as e:                                   # noqa: BLE001 -- reported below
+                mine, transport_note = 0.0, "librccl could not be loaded on rank %d: %s" % (rank, e)
+            ok = torch.tensor([mine], dtype=torch.float64)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0:
+                transport = "shm"
+                transport_note = transport_note or "librccl could not be loaded on another rank"
+                print("bench.py rank %d: %s -- falling back to the shared-memory transport" % (rank, transport_note), file=sys.stderr)
         uid = [pwnfps_amd.Renderer.tiled_unique_id(transport) if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         r.tiled_init(rank, world, uid[0], transport, args.halo)
@@ -430,6 +446,8 @@ def main():
         if world > 1:
             line["tiling"] = {k: tinfo[k] for k in ("rows_per_rank", "halo_rows", "groups", "frames", "frames_redone", "bytes_sent", "bytes_received")}
             line["tiling"]["transport"] = transport
+            if transport_note:
+                line["tiling"]["transport_note"] = transport_note
         if counters:
             line["work"] = counters
         if kernel_ms:
