@@ -415,7 +415,7 @@ pwn_trace_kernel(pwn_trace_params P)
 		const uint32_t unit = ticket * PWN_QUEUES + q;
 		uint32_t next_raw = 0;
 		if(lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], 1u);
-		// rows from the middle of the strip outwards: the horizon band, where rays run longest,
+		// rows from the middle outwards: the horizon band, where rays run longest,
 		// is started first and the cheap top and bottom edges make up the tail
 		// (this arithmetic is the same for the whole wave, but the compiler does it per lane because q starts
 		// from the wave number, which it derives from threadIdx.  Declaring q uniform and dividing by a multiply-high
@@ -423,16 +423,18 @@ pwn_trace_kernel(pwn_trace_params P)
 		// SLOWER at 4K, three runs -- a wave's scalar instructions issue one at a time and in order)
 		const uint32_t ux = unit % units_x, k = unit / units_x;
 		const uint32_t rows_u = ((uint32_t)(P.y1 - P.y0) + 3u) >> 2;
-		const uint32_t mid = rows_u >> 1;
-		// k = 0,1,2,3,... -> mid, mid-1, mid+1, mid-2, ...; rows that fall off one end continue on the other
+		// ... of the FRAME: a strip of a row tiling starts at its rows nearest the frame's middle row (the strip of
+		// the whole frame at its own middle), not at its own middle
+		const int hrow = ((P.h >> 1) - P.y0) >> 2;
+		const uint32_t mid = (uint32_t)min(max(hrow, 0), (int)rows_u - 1);
+		// k = 0,1,2,3,... -> mid, mid-1, mid+1, mid-2, ... while there are rows on both sides (a above, b below),
+		// then the rest of the longer side in order
 		uint32_t uy;
 		{
-			const uint32_t d = (k + 1u) >> 1;
-			const bool down = (k & 1u) != 0u;            // odd: above the middle
-			int cand = down ? (int)mid - (int)d : (int)mid + (int)d;
-			if(cand < 0) cand = (int)mid + (int)(k - mid);           // ran past the top: the remaining rows are at the bottom
-			else if(cand >= (int)rows_u) cand = (int)mid - (int)(k - (rows_u - 1u - mid)) ;   // ran past the bottom
-			uy = (uint32_t)cand;
+			const uint32_t a = mid, b = rows_u - 1u - mid, m = min(a, b);
+			const uint32_t j = (k + 1u) >> 1;
+			if(k <= 2u * m) uy = (k & 1u) ? mid - j : mid + j;
+			else uy = a > b ? mid - (k - b) : mid + (k - a);
 		}
 		const int half = (int)(ux & 1u);                  // left / right half of the 32-wide tile
 		const int cx0 = (int)(ux >> 1) * 32;              // the 32-pixel tile of screen.h:6-7 this wave is in

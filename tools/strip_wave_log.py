@@ -45,3 +45,6 @@ print("strip %d of %d, rows [%d,%d): %d units, %d waves logged, span %.1f us, me
 q = [0, 10, 25, 50, 75, 90, 99, 100]
 print("wave end us  ", dict(zip(q, np.round(np.percentile(e, q), 1))))
 print("wave life us ", dict(zip(q, np.round(np.percentile(life, q), 1))))
+late = np.sort(e)[::-1][:12]
+print("last wave ends us", np.round(late, 1).tolist(), "| waves ending after p99 + 3 us:", int((e > np.percentile(e, 99) + 3).sum()))
+
