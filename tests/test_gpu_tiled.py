@@ -61,7 +61,7 @@ def oracle_hashes(w, h, level, frames, oracle_lib, blur=1):
     return want
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
 def test_tiled_frames_are_the_oracles_frames(world, tmp_path, oracle_lib):
     w, h, frames = 640, 360, 6
     want = oracle_hashes(w, h, "pwnfps_level", frames, oracle_lib)
