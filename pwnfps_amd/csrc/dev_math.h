@@ -52,11 +52,13 @@ __device__ __forceinline__ float v4_dot(v4 a, v4 b)
 // costs an index, one ds_read_u16, one shift-add and a subtract in the
 // exponent field.  Everything else takes the general path.
 #include "tables.h"
-__device__ __forceinline__ uint32_t rcp_entry(const uint16_t *tab, uint32_t a)
+// (TP: a pointer to the table -- an LDS-address-space pointer at a constant offset in the trace kernels, see
+// trace_common.h, a plain one in the probe kernel)
+template<class TP> __device__ __forceinline__ uint32_t rcp_entry(TP tab, uint32_t a)
 {
 	return PWN_RCP_BASE + ((uint32_t)tab[(a >> 12) & 2047u] << 11);
 }
-__device__ __forceinline__ float tab_rcp(const uint16_t *tab, float x)
+template<class TP> __device__ __forceinline__ float tab_rcp(TP tab, float x)
 {
 	uint32_t b = __float_as_uint(x);
 	uint32_t sign = b & 0x80000000u, a = b & 0x7fffffffu;
@@ -79,13 +81,13 @@ __device__ __forceinline__ float tab_rcp(const uint16_t *tab, float x)
 	return __uint_as_float(r);
 }
 // x >= EPSILON is known (ray components after the clamp of trace.h:220-222)
-__device__ __forceinline__ float tab_rcp_pos(const uint16_t *tab, float x)
+template<class TP> __device__ __forceinline__ float tab_rcp_pos(TP tab, float x)
 {
 	uint32_t a = __float_as_uint(x);
 	return __uint_as_float(rcp_entry(tab, a) - (a & 0x7f800000u));
 }
 
-__device__ __forceinline__ float tab_rsqrt(const uint16_t *tab, float x)
+template<class TP> __device__ __forceinline__ float tab_rsqrt(TP tab, float x)
 {
 	uint32_t b = __float_as_uint(x);
 	uint32_t r;
@@ -106,7 +108,7 @@ __device__ __forceinline__ float tab_rsqrt(const uint16_t *tab, float x)
 	return __uint_as_float(r);
 }
 
-__device__ __forceinline__ v4 v4_normalise(const uint16_t *rsq, v4 a)
+template<class TP> __device__ __forceinline__ v4 v4_normalise(TP rsq, v4 a)
 {
 	return v4_scale(tab_rsqrt(rsq, v4_dot(a, a)), a);
 }
@@ -310,7 +312,7 @@ __device__ __forceinline__ uint64_t exp2f_tab(int i)
 
 // lds_tab: the 32-entry table in LDS (tables.h PWN_T_EXP2), or NULL for the copy in constant memory (a
 // per-lane global load: fine for the probe kernel, a long stall in the trace kernels)
-__device__ PWN_LIBM_ATTR float glibc_expf(float x, const uint64_t *lds_tab = nullptr)
+template<class TP> __device__ PWN_LIBM_ATTR float glibc_expf_t(float x, TP lds_tab, bool have_tab)
 {
 	const double N = 32.0;
 	const double InvLn2N = 0x1.71547652b82fep+0 * N;
@@ -328,7 +330,7 @@ __device__ PWN_LIBM_ATTR float glibc_expf(float x, const uint64_t *lds_tab = nul
 	uint64_t ki = (uint64_t)__double_as_longlong(kd);
 	kd -= SHIFT;
 	double r = fma(InvLn2N, xd, -kd);
-	uint64_t t = lds_tab ? lds_tab[ki & 31u] : exp2f_tab((int)(ki & 31u));
+	uint64_t t = have_tab ? (uint64_t)lds_tab[ki & 31u] : exp2f_tab((int)(ki & 31u));
 	t += ki << (52 - 5);
 	double s = __longlong_as_double((long long)t);
 	double z = fma(C0, r, C1);
@@ -352,3 +354,5 @@ __device__ PWN_LIBM_ATTR float glibc_expf(float x, const uint64_t *lds_tab = nul
 	}
 	return res;
 }
+__device__ PWN_LIBM_ATTR float glibc_expf(float x) { return glibc_expf_t<const uint64_t *>(x, nullptr, false); }
+template<class TP> __device__ PWN_LIBM_ATTR float glibc_expf(float x, TP lds_tab) { return glibc_expf_t<TP>(x, lds_tab, true); }

@@ -24,16 +24,38 @@ enum { FXP = 0, FZP, FXN, FZN, FYP, FYN };   // defs.h:25-33
 #define PWN_MIN_WAVES 3
 #endif
 
+// The tables of the blob sit at CONSTANT offsets of the workgroup's LDS (tables.h; the kernels have no static
+// __shared__ data, so the dynamic allocation they are copied into starts at LDS address 0 -- the kernels check
+// that once).  They are addressed through LDS-address-space pointers made from those constants, so a table
+// access is a ds_read with an immediate offset; through the `extern __shared__` symbol every access adds that
+// symbol's address (0, but known too late to fold): 21 `v_add_u32 v, 0, v` in the kernel, one per cell step.
+#define PWN_LDS __attribute__((address_space(3)))
+template<class T> __device__ __forceinline__ const PWN_LDS T *lds_at(uint32_t byte) { return (const PWN_LDS T *)(uintptr_t)byte; }
+// (16-byte LDS loads as a built-in vector type: HIP's float4 class has no constructor from another address space)
+typedef float pwn_f4 __attribute__((ext_vector_type(4)));
 struct Lds
 {
-	const uint32_t *cellinfo;
-	const uint16_t *rcp, *rsq;
-	const uint32_t *pmap;
-	const uint16_t *binidx;
-	const float *sph;
-	const uint64_t *exp2;         // tables.h PWN_T_EXP2
-	const float4 *faces;          // tables.h PWN_T_FACES: [0..4) wall colours, [4 + 2 * face ..] face constants
+	const PWN_LDS uint32_t *cellinfo;
+	const PWN_LDS uint16_t *rcp, *rsq;
+	const PWN_LDS uint32_t *pmap;
+	const PWN_LDS uint16_t *binidx;
+	const PWN_LDS float *sph;
+	const PWN_LDS uint64_t *exp2;         // tables.h PWN_T_EXP2
+	const PWN_LDS pwn_f4 *faces;           // tables.h PWN_T_FACES: [0..4) wall colours, [4 + 2 * face ..] face constants
 };
+__device__ __forceinline__ Lds lds_tables(uint32_t off_sph)
+{
+	Lds L;
+	L.cellinfo = lds_at<uint32_t>(PWN_T_CELLINFO);
+	L.rcp = lds_at<uint16_t>(PWN_T_RCP);
+	L.rsq = lds_at<uint16_t>(PWN_T_RSQ);
+	L.pmap = lds_at<uint32_t>(PWN_T_PMAP);
+	L.binidx = lds_at<uint16_t>(PWN_T_BINIDX);
+	L.faces = lds_at<pwn_f4>(PWN_T_FACES);
+	L.exp2 = lds_at<uint64_t>(PWN_T_EXP2);
+	L.sph = lds_at<float>(off_sph);
+	return L;
+}
 
 // util.h:151-158 (per-axis clamp to 0) -> the packed cell word.  The table has
 // 65 rows / columns; index 64 repeats index 0 (tables.h), so the clamp is a min.
@@ -71,7 +93,7 @@ __device__ __forceinline__ uint32_t cellword_pk(const Lds &L, uint32_t cxz)
 	const pwn_us2 lim = { 64, 64 }, pitch = { 4, (unsigned short)(PWN_GRID_PITCH * 4u) };
 	const pwn_us2 c = __builtin_elementwise_min(__builtin_bit_cast(pwn_us2, cxz), lim);
 	const uint32_t byte = __builtin_amdgcn_udot2(c, pitch, 0u, false);
-	return *(const uint32_t *)((const unsigned char *)L.cellinfo + byte);
+	return *(const PWN_LDS uint32_t *)((const PWN_LDS unsigned char *)L.cellinfo + byte);
 }
 
 // HAS_W = false: the camera rows x,y,z carry w = 0 and the position w = 1
@@ -106,7 +128,7 @@ template<bool W> __device__ __forceinline__ Vec<W> vsub(const Vec<W> &a, const V
 	return r;
 }
 // util.h:32-46
-template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const uint16_t *rsq, const Vec<W> &a)
+template<bool W> __device__ __forceinline__ Vec<W> vnormalise(const PWN_LDS uint16_t *rsq, const Vec<W> &a)
 {
 	return vscale<W>(tab_rsqrt(rsq, dot3<W>(a, a)), a);
 }

@@ -50,15 +50,9 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 	}
 	__syncthreads();
 
-	Lds L;
-	L.cellinfo = (const uint32_t *)(lds_raw + PWN_T_CELLINFO);
-	L.rcp = (const uint16_t *)(lds_raw + PWN_T_RCP);
-	L.rsq = (const uint16_t *)(lds_raw + PWN_T_RSQ);
-	L.pmap = (const uint32_t *)(lds_raw + PWN_T_PMAP);
-	L.binidx = (const uint16_t *)(lds_raw + PWN_T_BINIDX);
-	L.faces = (const float4 *)(lds_raw + PWN_T_FACES);
-	L.exp2 = (const uint64_t *)(lds_raw + PWN_T_EXP2);
-	L.sph = (const float *)(lds_raw + P.off_sph);
+	// (the tables are addressed from LDS address 0 on: trace_common.h)
+	if((uint32_t)(uintptr_t)(PWN_LDS unsigned char *)lds_raw != 0u) __builtin_trap();
+	const Lds L = lds_tables(P.off_sph);
 
 	typedef Vec<HAS_W> V;
 	V rayb, rdx, rdy, cam_from;
@@ -159,8 +153,8 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 				else
 				{
 					// trace.h:283-291 for the committed sphere
-					const float4 *sp = (const float4 *)(L.sph + 8 * aux_idx);
-					const float4 s0 = sp[0], s1 = sp[1];
+					const PWN_LDS pwn_f4 *sp = (const PWN_LDS pwn_f4 *)(L.sph + 8 * aux_idx);
+					const pwn_f4 s0 = sp[0], s1 = sp[1];
 					V d;
 					d.x = aux_pos.x - s0.z; d.y = aux_pos.y - s0.w; d.z = aux_pos.z - s1.x;
 					if constexpr(HAS_W) d.w = aux_pos.w - 1.0f; else d.w = 0.0f;
