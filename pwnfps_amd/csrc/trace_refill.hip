@@ -50,8 +50,8 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 	}
 	__syncthreads();
 
-	// (the tables are addressed from LDS address 0 on: trace_common.h)
-	if((uint32_t)(uintptr_t)(PWN_LDS unsigned char *)lds_raw != 0u) __builtin_trap();
+	// (the tables are addressed from LDS address 0 on, trace_common.h; the launcher checks that this kernel has
+	// no static LDS in front of the dynamic allocation)
 	const Lds L = lds_tables(P.off_sph);
 
 	typedef Vec<HAS_W> V;
@@ -497,7 +497,13 @@ static hipError_t launch_variant(const pwn_trace_params *P, int grid, size_t lds
 		size_t &lds_set = lds_mark[dev & 63];
 		if(lds_bytes > lds_set)
 		{
-			hipError_t e = hipFuncSetAttribute((const void *)pwn_trace_refill_kernel<COUNT, HAS_W>,
+			// the kernel addresses its tables from LDS address 0 (trace_common.h): that holds while it has no
+			// static LDS, which would be laid out in front of the dynamic allocation
+			hipFuncAttributes fa;
+			hipError_t e = hipFuncGetAttributes(&fa, (const void *)pwn_trace_refill_kernel<COUNT, HAS_W>);
+			if(e != hipSuccess) return e;
+			if(fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
+			e = hipFuncSetAttribute((const void *)pwn_trace_refill_kernel<COUNT, HAS_W>,
 				hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 			if(e != hipSuccess) return e;
 			lds_set = lds_bytes;
