@@ -34,19 +34,13 @@
 template<bool COUNT, bool HAS_W>
 __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uint32_t seed,
 	Vec<HAS_W> from, Vec<HAS_W> iray, float &out_x, float &out_y, float &out_z, float &out_w,
-	float *zpix, Counters &cnt, float *stk)
+	float *zpix, Counters &cnt)
 {
 	typedef Vec<HAS_W> V;
 	// icol (screen.h:24).  Its w lane, and the w lane of every surface colour, is
 	// x * 0.0f (COL_* have a = 0, defs.h:17-19; spheres get b,g,r only, script.h:30-32):
 	// +-0 for any finite input, and the sign of a zero never reaches a pixel, so the
 	// w lanes of icol and of the composite stack are not kept.
-	// (kept in the composite stack below: the top entry's colour)
-#ifdef PWN_LDS_STACK
-	// the composite stack (reflectivity, fog, colour of the two bounced-off surfaces) lives in
-	// LDS, one float per thread and slot (stride PWN_BLOCK: conflict-free), not in registers
-#define STK(level, k) stk[((level) * 5 + (k)) * PWN_BLOCK]
-#else
 	// The composite stack (reflectivity, fog, colour of the surfaces the ray bounced off), two entries, as a
 	// shift register: a bounce moves the top entry down and writes the new one on top (plain moves; indexing by
 	// the segment number made ten selects of it).  The top entry's colour IS the next segment's icol
@@ -57,7 +51,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #define icx sc0x
 #define icy sc0y
 #define icz sc0z
-#endif
 	// Every lane still in the segment loop is on the same segment, so the segment number `seg` is one scalar
 	// for the wave (tests on it are scalar branches); `depth`, the number of surfaces a pixel's ray bounced off,
 	// is per lane and set where the lane leaves the loop.
@@ -182,11 +175,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			if(diffuse < 0.0f) diffuse = 0.0f;
 			const float amb = 0.1f;
 			diffuse = (1.0f - amb) * diffuse + amb;
-#ifdef PWN_LDS_STACK
-			// icol of a bounced ray = the colour of the surface it left (trace.h:90): the stack entry below
-			float icx = 1.0f, icy = 1.0f, icz = 1.0f;
-			if(seg > 0) { icx = STK(seg - 1, 2); icy = STK(seg - 1, 3); icz = STK(seg - 1, 4); }
-#endif
 			colx = diffuse * (icx * wc.x); coly = diffuse * (icy * wc.y); colz = diffuse * (icz * wc.z);
 			w_acc = __builtin_fmaf(diffuse, 0.0f, w_acc);
 			refl = fa.w;
@@ -244,42 +232,14 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		ray.z += lcg_fs(seed) * REFLECT_BLUR_F;
 		lcg_next(seed);
 
-#ifdef PWN_LDS_STACK
-		STK(seg, 0) = refl; STK(seg, 1) = fog; STK(seg, 2) = colx; STK(seg, 3) = coly; STK(seg, 4) = colz;
-#else
 		st_refl1 = st_refl0; st_fog1 = st_fog0; sc1x = sc0x; sc1y = sc0y; sc1z = sc0z;
 		st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz;
-#endif
 		seg++;
 		from = pos;
 		iray = ray;
 	}
 
 	// trace.h:91-101, innermost first
-#ifdef PWN_LDS_STACK
-	if(depth >= 2)
-	{
-		const float st_refl1 = STK(1, 0), st_fog1 = STK(1, 1), sc1x = STK(1, 2), sc1y = STK(1, 3), sc1z = STK(1, 4);
-		const float r1 = st_refl1, q1 = 1.0f - st_refl1;
-		vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
-		if(st_fog1 != 0.0f)
-		{
-			float f = glibc_expf(-0.6f * st_fog1, L.exp2), g = 1.0f - f;
-			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
-		}
-	}
-	if(depth >= 1)
-	{
-		const float st_refl0 = STK(0, 0), st_fog0 = STK(0, 1), sc0x = STK(0, 2), sc0y = STK(0, 3), sc0z = STK(0, 4);
-		const float r0 = st_refl0, q0 = 1.0f - st_refl0;
-		vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw;
-		if(st_fog0 != 0.0f)
-		{
-			float f = glibc_expf(-0.6f * st_fog0, L.exp2), g = 1.0f - f;
-			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
-		}
-	}
-#else
 	// the top of the stack is the last surface the ray bounced off, the entry below it the one before
 	if(depth >= 1)
 	{
@@ -304,7 +264,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #undef icx
 #undef icy
 #undef icz
-#endif
 	out_x = vx; out_y = vy; out_z = vz; out_w = vw + w_acc;
 }
 
@@ -473,8 +432,7 @@ pwn_trace_kernel(pwn_trace_params P)
 
 			float ox, oy, oz, ow;
 			const size_t o = (size_t)y * (size_t)P.w + (size_t)x;
-			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt,
-				(float *)(lds_raw + ((P.blob_bytes + 15u) & ~15u)) + threadIdx.x);
+			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
 			P.sbuf[o] = ftoint_lane(ox) | (ftoint_lane(oy) << 8) | (ftoint_lane(oz) << 16) | (ftoint_lane(ow) << 24);
 		}
 		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
@@ -549,11 +507,7 @@ extern "C" int pwn_trace_tile_w(void) { return TILE_W; }
 // LDS a workgroup needs beyond the table blob
 extern "C" unsigned pwn_trace_lds_extra(void)
 {
-#ifdef PWN_LDS_STACK
-	return 10u * 4u * PWN_BLOCK;
-#else
 	return 0u;
-#endif
 }
 
 extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w)
