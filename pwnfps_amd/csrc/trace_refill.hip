@@ -91,9 +91,12 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 	int ev = EV_IDLE;
 	uint32_t o = 0u, seed = 0u;
 	int depth = 0;
-	float icx = 1.0f, icy = 1.0f, icz = 1.0f;          // icol (screen.h:24; trace.h:90 for a bounced ray); w lanes: see trace_kernel.hip
+	// icol (screen.h:24; trace.h:90 for a bounced ray) is the colour of the composite stack's top entry (trace_kernel.hip)
 	float st_refl0 = 0.0f, st_refl1 = 0.0f, st_fog0 = 0.0f, st_fog1 = 0.0f;
-	float sc0x = 0.0f, sc0y = 0.0f, sc0z = 0.0f, sc1x = 0.0f, sc1y = 0.0f, sc1z = 0.0f;
+	float sc0x = 1.0f, sc0y = 1.0f, sc0z = 1.0f, sc1x = 0.0f, sc1y = 0.0f, sc1z = 0.0f;
+#define icx sc0x
+#define icy sc0y
+#define icz sc0z
 	float w_acc = 0.0f;                                 // stand-in for the colour's w lane (trace_kernel.hip)
 	// ---- per lane: the ray (trace.h:186-248)
 	V pos, ray, aux_pos;
@@ -134,21 +137,31 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 				aux_norm.x = aux_norm.y = aux_norm.z = aux_norm.w = 0.0f;
 				if(ev == EV_WALL)
 				{
-					// trace.h:108-154
-					float bx, by, bz;
-					if(base == BASE_CEIL) { bx = 30.0f; by = 30.0f; bz = 0.0f; }
-					else if(base == BASE_FLOOR) { bx = 1.0f; by = 1.0f; bz = 1.0f; }
-					else if(base == BASE_WALL) { bx = 0.8f; by = 0.8f; bz = 1.0f; }
-					else { bx = 5.0f; by = 0.0f; bz = 5.0f; }
-					float diffuse;
-					if(ldir >= FYP) diffuse = ray.y; else diffuse = (ldir & 1) ? ray.z : ray.x;
-					if(ldir == FXN || ldir == FZN || ldir == FYN) diffuse = -diffuse;
+					// trace.h:108-154 and the axis-aligned mirrors of trace.h:50-75 from the constant tables in LDS
+					// (tables.h PWN_T_FACES; trace_kernel.hip has the same block)
+					// (one table entry at a time: this kernel keeps every lane's walk state live across phase A)
+					float diffuse = (ldir & 1) ? ray.z : ray.x;
+					diffuse = ldir >= FYP ? ray.y : diffuse;
+					{
+						const pwn_f4 fb = L.faces[5 + 2 * ldir];
+						diffuse = __uint_as_float(__float_as_uint(diffuse) ^ __float_as_uint(fb.w));      // -ray.c on the N faces
+						pos.x += fb.x; pos.y += fb.y; pos.z += fb.z;
+					}
 					if(diffuse < 0.0f) diffuse = 0.0f;
 					const float amb = 0.1f;
 					diffuse = (1.0f - amb) * diffuse + amb;
-					colx = diffuse * (icx * bx); coly = diffuse * (icy * by); colz = diffuse * (icz * bz);
+					{
+						const pwn_f4 wc = L.faces[base];
+						colx = diffuse * (icx * wc.x); coly = diffuse * (icy * wc.y); colz = diffuse * (icz * wc.z);
+					}
 					w_acc = __builtin_fmaf(diffuse, 0.0f, w_acc);
-					refl = (ldir == FYN ? 0.7f : 0.25f);
+					{
+						const pwn_f4 fa = L.faces[4 + 2 * ldir];
+						refl = fa.w;
+						ray.x = __uint_as_float(__float_as_uint(ray.x) ^ __float_as_uint(fa.x));
+						ray.y = __uint_as_float(__float_as_uint(ray.y) ^ __float_as_uint(fa.y));
+						ray.z = __uint_as_float(__float_as_uint(ray.z) ^ __float_as_uint(fa.z));
+					}
 				}
 				else
 				{
@@ -173,7 +186,6 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 					// trace.h:9-75
 					if(ldir == FYN)
 					{
-						pos.y -= 0.001f;
 						const float pi = (float)3.14159265358979323846;
 						float ang = (pi * 2.0f) * (
 							(glibc_sincosf((pi * 0.5f) * pos.x, 0) + glibc_sincosf((pi * 0.5f) * pos.z, 1))
@@ -190,11 +202,6 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 						float rmul = -2.0f * ((ray.x * aux_norm.x + ray.y * aux_norm.y) + ray.z * aux_norm.z);
 						ray = vnormalise<HAS_W>(L.rsq, vadd<HAS_W>(vscale<HAS_W>(rmul, aux_norm), ray));
 					}
-					else if(ldir == FXP) { ray.x = -ray.x; pos.x -= 0.001f; }
-					else if(ldir == FXN) { ray.x = -ray.x; pos.x += 0.001f; }
-					else if(ldir == FZP) { ray.z = -ray.z; pos.z -= 0.001f; }
-					else if(ldir == FZN) { ray.z = -ray.z; pos.z += 0.001f; }
-					else { ray.y = -ray.y; pos.y -= 0.001f; }
 
 					// trace.h:77-84: five draws, two discarded
 					ray.x += lcg_fs(seed) * REFLECT_BLUR_F;
@@ -203,10 +210,10 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 					ray.z += lcg_fs(seed) * REFLECT_BLUR_F;
 					lcg_next(seed);
 
-					if(depth == 0) { st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz; }
-					else { st_refl1 = refl; st_fog1 = fog; sc1x = colx; sc1y = coly; sc1z = colz; }
+					// the composite stack as a shift register; its top entry's colour is the next segment's icol
+					st_refl1 = st_refl0; st_fog1 = st_fog0; sc1x = sc0x; sc1y = sc0y; sc1z = sc0z;
+					st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz;
 					depth++;
-					icx = colx; icy = coly; icz = colz;
 					// the bounced ray starts at pos with direction ray (trace.h:90): set up below
 					ev = EV_SETUP;
 					finished = false;
@@ -215,17 +222,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 			}
 			if(finished)
 			{
-				// trace.h:91-101, innermost first
-				if(depth >= 2)
-				{
-					const float r1 = st_refl1, q1 = 1.0f - st_refl1;
-					vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
-					if(st_fog1 != 0.0f)
-					{
-						float f = glibc_expf(-0.6f * st_fog1, L.exp2), g = 1.0f - f;
-						vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
-					}
-				}
+				// trace.h:91-101, innermost first: the top of the stack, then the entry below it
 				if(depth >= 1)
 				{
 					const float r0 = st_refl0, q0 = 1.0f - st_refl0;
@@ -233,6 +230,16 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 					if(st_fog0 != 0.0f)
 					{
 						float f = glibc_expf(-0.6f * st_fog0, L.exp2), g = 1.0f - f;
+						vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
+					}
+				}
+				if(depth >= 2)
+				{
+					const float r1 = st_refl1, q1 = 1.0f - st_refl1;
+					vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
+					if(st_fog1 != 0.0f)
+					{
+						float f = glibc_expf(-0.6f * st_fog1, L.exp2), g = 1.0f - f;
 						vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 					}
 				}
@@ -360,7 +367,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 						seed = (uint32_t)x + (uint32_t)y * (uint32_t)y * ((uint32_t)P.w + 1u);
 						seed *= seed * seed;
 						seed *= seed * seed;
-						depth = 0; icx = icy = icz = 1.0f; w_acc = 0.0f;
+						depth = 0; sc0x = sc0y = sc0z = 1.0f; w_acc = 0.0f;
 						ev = EV_SETUP;
 					}
 				}
@@ -381,24 +388,27 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 			const V iray = ray;
 			ray = vnormalise<HAS_W>(L.rsq, iray);
 			const int cx = (int)pos.x, cz = (int)pos.z;
-			if(fabsf(ray.x) < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
-			if(fabsf(ray.y) < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
-			if(fabsf(ray.z) < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
 			// signs of the UN-normalised input (trace.h:225-227)
 			const int gx = (iray.x < 0.0f ? -1 : 1);
 			const int gz = (iray.z < 0.0f ? -1 : 1);
 			const bool gyp = !(iray.y < 0.0f);          // gy > 0
+			// trace.h:220-222 and 230-231: one test on the bit patterns, one wave-uniform branch (trace_kernel.hip)
 			{
-				const float ax = fabsf(ray.x), ay = fabsf(ray.y), az = fabsf(ray.z);
-				const uint32_t ux = __float_as_uint(ax) - 0x00800000u, uy = __float_as_uint(ay) - 0x00800000u,
-					uz = __float_as_uint(az) - 0x00800000u;
-				if(max(max(ux, uy), uz) < 0x7e000000u)
+				const uint32_t EPSB = __float_as_uint(EPS);
+				const uint32_t bx = __float_as_uint(ray.x) & 0x7fffffffu, by = __float_as_uint(ray.y) & 0x7fffffffu,
+					bz = __float_as_uint(ray.z) & 0x7fffffffu;
+				const bool plain = max(max(bx - EPSB, by - EPSB), bz - EPSB) < 0x7e800000u - EPSB;
+				if(__builtin_expect(__ballot(!plain) == 0ull, 1))
 				{
-					iax = tab_rcp_pos(L.rcp, ax); iay = tab_rcp_pos(L.rcp, ay); iaz = tab_rcp_pos(L.rcp, az);
+					iax = tab_rcp_pos(L.rcp, __uint_as_float(bx)); iay = tab_rcp_pos(L.rcp, __uint_as_float(by));
+					iaz = tab_rcp_pos(L.rcp, __uint_as_float(bz));
 				}
 				else
 				{
-					iax = tab_rcp(L.rcp, ax); iay = tab_rcp(L.rcp, ay); iaz = tab_rcp(L.rcp, az);
+					if(fabsf(ray.x) < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
+					if(fabsf(ray.y) < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
+					if(fabsf(ray.z) < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
+					iax = tab_rcp(L.rcp, fabsf(ray.x)); iay = tab_rcp(L.rcp, fabsf(ray.y)); iaz = tab_rcp(L.rcp, fabsf(ray.z));
 				}
 			}
 			wx = pos.x - (float)cx; wy = pos.y; wz = pos.z - (float)cz;
