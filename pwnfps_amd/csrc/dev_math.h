@@ -125,7 +125,8 @@ __device__ __forceinline__ float lcg_fs(uint32_t &s)
 	// under the reference's -ffast-math
 	const float inv = 1.0f / 3759.0f;
 	float u = (float)(lcg_next(s) % 3759u) * inv;
-	return u * 2.0f - 1.0f;
+	// u * 2 - 1 as one fused operation: doubling is exact, so there is still exactly one rounding
+	return __builtin_fmaf(u, 2.0f, -1.0f);
 }
 
 // ---- colour pack: cvtps2dq (RNE) + packs_epi32 + packus_epi16 --------------
