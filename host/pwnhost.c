@@ -32,6 +32,8 @@
  * GPU (pwn_tiled_*: RCCL inside the library): start the same command once per rank with its
  * -R (and -d DEVICE); rank 0 writes the group id to IDFILE, the others wait for it; rank 0
  * presents the frames.  -H ROWS sets the halo (default -1 = depth 24, 0 = whole strips).
+ * -M 1: the frames are delivered to the host by every rank (pwn_tiled_host_sink): one frame buffer in POSIX
+ * shared memory, every rank copies its strip into it over its own PCIe link, nothing is gathered to rank 0.
  * -q SLOTS (2..4) keeps that many frames in flight (pwn_submit_frame /
  * pwn_wait_frame): the frame and its upscaled surface arrive in the library's
  * pinned host buffers while the next frame's kernels run; frame f is presented
@@ -45,6 +47,10 @@
 #include <stdint.h>
 #include <math.h>
 #include <time.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
 
 #include "pwnhip.h"
 #include "game_script.h"
@@ -167,7 +173,7 @@ int main(int argc, char **argv)
 {
 	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL, *luafile = NULL, *keyfile = NULL;
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
-	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL, window = 0, frames_given = 0;
+	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL, window = 0, frames_given = 0, hostsink = 0;
 	const char *idfile = NULL;
 	float turn = 0.0f, fixed_dt = -1.0f;
 	for(int i = 1; i < argc; i++)
@@ -197,6 +203,7 @@ int main(int argc, char **argv)
 			case 'R': rank = atoi(argv[++i]); break;
 			case 'I': idfile = argv[++i]; break;
 			case 'H': halo = atoi(argv[++i]); break;
+			case 'M': hostsink = atoi(argv[++i]); break;
 			case 'T': transport = strcmp(argv[++i], "shm") == 0 ? PWN_TRANSPORT_SHM : PWN_TRANSPORT_RCCL; break;
 			default: fprintf(stderr, "unknown option %s\n", argv[i]); return 2;
 		}
@@ -317,6 +324,38 @@ int main(int argc, char **argv)
 			fclose(fp);
 		}
 		CHK(pwn_tiled_init(ctx, rank, world, id, transport, halo));
+		void *host_frames = NULL;
+		const size_t host_bytes = (size_t)PWN_TILED_SLOTS * npix * 4;
+		char shm_name[256];
+		shm_name[0] = 0;
+		if(hostsink)
+		{
+			/* one frame buffer for all ranks: POSIX shared memory named after the id file.  Rank 0 creates it;
+			   the others, who leave pwn_tiled_init (a collective) after rank 0 entered it, wait for its size. */
+			const char *b = strrchr(idfile, '/');
+			snprintf(shm_name, sizeof(shm_name), "/pwn_frames_%s", b ? b + 1 : idfile);
+			int fd = -1;
+			if(rank == 0)
+			{
+				fd = shm_open(shm_name, O_CREAT | O_RDWR, 0600);
+				if(fd >= 0 && ftruncate(fd, (off_t)host_bytes) != 0) { close(fd); fd = -1; }
+			}
+			else
+				for(int tries = 0; tries < 12000; tries++)
+				{
+					struct stat sb;
+					fd = shm_open(shm_name, O_RDWR, 0600);
+					if(fd >= 0 && fstat(fd, &sb) == 0 && (size_t)sb.st_size >= host_bytes) break;
+					if(fd >= 0) { close(fd); fd = -1; }
+					struct timespec ts = { 0, 10 * 1000 * 1000 };
+					nanosleep(&ts, NULL);
+				}
+			if(fd < 0) { fprintf(stderr, "rank %d: shared memory %s\n", rank, shm_name); pwn_destroy(ctx); return 1; }
+			host_frames = mmap(NULL, host_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+			close(fd);
+			if(host_frames == MAP_FAILED) { fprintf(stderr, "rank %d: mmap %s\n", rank, shm_name); pwn_destroy(ctx); return 1; }
+			CHK(pwn_tiled_host_sink(ctx, host_frames, host_bytes));
+		}
 		if(fixed_dt < 0.0f) fixed_dt = 0.0f;
 		pwn_tiled_frame tf;
 		memset(&tf, 0, sizeof(tf));
@@ -333,7 +372,7 @@ int main(int argc, char **argv)
 			if(f >= 2)
 			{
 				CHK(pwn_tiled_wait(ctx, PWN_TILED_HOST, &tf));
-				if(rank == 0 && verbose)
+				if((rank == 0 || hostsink) && verbose)
 					printf("frame %d sec %.9g fnv64 %016llx\n", f - 2, (double)(fixed_dt * (float)(f - 2)), (unsigned long long)fnv64(tf.sbuf, npix));
 				if(f == 2) t1 = now_s();
 			}
@@ -367,6 +406,11 @@ int main(int argc, char **argv)
 		}
 		pwn_tiled_shutdown(ctx);
 		pwn_destroy(ctx);
+		if(host_frames != NULL)
+		{
+			munmap(host_frames, host_bytes);
+			if(rank == 0) shm_unlink(shm_name);
+		}
 		free(sph); free(sbuf); free(zbuf); free(surface.pixels);
 		return 0;
 	}

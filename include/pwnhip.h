@@ -250,6 +250,16 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
  *   pwn_tiled_wait       every rank: block until the oldest frame in flight is complete; on rank 0
  *                        out->d_sbuf is the full frame on the device (valid until three more frames
  *                        were submitted) and, with PWN_TILED_HOST, out->sbuf a pinned host copy.
+ *   pwn_tiled_host_sink  optional, every rank, after pwn_tiled_init and before the first frame: frames are
+ *                        delivered to the HOST instead (main.c:107-109 presents every frame there).  `base` is
+ *                        host memory for PWN_TILED_SLOTS whole frames (w*h*4 bytes each, pitch = width), the SAME
+ *                        memory in every rank -- POSIX shared memory mapped by every process -- which the library
+ *                        registers with its device.  Every rank then copies its finished strip straight into the
+ *                        frame over its own PCIe link (N links, not rank 0's one) and there is no gather to rank
+ *                        0: the grouped exchange carries the halo rows and one word per rank, sent behind that
+ *                        rank's copy, so that a frame is delivered when every strip has landed.  pwn_tiled_wait
+ *                        then gives out->sbuf on EVERY rank (valid until the second next pwn_tiled_wait),
+ *                        out->d_sbuf is NULL.
  *   pwn_tiled_shutdown   collective; pwn_destroy does it too.
  * PWN_TRANSPORT_SHM moves the same messages through POSIX shared memory instead: for tests
  * on a box with one GPU, where RCCL cannot run two ranks; the ranks may share a device.
@@ -258,10 +268,11 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
 #define PWN_TRANSPORT_RCCL 0
 #define PWN_TRANSPORT_SHM  1
 #define PWN_TILED_HOST     1
+#define PWN_TILED_SLOTS    4       /* frames a host sink holds (three in flight and the one being reused) */
 typedef struct pwn_tiled_frame
 {
 	const void *d_sbuf;          /* rank 0: the frame on the device, BGRA8, pitch = width; NULL elsewhere */
-	const uint32_t *sbuf;        /* rank 0 with PWN_TILED_HOST: pinned host copy                          */
+	const uint32_t *sbuf;        /* rank 0 with PWN_TILED_HOST: pinned host copy; with a host sink: the frame, on every rank */
 	uint64_t seq;                /* 1, 2, ... in submission order */
 	int redone;                  /* 1: a tap left the halo and the frame was repeated with whole strips */
 	int timed;                   /* PWN_OPT_FRAME_TIMING sampled this frame: */
@@ -272,11 +283,14 @@ typedef struct pwn_tiled_info
 	int rank, world, y0, y1, rows_per_rank, halo_rows, transport;
 	uint64_t frames, frames_redone, groups;        /* delivered frames; repeated ones; grouped exchanges launched */
 	uint64_t bytes_sent, bytes_received;           /* by this rank */
+	uint64_t bytes_to_host;                        /* host sink: copied into the host frame by this rank */
+	int host_sink;                                 /* 1: every rank delivers its strip to the host (pwn_tiled_host_sink) */
 } pwn_tiled_info;
 int pwn_tiled_unique_id(void *id128, int transport);
 int pwn_tiled_init(pwn_ctx *ctx, int rank, int world, const void *id128, int transport, int halo_rows);
 int pwn_tiled_submit(pwn_ctx *ctx, const float cam[16], float sec_current);
 int pwn_tiled_wait(pwn_ctx *ctx, int flags, pwn_tiled_frame *out);
+int pwn_tiled_host_sink(pwn_ctx *ctx, void *base, size_t bytes);
 int pwn_tiled_get_info(pwn_ctx *ctx, pwn_tiled_info *out);
 void pwn_tiled_shutdown(pwn_ctx *ctx);
 

@@ -50,12 +50,14 @@ class TiledFrame(C.Structure):
 
 class TiledInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("rank", "world", "y0", "y1", "rows_per_rank", "halo_rows", "transport")] + \
-               [(n, C.c_uint64) for n in ("frames", "frames_redone", "groups", "bytes_sent", "bytes_received")]
+               [(n, C.c_uint64) for n in ("frames", "frames_redone", "groups", "bytes_sent", "bytes_received", "bytes_to_host")] + \
+               [("host_sink", C.c_int)]
 
 
 PWN_TILED_ID_BYTES = 128
 PWN_TRANSPORT_RCCL, PWN_TRANSPORT_SHM = 0, 1
 PWN_TILED_HOST = 1
+PWN_TILED_SLOTS = 4
 
 # every symbol include/pwnhip.h declares: (name, restype, argtypes)
 _vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
@@ -90,6 +92,7 @@ ABI = [
     ("pwn_tiled_init", _i, [_vp, _i, _i, _vp, _i, _i]),
     ("pwn_tiled_submit", _i, [_vp, _vp, _f]),
     ("pwn_tiled_wait", _i, [_vp, _i, C.POINTER(TiledFrame)]),
+    ("pwn_tiled_host_sink", _i, [_vp, _vp, C.c_size_t]),
     ("pwn_tiled_get_info", _i, [_vp, C.POINTER(TiledInfo)]),
     ("pwn_tiled_shutdown", None, [_vp]),
     ("pwn_screen_upscale", _i, [_vp, _vp, _i, _i, _vp]),

@@ -27,6 +27,12 @@
 // delivered frame is always exact; the host synchronises only at delivery, two frames behind the
 // submissions.
 //
+// Host sink (pwn_tiled_host_sink): frames are delivered to ONE frame buffer in host memory that every rank has
+// mapped and registered.  There is then no gather: behind its blur every rank copies its strip into the frame on a
+// copy stream of its own (N PCIe links in parallel), and the second half of a group is one word per pair of ranks,
+// sent behind the sender's copy -- when a rank has received every other rank's word of frame f, every strip of f
+// is in host memory.  The word is the miss word, so the exactness protocol is unchanged.
+//
 // The transport is a small interface: RCCL (ncclSend / ncclRecv in a group, loaded with dlopen so
 // that libpwnhip.so has no link-time dependency on it), or -- for tests on a box with one GPU,
 // where RCCL cannot run two ranks -- POSIX shared memory through the host.
@@ -229,6 +235,10 @@ struct pwn_tiled
 	hipEvent_t ev_t[NSLOT], ev_x[NSLOT], ev_b[NSLOT], ev_d[NSLOT];
 	hipEvent_t ev_k0[NSLOT], ev_k1[NSLOT], ev_k2[NSLOT];      // timing (PWN_OPT_FRAME_TIMING): around the trace, behind the blur
 	hipEvent_t gathered_by[NSLOT];      // which of the above marks the slot's gather as done
+	// host sink: NSLOT whole frames in host memory shared by the ranks; this rank's copies on their own stream
+	uint8_t *host_base; bool host_registered;
+	hipStream_t copy;
+	hipEvent_t ev_h[NSLOT];             // behind the copy of the slot's strip into the host frame
 	bool timed[NSLOT];
 	// frames: submitted (traced, group opened), blurred (blur enqueued), gathered (gather in a group), delivered
 	unsigned long long submitted, blurred, gathered, delivered;
@@ -259,6 +269,7 @@ extern "C" int pwn_tiled_unique_id(void *id, int transport)
 	char err[200];
 	rccl_api *api = rccl_load(err, sizeof(err));
 	if(api == NULL) return PWN_ENOTSUP;
+	static_assert(NSLOT == PWN_TILED_SLOTS, "the host sink holds one frame per buffer set");
 	static_assert(sizeof(ncclUniqueId) == PWN_TILED_ID_BYTES, "the id is an ncclUniqueId");
 	return api->GetUniqueId((ncclUniqueId *)id) == ncclSuccess ? PWN_OK : PWN_EHIP;
 }
@@ -282,6 +293,9 @@ void pwn_tiled_destroy(pwn_ctx *c)
 		if(t->ev_k1[s]) (void)hipEventDestroy(t->ev_k1[s]);
 		if(t->ev_k2[s]) (void)hipEventDestroy(t->ev_k2[s]);
 	}
+	for(int s = 0; s < NSLOT; s++) if(t->ev_h[s]) (void)hipEventDestroy(t->ev_h[s]);
+	if(t->copy) (void)hipStreamDestroy(t->copy);
+	if(t->host_registered) (void)hipHostUnregister(t->host_base);
 	if(t->h_missv) (void)hipHostFree(t->h_missv);
 	if(t->h_frame) (void)hipHostFree(t->h_frame);
 	if(t->comm) (void)hipStreamDestroy(t->comm);
@@ -395,6 +409,27 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	return PWN_OK;
 }
 
+extern "C" int pwn_tiled_host_sink(pwn_ctx *c, void *base, size_t bytes)
+{
+	if(c == NULL || c->tiled == NULL || base == NULL) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	if(t->submitted != 0 || t->host_base != NULL) return PWN_EBUSY;
+	const size_t frame = (size_t)c->w * (size_t)c->h * 4;
+	if(bytes < frame * NSLOT) { snprintf(c->err, sizeof(c->err), "a host sink holds %d frames: %zu bytes", NSLOT, frame * NSLOT); return PWN_EINVAL; }
+	(void)hipSetDevice(c->device);
+	// memory of the caller (shared between the rank processes): make it known to this device.  Already pinned by
+	// this process (hipHostMalloc in a one-process test) is fine too.
+	hipError_t e = hipHostRegister(base, frame * NSLOT, hipHostRegisterDefault);
+	if(e == hipSuccess) t->host_registered = true;
+	else if(e == hipErrorHostMemoryAlreadyRegistered) (void)hipGetLastError();
+	else { snprintf(c->err, sizeof(c->err), "hipHostRegister: %s", hipGetErrorString(e)); return PWN_EHIP; }
+	if(hipStreamCreateWithFlags(&t->copy, hipStreamNonBlocking) != hipSuccess) return PWN_EHIP;
+	for(int s = 0; s < NSLOT; s++) if(hipEventCreateWithFlags(&t->ev_h[s], hipEventDisableTiming) != hipSuccess) return PWN_EHIP;
+	t->host_base = (uint8_t *)base;
+	t->info.host_sink = 1;
+	return PWN_OK;
+}
+
 extern "C" int pwn_tiled_get_info(pwn_ctx *c, pwn_tiled_info *out)
 {
 	if(c == NULL || out == NULL || c->tiled == NULL) return PWN_EINVAL;
@@ -415,6 +450,17 @@ static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 	const int s = (int)(g % NSLOT);
 	const size_t w4 = (size_t)c->w * 4;
 	uint32_t *mine = c->blur_passes ? t->out[s] : t->pre[s];
+	if(t->host_base != NULL)
+	{
+		// host sink: no strips; the word of every rank to every rank, behind that rank's copy to the host
+		for(int r = 0; r < t->world; r++)
+		{
+			if(r == t->rank) continue;
+			TPCHK(c, t->tp->send(t->missw[s], 4, r));
+			TPCHK(c, t->tp->recv(t->missv[s] + r, 4, r));
+		}
+		return PWN_OK;
+	}
 	if(t->rank == 0)
 	{
 		for(int r = 1; r < t->world; r++)
@@ -452,6 +498,20 @@ static int add_allgather(pwn_ctx *c, pwn_tiled *t, int s)
 	return PWN_OK;
 }
 
+// host sink: this rank's finished strip of the slot's frame into the host frame, behind its blur
+static int copy_strip_to_host(pwn_ctx *c, pwn_tiled *t, int s)
+{
+	if(t->y1 <= t->y0) { HIPCHK(c, hipEventRecord(t->ev_h[s], t->copy)); return PWN_OK; }
+	const size_t w4 = (size_t)c->w * 4, frame = w4 * (size_t)c->h;
+	const uint32_t *src = c->blur_passes ? t->out[s] : t->pre[s];
+	HIPCHK(c, hipStreamWaitEvent(t->copy, t->ev_b[s], 0));
+	HIPCHK(c, hipMemcpyAsync(t->host_base + (size_t)s * frame + (size_t)t->y0 * w4, src + (size_t)t->y0 * c->w,
+		(size_t)(t->y1 - t->y0) * w4, hipMemcpyDeviceToHost, t->copy));
+	HIPCHK(c, hipEventRecord(t->ev_h[s], t->copy));
+	t->info.bytes_to_host += (unsigned long long)(t->y1 - t->y0) * w4;
+	return PWN_OK;
+}
+
 // the blur of frame k, behind the group that brought its halo rows
 static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 {
@@ -460,7 +520,7 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 	if(c->blur_passes)
 	{
 		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
-		uint32_t *dst = t->rank == 0 ? t->fin[s] : t->out[s];
+		uint32_t *dst = (t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->out[s];
 		int rc;
 		if(t->fhalo[s])
 		{
@@ -473,6 +533,7 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 	}
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k2[s], cs));
 	HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
+	if(t->host_base != NULL) return copy_strip_to_host(c, t, s);
 	return PWN_OK;
 }
 
@@ -490,7 +551,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	// The slot's buffers were frame f-4's.  Its blur ran on this stream; its strips left in G(f-4) and in
 	// the group that carried its gather, and the frame was delivered (three in flight at most), which
 	// waited for that group on the host: nothing to wait for here.
-	uint32_t *plane = c->blur_passes ? t->pre[s] : (t->rank == 0 ? t->fin[s] : t->pre[s]);
+	uint32_t *plane = c->blur_passes ? t->pre[s] : ((t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->pre[s]);
 	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
 	int rc = pwn_i_launch_trace(c, cam, sec, t->y0, t->y1, plane, t->z[s], cs);
@@ -511,7 +572,11 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	// normally of frame f-2
 	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
 	const unsigned long long g_end = f >= 1 ? f - 1 : 0;        // gather frames [gathered, g_end)
-	for(unsigned long long g = t->gathered; g < g_end; g++) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
+	for(unsigned long long g = t->gathered; g < g_end; g++)
+	{
+		HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
+		if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));       // the word goes out behind the copy
+	}
 	if(t->world > 1)
 	{
 		TPCHK(c, t->tp->begin(t->comm));
@@ -564,7 +629,11 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	}
 	if(t->gathered <= d)
 	{
-		for(unsigned long long g = t->gathered; g <= d; g++) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
+		for(unsigned long long g = t->gathered; g <= d; g++)
+		{
+			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
+			if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));
+		}
 		if(t->world > 1)
 		{
 			TPCHK(c, t->tp->begin(t->comm));
@@ -578,6 +647,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	}
 	HIPCHK(c, hipEventSynchronize(t->gathered_by[s]));
 	HIPCHK(c, hipEventSynchronize(t->ev_b[s]));               // (world 1, and rank 0's own strip)
+	if(t->host_base != NULL) HIPCHK(c, hipEventSynchronize(t->ev_h[s]));      // this rank's own strip is in the host frame
 
 	// ---- was the bounded halo enough for this frame, on every rank?
 	bool miss = false;
@@ -603,11 +673,17 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		TPCHK(c, t->tp->end());
 		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
 		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_d[s], 0));
-		uint32_t *dst = t->rank == 0 ? t->fin[s] : t->out[s];
+		uint32_t *dst = (t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->out[s];
 		rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL);
 		if(rc != PWN_OK) return rc;
 		HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
 		HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[s], 0));
+		if(t->host_base != NULL)
+		{
+			rc = copy_strip_to_host(c, t, s);                     // the strip again, and the words behind it
+			if(rc != PWN_OK) return rc;
+			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[s], 0));
+		}
 		TPCHK(c, t->tp->begin(t->comm));
 		rc = add_gather(c, t, d);
 		if(rc != PWN_OK) return rc;
@@ -615,6 +691,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		t->info.groups += 2;
 		HIPCHK(c, hipStreamSynchronize(t->comm));
 		HIPCHK(c, hipStreamSynchronize(cs));
+		if(t->host_base != NULL) HIPCHK(c, hipStreamSynchronize(t->copy));
 	}
 	t->delivered = d + 1;
 	t->info.frames++;
@@ -629,7 +706,8 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 			(void)hipEventElapsedTime(&out->trace_ms, t->ev_k0[s], t->ev_k1[s]);
 			(void)hipEventElapsedTime(&out->frame_ms, t->ev_k0[s], t->ev_k2[s]);      // trace .. blur: the next frame's trace and the exchange in between
 		}
-		if(t->rank == 0)
+		if(t->host_base != NULL) out->sbuf = (const uint32_t *)(t->host_base + (size_t)s * n * 4);
+		else if(t->rank == 0)
 		{
 			out->d_sbuf = t->fin[s];
 			if(flags & PWN_TILED_HOST)

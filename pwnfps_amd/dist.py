@@ -37,6 +37,11 @@ a group with only the second half when no newer frames were submitted); three fr
 most.  Every rank then holds every rank's miss word of frame f: if one is non-zero ALL ranks repeat
 that frame's exchange with whole strips, its blur and its gather before it is delivered, and use
 whole strips from then on.
+
+Host sink (``pwn_tiled_host_sink``; here ``host_sink=`` an array of NSLOT frames in memory that every
+rank has mapped): there is no gather.  Behind its blur every rank copies its strip into the frame, and
+the second half of a group is one word per pair of ranks, sent after the sender's copy; a frame is
+delivered, on every rank, when every other rank's word of it has arrived.
 """
 import numpy as np
 import torch
@@ -93,7 +98,7 @@ class HipStripBackend:
 class TiledFrames:
     """pwn_tiled_init / _submit / _wait of pwn_tiled.cpp, restated.  Names follow the C code."""
 
-    def __init__(self, w, h, backend, device, rank=None, world=None, blur_passes=1, halo_rows=-1, group=None):
+    def __init__(self, w, h, backend, device, rank=None, world=None, blur_passes=1, halo_rows=-1, group=None, host_sink=None):
         self.w, self.h = int(w), int(h)
         self.group = group
         if world is None:
@@ -123,7 +128,11 @@ class TiledFrames:
         self.missw = [torch.zeros(1, dtype=torch.int32, **kw) for _ in range(NSLOT)]
         self.missv = [torch.zeros(world, dtype=torch.int32, **kw) for _ in range(NSLOT)]
         self.submitted = self.blurred = self.gathered = self.delivered = 0
-        self.info = dict(frames=0, frames_redone=0, groups=0, bytes_sent=0, bytes_received=0)
+        self.info = dict(frames=0, frames_redone=0, groups=0, bytes_sent=0, bytes_received=0, bytes_to_host=0)
+        # pwn_tiled_host_sink: uint32 [NSLOT, h, w] in memory shared by the ranks (np.memmap of one file ...)
+        self.host = host_sink
+        if self.host is not None and tuple(self.host.shape) != (NSLOT, self.h, self.w):
+            raise ValueError("a host sink holds %d frames of %dx%d" % (NSLOT, self.w, self.h))
 
     # ---- the transport: a group = operations that progress together -----------------------
     def _begin(self):
@@ -150,6 +159,14 @@ class TiledFrames:
     def _add_gather(self, g):
         s = g % NSLOT
         mine = self.out[s] if self.blur_passes else self.pre[s]
+        if self.host is not None:
+            # no strips: the word of every rank to every rank, behind that rank's copy to the host
+            for r in range(self.world):
+                if r == self.rank:
+                    continue
+                self._send(self.missw[s], r, TAG_MISS)
+                self._recv(self.missv[s][r:r + 1], r, TAG_MISS)
+            return
         if self.rank == 0:
             for r in range(1, self.world):
                 a, b = self._rows_of(r)
@@ -174,10 +191,18 @@ class TiledFrames:
             if b > a:
                 self._recv(self.pre[s][a:b], r, TAG_STRIP)
 
+    def _copy_strip_to_host(self, s):
+        if self.y1 > self.y0:
+            src = self.out[s] if self.blur_passes else self.pre[s]
+            self.host[s, self.y0:self.y1] = src[self.y0:self.y1].cpu().numpy().view(np.uint32)
+            if hasattr(self.host, "flush"):
+                self.host.flush()
+            self.info["bytes_to_host"] += (self.y1 - self.y0) * self.w * 4
+
     def _enqueue_blur(self, k):
         s = k % NSLOT
         if self.blur_passes:
-            dst = self.fin[s] if self.rank == 0 else self.out[s]
+            dst = self.fin[s] if (self.rank == 0 and self.host is None) else self.out[s]
             if self.fhalo[s]:
                 H = self.fhalo[s]
                 a0 = self.y0 - H if self.rank > 0 else 0
@@ -185,6 +210,8 @@ class TiledFrames:
                 self.backend.blur_rows_bounded(self.y0, self.y1, self.pre[s], self.z[s], dst, a0, a1, self.missw[s])
             else:
                 self.backend.blur_rows(self.y0, self.y1, self.pre[s], self.z[s], dst)
+        if self.host is not None:
+            self._copy_strip_to_host(s)
 
     # ---- pwn_tiled_submit ---------------------------------------------------------------------
     def submit(self, cam, sec=0.0):
@@ -194,7 +221,7 @@ class TiledFrames:
         s = f % NSLOT
         self.fhalo[s] = self.halo
         cam = np.ascontiguousarray(cam, np.float32).reshape(16)
-        plane = self.pre[s] if self.blur_passes else (self.fin[s] if self.rank == 0 else self.pre[s])
+        plane = self.pre[s] if self.blur_passes else (self.fin[s] if (self.rank == 0 and self.host is None) else self.pre[s])
         self.backend.trace_rows(cam, float(sec), self.y0, self.y1, plane, self.z[s])
         self.missw[s].zero_()
         # the blur of the frames before this one (normally just f-1)
@@ -225,7 +252,8 @@ class TiledFrames:
     # ---- pwn_tiled_wait -------------------------------------------------------------------------
     def wait(self):
         """Oldest frame in flight, on every rank.  Returns (frame, redone): frame = the full frame
-        tensor on rank 0 (valid until three more frames were submitted), None elsewhere."""
+        tensor on rank 0 (valid until three more frames were submitted), None elsewhere; with a host
+        sink the frame in the shared host memory, on every rank."""
         if self.delivered >= self.submitted:
             raise RuntimeError("nothing in flight")
         d = self.delivered
@@ -254,13 +282,17 @@ class TiledFrames:
             self._begin()
             self._add_allgather(s)
             self._end()
-            dst = self.fin[s] if self.rank == 0 else self.out[s]
+            dst = self.fin[s] if (self.rank == 0 and self.host is None) else self.out[s]
             self.backend.blur_rows(self.y0, self.y1, self.pre[s], self.z[s], dst)
+            if self.host is not None:
+                self._copy_strip_to_host(s)            # the strip again, and the words behind it
             self._begin()
             self._add_gather(d)
             self._end()
         self.delivered = d + 1
         self.info["frames"] += 1
+        if self.host is not None:
+            return self.host[s], miss                  # on every rank (valid until the second next wait)
         return (self.fin[s] if self.rank == 0 else None), miss
 
     def to_host(self, t):

@@ -237,7 +237,8 @@ class Renderer:
 
     def tiled_wait(self, host=False):
         """Oldest frame in flight.  Rank 0: dict with d_sbuf (device pointer) and, with host=True,
-        sbuf (numpy view of the pinned copy); other ranks: dict without them."""
+        sbuf (numpy view of the pinned copy); other ranks: dict without them.  With a host sink
+        (tiled_host_sink) every rank gets sbuf, a view of the frame in the shared host memory."""
         fr = _lib.TiledFrame()
         self._chk(lib.pwn_tiled_wait(self._ctx, _lib.PWN_TILED_HOST if host else 0, C.byref(fr)), "pwn_tiled_wait")
         out = {"seq": fr.seq, "redone": bool(fr.redone), "d_sbuf": fr.d_sbuf, "timed": bool(fr.timed),
@@ -245,6 +246,13 @@ class Renderer:
         if fr.sbuf:
             out["sbuf"] = np.ctypeslib.as_array(C.cast(fr.sbuf, C.POINTER(C.c_uint32)), shape=(self.w * self.h,)).reshape(self.h, self.w)
         return out
+
+    def tiled_host_sink(self, buf):
+        """Deliver frames to the host from every rank: `buf` is writable host memory for PWN_TILED_SLOTS whole
+        frames (a numpy array, an mmap of POSIX shared memory ...), the same memory in every rank."""
+        arr = np.frombuffer(buf, np.uint8)
+        self._host_sink = (buf, arr)                      # keep it mapped for as long as the context lives
+        self._chk(lib.pwn_tiled_host_sink(self._ctx, arr.ctypes.data, arr.size), "pwn_tiled_host_sink")
 
     def tiled_info(self):
         inf = _lib.TiledInfo()

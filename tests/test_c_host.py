@@ -124,6 +124,17 @@ def test_host_row_tiled_over_three_processes(host_bin, tmp_path):
     assert "rank 2 of 3: rows [240,360)" in outs[2]
     sa = re.search(r"surface fnv64 ([0-9a-f]{16})", a.stdout.decode()).group(1)
     assert re.search(r"surface fnv64 ([0-9a-f]{16})", outs[0]).group(1) == sa
+    # -M 1: every rank copies its strip into one frame in POSIX shared memory (pwn_tiled_host_sink); every rank
+    # then sees every whole frame
+    idfile = str(tmp_path / "group2.id")
+    procs = [subprocess.Popen(base + ["-W", "3", "-R", str(r), "-I", idfile, "-T", "shm", "-M", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(3)]
+    for r, p in enumerate(procs):
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e.decode()
+        assert re.findall(r"frame (\d+) sec \S+ fnv64 ([0-9a-f]{16})", o.decode()) == fa, r
+        if r == 0:
+            assert re.search(r"surface fnv64 ([0-9a-f]{16})", o.decode()).group(1) == sa
 
 
 @pytest.mark.gpu

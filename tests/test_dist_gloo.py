@@ -62,7 +62,7 @@ class OracleStripBackend:
         self.o.L.pwno_blur_rows(self.w, self.h, y0, y1, 1, pre.data_ptr(), z.data_ptr(), out.data_ptr())
 
 
-def _worker(rank, world, port, w, h, level, frames, blur, halo, q):
+def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=None):
     import sys
     sys.path.insert(0, HERE)
     sys.path.insert(0, ROOT)
@@ -78,13 +78,20 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q):
         base = load_spheres(key)
         be = OracleStripBackend(w, h, level_path(level), base)
         _, _, spawn = be.o.get_level()
-        fr = TiledFrames(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur, halo_rows=halo)
+        sink = None
+        if sink_path is not None:
+            # pwn_tiled_host_sink: one file mapped by every rank plays the shared host memory
+            sink = np.memmap(sink_path, dtype=np.uint32, mode="r+", shape=(4, h, w))
+        fr = TiledFrames(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur, halo_rows=halo, host_sink=sink)
         assert (fr.y0, fr.y1) == strip_range(h, world, rank)
         halo0 = fr.halo
         got = []
 
         def deliver(k):
             frame, redone = fr.wait()
+            if sink is not None:
+                got.append((oracle.fnv64(np.array(frame)), redone))        # every rank sees the whole frame
+                return
             assert (frame is not None) == (rank == 0)
             got.append((oracle.fnv64(fr.to_host(frame)) if rank == 0 else None, redone))
         for k in range(frames):
@@ -109,11 +116,11 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q):
         dist.destroy_process_group()
 
 
-def _run(world, w, h, level, frames, blur, halo):
+def _run(world, w, h, level, frames, blur, halo, sink_path=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, level, frames, blur, halo, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, level, frames, blur, halo, q, sink_path)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -191,3 +198,27 @@ def test_strip_geometry():
     assert [strip_range(2160, 8, r) for r in (0, 6, 7)] == [(0, 272), (1632, 1904), (1904, 2160)]
     assert strip_range(100, 3, 2) == (80, 100) and strip_range(16, 4, 3) == (16, 16)
     assert default_halo(2160) == 105 and default_halo(4320) == 209 and default_halo(240) == 13
+
+
+@pytest.mark.parametrize("world,blur,halo", [(2, 1, -1), (3, 1, 1), (8, 1, -1), (3, 0, -1)])
+def test_host_sink_delivers_whole_frames_to_every_rank(world, blur, halo, tmp_path):
+    """pwn_tiled_host_sink restated: no gather; every rank copies its strip into one frame that all ranks have
+    mapped, a word per pair of ranks follows the copy, and a delivered frame is whole on EVERY rank."""
+    w, h, frames = 320, 240, 5
+    path = str(tmp_path / "frames.bin")
+    np.zeros((4, h, w), np.uint32).tofile(path)
+    want = _want(w, h, "pwnfps_level", frames + 1, blur)
+    res = _run(world, w, h, "pwnfps_level", frames, blur, halo, sink_path=path)
+    redone = [g[1] for g in res[0][0]]
+    for r in range(world):
+        g, h0, h1, info = res[r]
+        assert [x[0] for x in g] == want, r
+        assert [x[1] for x in g] == redone
+        assert info["bytes_to_host"] > 0
+        # between ranks: halo rows (or whole pre-blur strips after a miss) and one word per pair -- never finished strips
+        if halo == -1 and blur:
+            assert info["bytes_sent"] <= (frames + 1) * (2 * 13 * w * 4 + 4 * (world - 1))
+        if blur == 0:
+            assert info["bytes_sent"] == (frames + 1) * 4 * (world - 1)
+    assert (sum(redone) > 0) == (halo == 1)
+

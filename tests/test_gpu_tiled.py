@@ -21,12 +21,14 @@ RANK = os.path.join(ROOT, "tools", "tiled_rank.py")
 _runs = [0]
 
 
-def run_ranks(world, w, h, level, frames, halo, tmp_path, transport="shm", blur=None):
+def run_ranks(world, w, h, level, frames, halo, tmp_path, transport="shm", blur=None, hostsink=False, seen=None):
     _runs[0] += 1
     idfile = str(tmp_path / ("id_%d" % _runs[0]))          # a fresh file per run: the ranks wait for it to appear
     env = dict(os.environ)
     if blur is not None:
         env["TILED_BLUR"] = str(blur)
+    if hostsink:
+        env["TILED_HOSTSINK"] = "1"
     procs = [subprocess.Popen([sys.executable, RANK, str(r), str(world), idfile, transport, str(w), str(h), level, str(frames), str(halo)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
     outs = []
@@ -40,6 +42,8 @@ def run_ranks(world, w, h, level, frames, halo, tmp_path, transport="shm", blur=
         assert p.returncode == 0, e[-3000:]
         outs.append(o)
     hashes = re.findall(r"frame (\d+) fnv64 ([0-9a-f]{16}) redone (\d)", outs[0])
+    if seen is not None:                                  # host sink: what the other ranks saw in the shared frame
+        seen.extend([h for _, h in re.findall(r"seen (\d+) fnv64 ([0-9a-f]{16})", o)] for o in outs[1:])
     infos = [json.loads(re.search(r"info (\{.*\})", o).group(1)) for o in outs]
     return hashes, infos
 
@@ -170,3 +174,30 @@ def test_eight_strip_geometry_single_process(name, oracle_lib, cases):
     if c["level"] == "pwnfps_level":
         assert (misses == 0).all()
     r.close()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_tiled_host_sink(world, tmp_path, oracle_lib):
+    """pwn_tiled_host_sink: every rank copies its strip into ONE frame in POSIX shared memory, no gather; when a
+    rank's wait returns, the whole frame is there -- on every rank.  Default halo, whole strips, and a 1-row halo
+    that is missed (the frame is repeated and copied again)."""
+    w, h, frames = 640, 360, 6
+    want = oracle_hashes(w, h, "pwnfps_level", frames, oracle_lib)
+    for halo in (-1, 0, 1):
+        seen = []
+        hashes, infos = run_ranks(world, w, h, "pwnfps_level", frames, halo, tmp_path, hostsink=True, seen=seen)
+        assert [x[1] for x in hashes] == want, (world, halo)
+        assert all(sv == want for sv in seen), (world, halo)
+        assert all(i["host_sink"] == 1 for i in infos)
+        redone = infos[0]["frames_redone"]
+        assert (redone > 0) == (world > 1 and halo == 1)
+        for i in infos:
+            assert i["bytes_to_host"] == (frames + i["frames_redone"]) * (i["y1"] - i["y0"]) * w * 4
+            # nothing but halo rows, whole pre-blur strips after a miss, and one word per pair travels between ranks
+            if world > 1 and halo == -1:
+                assert i["bytes_sent"] <= frames * 2 * (int(0.002 * h * 24) + 2) * w * 4
+    # no blur: the traced strips go straight to the host
+    want0 = oracle_hashes(w, h, "pwnfps_level", 3, oracle_lib, blur=0)
+    hashes, infos = run_ranks(world, w, h, "pwnfps_level", 3, -1, tmp_path, blur=0, hostsink=True)
+    assert [x[1] for x in hashes] == want0
+

@@ -8,7 +8,8 @@ Rank 0 creates the group id and writes it to IDFILE (.tmp + rename); the others 
 file.  Every frame has its own camera, sec_current and sphere set (tools/tiled_rank.scene), so a
 frame that is delivered late or from the wrong buffers shows.  Rank 0 prints one line per frame:
     frame K fnv64 HASH redone R
-and every rank a line `info {...}` (pwn_tiled_info)."""
+and every rank a line `info {...}` (pwn_tiled_info).  TILED_HOSTSINK=1: frames are delivered into POSIX shared
+memory by every rank (pwn_tiled_host_sink); the other ranks then print `seen K fnv64 HASH` too."""
 import json
 import os
 import sys
@@ -31,6 +32,10 @@ def scene(k, base, spawn):
     if k % 3 == 1:
         sph = sph[:max(1, len(sph) - 2)]
     return pwnfps_amd.spawn_camera(spawn, ang_y=0.21 * k, ang_x=0.03 * k), 0.1 * k, sph
+
+
+def shm_path(idfile):
+    return "/dev/shm/pwn_frames_" + os.path.basename(idfile) + "_%d" % os.getppid()
 
 
 def main():
@@ -60,13 +65,28 @@ def main():
                 sys.exit("rank %d: no id file" % rank)
             time.sleep(0.01)
         uid = open(idfile, "rb").read()
+    hostsink = os.environ.get("TILED_HOSTSINK") == "1"
+    if hostsink and rank == 0:
+        # the frames' host memory: POSIX shared memory that every rank maps (created before the id file appears)
+        with open(shm_path(idfile), "wb") as f:
+            f.truncate(4 * w * h * 4)
     r.tiled_init(rank, world, uid, transport, halo)
+    mm = None
+    if hostsink:
+        import mmap
+        fd = os.open(shm_path(idfile), os.O_RDWR)
+        mm = mmap.mmap(fd, 4 * w * h * 4)
+        os.close(fd)
+        r.tiled_host_sink(mm)
 
     def deliver(k):
         fr = r.tiled_wait(host=True)
         assert fr["seq"] == k + 1
         if rank == 0:
             print("frame %d fnv64 %s redone %d" % (k, oracle.fnv64(fr["sbuf"]), int(fr["redone"])), flush=True)
+        elif hostsink:
+            # with a host sink every rank holds the whole frame when its wait returns
+            print("seen %d fnv64 %s" % (k, oracle.fnv64(fr["sbuf"])), flush=True)
     for k in range(frames):
         cam, sec, sph = scene(k, base, spawn)
         r.set_objects(sph)
@@ -78,6 +98,13 @@ def main():
     print("info " + json.dumps(r.tiled_info()), flush=True)
     r.tiled_shutdown()
     r.close()
+    if mm is not None:                       # (the mapping itself goes with the process: views of it are still alive)
+        if rank == 0:
+            time.sleep(0.5)
+            try:
+                os.unlink(shm_path(idfile))
+            except OSError:
+                pass
 
 
 if __name__ == "__main__":
