@@ -415,7 +415,14 @@ def main():
         frames_mm = mmap.mmap(fd, _lib_slots() * 4 * w * h)
         os.close(fd)
         r.tiled_init(rank, world, uid2[0], transport, args.halo)
-        r.tiled_host_sink(frames_mm)
+        sink_err = None
+        try:
+            r.tiled_host_sink(frames_mm)
+        except Exception as e:                                       # noqa: BLE001 -- reported in the line
+            sink_err = "rank %d: %s" % (rank, e)
+        ok = torch.tensor([0.0 if sink_err else 1.0], dtype=torch.float64)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        sink_ok = float(ok.item()) == 1.0                            # every rank takes the same branch
         held = {"f": None}
 
         def host_block(n):
@@ -430,27 +437,30 @@ def main():
                 held["f"] = r.tiled_wait()
             barrier()
             return max_over_ranks(time.perf_counter() - t1)
-        host_block(args.warmup)
-        host_s = []
-        while True:
-            host_s.append(host_block(args.steps))
-            if sum(host_s) >= args.min_time or len(host_s) >= 500:
-                break
-        host_dt = float(np.median(host_s))
-        hinfo = r.tiled_info()
-        host_ok = None
-        if rank == 0 and oracle is not None and frame_hash is not None:
-            host_ok = bool(oracle.fnv64(held["f"]["sbuf"]) == frame_hash)
-        pcie = {"value": round(w * h * args.steps / host_dt / 1e6, 3), "unit": "Mpixels/s",
-                "ms_per_step": round(host_dt / args.steps * 1e3, 4), "frames_in_flight": 3,
-                "blocks": len(host_s), "block_ms_p10_p50_p90": [round(float(np.percentile(host_s, q)) * 1e3, 3) for q in (10, 50, 90)],
-                "bytes_over_pcie_per_frame_and_rank": int(hinfo["bytes_to_host"] // max(hinfo["frames"] + hinfo["frames_redone"], 1)),
-                "pcie_links": world,
-                "host_frame_gbs": round(4 * w * h * args.steps / host_dt / 1e9, 2),
-                "frames_repeated_with_whole_strips": int(max_over_ranks(float(hinfo["frames_redone"]))),
-                "last_frame_equals_resident_frame": host_ok,
-                "what": "pwn_tiled_host_sink: set_objects + pwn_tiled_submit / pwn_tiled_wait; every rank copies its finished strip "
-                        "into one frame in POSIX shared memory over its own PCIe link, no gather to rank 0"}
+        if not sink_ok:
+            pcie = {"value": None, "error": sink_err or "pwn_tiled_host_sink failed on another rank"}
+        else:
+            host_block(args.warmup)
+            host_s = []
+            while True:
+                host_s.append(host_block(args.steps))
+                if sum(host_s) >= args.min_time or len(host_s) >= 500:
+                    break
+            host_dt = float(np.median(host_s))
+            hinfo = r.tiled_info()
+            host_ok = None
+            if rank == 0 and oracle is not None and frame_hash is not None:
+                host_ok = bool(oracle.fnv64(held["f"]["sbuf"]) == frame_hash)
+            pcie = {"value": round(w * h * args.steps / host_dt / 1e6, 3), "unit": "Mpixels/s",
+                    "ms_per_step": round(host_dt / args.steps * 1e3, 4), "frames_in_flight": 3,
+                    "blocks": len(host_s), "block_ms_p10_p50_p90": [round(float(np.percentile(host_s, q)) * 1e3, 3) for q in (10, 50, 90)],
+                    "bytes_over_pcie_per_frame_and_rank": int(hinfo["bytes_to_host"] // max(hinfo["frames"] + hinfo["frames_redone"], 1)),
+                    "pcie_links": world,
+                    "host_frame_gbs": round(4 * w * h * args.steps / host_dt / 1e9, 2),
+                    "frames_repeated_with_whole_strips": int(max_over_ranks(float(hinfo["frames_redone"]))),
+                    "last_frame_equals_resident_frame": host_ok,
+                    "what": "pwn_tiled_host_sink: set_objects + pwn_tiled_submit / pwn_tiled_wait; every rank copies its finished strip "
+                            "into one frame in POSIX shared memory over its own PCIe link, no gather to rank 0"}
         barrier()
         held["f"] = None
         r.tiled_shutdown()

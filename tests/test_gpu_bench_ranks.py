@@ -46,3 +46,7 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     assert t["transport"] == "shm" and t["frames_redone"] == 0 and t["halo_rows"] > 0
     assert d["config"]["frames_repeated_with_whole_strips"] == 0
     assert d["roofline"]["pixels_per_launch"] == t["rows_per_rank"] * size[0]
+    # the host-delivered leg (pwn_tiled_host_sink): every rank's strip into one shared frame, hashed against the resident one
+    hs = d["d2h_inclusive"]
+    assert hs["value"] > 0 and hs["pcie_links"] == world and hs["last_frame_equals_resident_frame"] is True
+    assert hs["bytes_over_pcie_per_frame_and_rank"] == t["rows_per_rank"] * size[0] * 4
