@@ -258,7 +258,7 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
  *                        frame over its own PCIe link (N links, not rank 0's one) and there is no gather to rank
  *                        0: the grouped exchange carries the halo rows and one word per rank, sent behind that
  *                        rank's copy, so that a frame is delivered when every strip has landed.  pwn_tiled_wait
- *                        then gives out->sbuf on EVERY rank (valid until the second next pwn_tiled_wait),
+ *                        then gives out->sbuf on EVERY rank (valid until the second next pwn_tiled_submit),
  *                        out->d_sbuf is NULL.
  *   pwn_tiled_shutdown   collective; pwn_destroy does it too.
  * PWN_TRANSPORT_SHM moves the same messages through POSIX shared memory instead: for tests

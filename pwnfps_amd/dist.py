@@ -292,7 +292,7 @@ class TiledFrames:
         self.delivered = d + 1
         self.info["frames"] += 1
         if self.host is not None:
-            return self.host[s], miss                  # on every rank (valid until the second next wait)
+            return self.host[s], miss                  # on every rank (valid until the second next submit)
         return (self.fin[s] if self.rank == 0 else None), miss
 
     def to_host(self, t):
