@@ -236,7 +236,7 @@ struct pwn_tiled
 	hipEvent_t ev_k0[NSLOT], ev_k1[NSLOT], ev_k2[NSLOT];      // timing (PWN_OPT_FRAME_TIMING): around the trace, behind the blur
 	hipEvent_t gathered_by[NSLOT];      // which of the above marks the slot's gather as done
 	// host sink: NSLOT whole frames in host memory shared by the ranks; this rank's copies on their own stream
-	uint8_t *host_base; bool host_registered;
+	uint8_t *host_base; void *host_registered;   // the frames; what this context registered with the device (or NULL)
 	hipStream_t copy;
 	hipEvent_t ev_h[NSLOT];             // behind the copy of the slot's strip into the host frame
 	bool timed[NSLOT];
@@ -295,7 +295,7 @@ void pwn_tiled_destroy(pwn_ctx *c)
 	}
 	for(int s = 0; s < NSLOT; s++) if(t->ev_h[s]) (void)hipEventDestroy(t->ev_h[s]);
 	if(t->copy) (void)hipStreamDestroy(t->copy);
-	if(t->host_registered) (void)hipHostUnregister(t->host_base);
+	if(t->host_registered) (void)hipHostUnregister(t->host_registered);
 	if(t->h_missv) (void)hipHostFree(t->h_missv);
 	if(t->h_frame) (void)hipHostFree(t->h_frame);
 	if(t->comm) (void)hipStreamDestroy(t->comm);
@@ -420,7 +420,7 @@ extern "C" int pwn_tiled_host_sink(pwn_ctx *c, void *base, size_t bytes)
 	// memory of the caller (shared between the rank processes): make it known to this device.  Already pinned by
 	// this process (hipHostMalloc in a one-process test) is fine too.
 	hipError_t e = hipHostRegister(base, frame * NSLOT, hipHostRegisterDefault);
-	if(e == hipSuccess) t->host_registered = true;
+	if(e == hipSuccess) t->host_registered = base;
 	else if(e == hipErrorHostMemoryAlreadyRegistered) (void)hipGetLastError();
 	else { snprintf(c->err, sizeof(c->err), "hipHostRegister: %s", hipGetErrorString(e)); return PWN_EHIP; }
 	if(hipStreamCreateWithFlags(&t->copy, hipStreamNonBlocking) != hipSuccess) return PWN_EHIP;
