@@ -209,7 +209,7 @@ static int pack_blob(pwn_ctx *c)
 		uint32_t cnt = (uint32_t)(c->bin_off[i + 1] - c->bin_off[i]);
 		if(cnt) nbin += cnt + 1u;
 	}
-	if(nbin > 32767u || nsph >= PWN_LIST_END) return PWN_ETOOBIG;
+	if(nbin > 32767u || nsph * 32u >= PWN_LIST_END) return PWN_ETOOBIG;      // list entries are byte offsets (index * 32) in 16 bits
 	uint32_t total = (pwn_t_total(nbin, nsph) + 15u) & ~15u;
 	if(total > PWN_BLOB_MAX) return PWN_ETOOBIG;
 	c->blob.assign(total, 0);        // (nothing has changed up to here: a failed call leaves the context as it was)
@@ -226,7 +226,7 @@ static int pack_blob(pwn_ctx *c)
 		if(k1 > k0)
 		{
 			word |= PWN_C_SPH | (at << 16);
-			for(int32_t k = k0; k < k1; k++) bi[at++] = (uint16_t)c->bin_idx[k];
+			for(int32_t k = k0; k < k1; k++) bi[at++] = (uint16_t)(c->bin_idx[k] * 32);
 			bi[at++] = (uint16_t)PWN_LIST_END;
 		}
 		ci[z * PWN_GRID_PITCH + x] = word;
@@ -246,7 +246,18 @@ static int pack_blob(pwn_ctx *c)
 		pm[2 * i + 1] = (uint32_t)(p.rot12 & 0xff) | ((uint32_t)(p.c1 & 0xff) << 8) | ((uint32_t)(p.c2 & 0xff) << 16);
 	}
 	c->off_sph = pwn_t_sph_offset(nbin);
-	if(nsph) memcpy(b + c->off_sph, c->spheres.data(), nsph * sizeof(pwn_sphere));
+	// the kernels' layout of a sphere (tables.h): position and r*r in one 16-byte half, the rest in the other
+	{
+		float *sp = (float *)(b + c->off_sph);
+		for(uint32_t i = 0; i < nsph; i++, sp += 8)
+		{
+			const pwn_sphere &q = c->spheres[i];
+			float r2 = q.r * q.r;                 // trace.h:262 `rad*rad`, one fp32 multiply
+			if(r2 < 1.17549435e-38f) r2 = 0.0f;   // ... whose result the device flushes like the reference build (FTZ)
+			sp[0] = q.x; sp[1] = q.y; sp[2] = q.z; sp[3] = r2;
+			sp[4] = q.refl; sp[5] = q.cb; sp[6] = q.cg; sp[7] = q.cr;
+		}
+	}
 
 	// Upload into the copy no launch in flight reads.  The rcp / rsqrt head of the blob never
 	// changes: once a copy has it, only [cellinfo, end) travels (cell words carry the sphere-list

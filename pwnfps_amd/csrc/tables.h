@@ -30,8 +30,11 @@
 //                       word0 = x1 | z1<<8 | x2<<16 | z2<<24   (0xff = -1)
 //                       word1 = rot12 | c1<<8 | c2<<16
 //   [25824  .. +2*nbin pad 16)  binidx u16        per-cell sphere lists (level.h:64-81),
-//                                                 object order, each list closed by 0xffff
-//   [...    .. +32*nsph)        spheres 8 x f32   r, refl, x, y, z, cb, cg, cr
+//                                                 object order, as BYTE offsets into the sphere
+//                                                 array (index * 32), each list closed by 0xffff
+//   [...    .. +32*nsph)        spheres 8 x f32   x, y, z, r*r | refl, cb, cg, cr: what a test reads is ONE 16-byte
+//                                                 load (r only ever enters as r*r, trace.h:262,270; the host squares it
+//                                                 in fp32 like the reference does)
 #pragma once
 #include <stdint.h>
 

@@ -166,15 +166,15 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 				else
 				{
 					// trace.h:283-291 for the committed sphere
-					const PWN_LDS pwn_f4 *sp = (const PWN_LDS pwn_f4 *)(L.sph + 8 * aux_idx);
+					const PWN_LDS pwn_f4 *sp = (const PWN_LDS pwn_f4 *)((const PWN_LDS unsigned char *)L.sph + aux_idx);      // (a byte offset)
 					const pwn_f4 s0 = sp[0], s1 = sp[1];
 					V d;
-					d.x = aux_pos.x - s0.z; d.y = aux_pos.y - s0.w; d.z = aux_pos.z - s1.x;
+					d.x = aux_pos.x - s0.x; d.y = aux_pos.y - s0.y; d.z = aux_pos.z - s0.z;
 					if constexpr(HAS_W) d.w = aux_pos.w - 1.0f; else d.w = 0.0f;
 					aux_norm = vnormalise<HAS_W>(L.rsq, d);
 					colx = aux_diff * s1.y; coly = aux_diff * s1.z; colz = aux_diff * s1.w;
 					w_acc = __builtin_fmaf(aux_diff, 0.0f, w_acc);
-					refl = s0.y;
+					refl = s1.x;
 					ldir = -1;
 					pos = aux_pos;
 				}
