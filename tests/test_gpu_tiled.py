@@ -201,3 +201,45 @@ def test_tiled_host_sink(world, tmp_path, oracle_lib):
     hashes, infos = run_ranks(world, w, h, "pwnfps_level", 3, -1, tmp_path, blur=0, hostsink=True)
     assert [x[1] for x in hashes] == want0
 
+
+def test_host_sink_argument_checks_and_one_rank(oracle_lib, cases):
+    """pwn_tiled_host_sink in one process (world 1, no transport traffic): a buffer that is too small, a second
+    sink, a sink after the first frame are refused; frames arrive in the caller's memory."""
+    import pwnfps_amd
+    from pwnfps_amd import _lib
+    from pwnfps_amd.render import PwnError
+    from conftest import load_spheres
+    c = [x for x in cases if x["name"] == "level_pose1_1280x720"][0]
+    w, h = c["w"], c["h"]
+    r = pwnfps_amd.Renderer(w, h)
+    r.level_load(level_path(c["level"]))
+    r.set_objects(load_spheres(c["spheres"]))
+    cam = np.array(c["cam"], np.float32)
+    r.tiled_init(0, 1, pwnfps_amd.Renderer.tiled_unique_id("shm"), "shm", -1)
+    small = np.zeros(w * h, np.uint32)
+    with pytest.raises(PwnError) as e:
+        r.tiled_host_sink(small)
+    assert e.value.code == -1                      # PWN_EINVAL: a sink holds PWN_TILED_SLOTS frames
+    frames = np.zeros((_lib.PWN_TILED_SLOTS, h, w), np.uint32)
+    r.tiled_host_sink(frames)
+    with pytest.raises(PwnError) as e:
+        r.tiled_host_sink(frames)
+    assert e.value.code == -8                      # PWN_EBUSY
+    for k in range(5):
+        r.tiled_submit(cam, c["sec"])
+        fr = r.tiled_wait()
+        assert fr["d_sbuf"] in (None, 0) and oracle_lib.fnv64(fr["sbuf"]) == c["post"]
+        # the frame IS the caller's memory: slot k mod 4
+        assert oracle_lib.fnv64(frames[k % _lib.PWN_TILED_SLOTS]) == c["post"]
+    assert r.tiled_info()["bytes_to_host"] == 5 * w * h * 4
+    r.tiled_shutdown()
+    # after a frame without a sink it is too late
+    r.tiled_init(0, 1, pwnfps_amd.Renderer.tiled_unique_id("shm"), "shm", -1)
+    r.tiled_submit(cam, c["sec"])
+    with pytest.raises(PwnError) as e:
+        r.tiled_host_sink(frames)
+    assert e.value.code == -8
+    r.tiled_wait()
+    r.tiled_shutdown()
+    r.close()
+
