@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) NAME(unsigned long long *out, float seed)
 	for(int it = 0; it < ITER; it++) \
 	{ \
 		asm volatile(ASMSTR ::: "v32","v33","v34","v35","v36","v37","v38","v39","v40","v41","v42","v43","v44","v45","v46","v47", \
-			"v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67"); \
+			"v48","v49","v50","v51","v52","v53","v54","v55","v56","v57","v58","v59","v60","v61","v62","v63","v64","v65","v66","v67","s4","s5","vcc","scc"); \
 	} \
 	unsigned long long t1 = __builtin_amdgcn_s_memtime(); \
 	unsigned long long q1 = __builtin_amdgcn_s_memrealtime(); \
@@ -108,6 +108,10 @@ KERNEL(k_f64_fma,   "v_fma_f64 v[32:33], v[64:65], v[66:67], v[64:65]\nv_fma_f64
 	"v_fma_f64 v[40:41], v[64:65], v[66:67], v[64:65]\nv_fma_f64 v[42:43], v[64:65], v[66:67], v[64:65]\nv_fma_f64 v[44:45], v[64:65], v[66:67], v[64:65]\nv_fma_f64 v[46:47], v[64:65], v[66:67], v[64:65]\n" \
 	"v_fma_f64 v[48:49], v[64:65], v[66:67], v[64:65]\nv_fma_f64 v[50:51], v[64:65], v[66:67], v[64:65]\nv_fma_f64 v[52:53], v[64:65], v[66:67], v[64:65]\nv_fma_f64 v[54:55], v[64:65], v[66:67], v[64:65]\n" \
 	"v_fma_f64 v[56:57], v[64:65], v[66:67], v[64:65]\nv_fma_f64 v[58:59], v[64:65], v[66:67], v[64:65]\nv_fma_f64 v[60:61], v[64:65], v[66:67], v[64:65]\nv_fma_f64 v[62:63], v[64:65], v[66:67], v[64:65]\n")
+KERNEL_PK(k_mad_u64, "v_mad_u64_u32 v[32:33], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[34:35], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[36:37], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[38:39], s[4:5], v64, v66, v[64:65]\n" \
+	"v_mad_u64_u32 v[40:41], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[42:43], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[44:45], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[46:47], s[4:5], v64, v66, v[64:65]\n" \
+	"v_mad_u64_u32 v[48:49], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[50:51], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[52:53], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[54:55], s[4:5], v64, v66, v[64:65]\n" \
+	"v_mad_u64_u32 v[56:57], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[58:59], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[60:61], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[62:63], s[4:5], v64, v66, v[64:65]\n")
 KERNEL(k_max_f32,   ASM16("v_max_f32 ", ", %16, %17"))
 KERNEL(k_cvt,       ASM16("v_cvt_f32_i32 ", ", %16"))
 KERNEL(k_mul_lo,    ASM16("v_mul_lo_u32 ", ", %16, %17"))
@@ -177,7 +181,7 @@ int main(int argc, char **argv)
 	unsigned long long *d; hipMalloc(&d, 8 * (ncu * 32 + 1));
 #define R(n) if(only == NULL || strcmp(only, #n) == 0) run<16>(#n, k_##n, d, ncu)
 	R(add_f32); R(mul_f32); R(fma_f32); R(add_u32); R(and_b32); R(lshl); R(bfe); R(mov); R(cndmask); R(cndmask64);
-	R(pk_add_f32); R(pk_mul_f32); R(pk_fma_f32); R(min3_f32); R(med3_i32); R(xor_b32); R(sub_f32); R(lshl_add); R(pk_add_u16); R(dot2_u16); R(bitop3); R(add_dpp); R(cmp_u32); R(f64_fma);
+	R(mad_u64); R(pk_add_f32); R(pk_mul_f32); R(pk_fma_f32); R(min3_f32); R(med3_i32); R(xor_b32); R(sub_f32); R(lshl_add); R(pk_add_u16); R(dot2_u16); R(bitop3); R(add_dpp); R(cmp_u32); R(f64_fma);
 	R(cmp); R(cmp_e64); R(max_f32); R(cvt); R(mul_lo); R(mul_hi); R(mad_u32); R(add3); R(rcp); R(sqrt); R(salu); R(salu64);
 	R(cmpcnd); R(ifblock);
 	if(only == NULL || strcmp(only, "mix_vs") == 0) run<16>("mix_vs(8v+8s)", k_mix_vs, d, ncu);
