@@ -30,9 +30,9 @@ struct pwn_blur_params
 
 __device__ __forceinline__ uint32_t avg_u8x4(uint32_t a, uint32_t b)
 {
-	// _mm_avg_epu8: per byte (p + q + 1) >> 1, without inter-byte carries:
-	// (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7f)
-	return (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7fu);
+	// _mm_avg_epu8: per byte (p + q + 1) >> 1 -- which is what v_lerp_u8 computes with a round bit of 1 in
+	// every byte of its third operand (one instruction; as (a | b) - (((a ^ b) >> 1) & 0x7f7f7f7f) it was five)
+	return __builtin_amdgcn_lerp(a, b, 0x01010101u);
 }
 
 // screen.h:101-106: a tap coordinate goes float -> int with cvttss2si (INT_MIN for NaN and for anything
