@@ -1,3 +1,6 @@
+# The randomised parity campaign that closes a round: generic and lattice scenes, the forced 4-lane variant, the
+# refill scheduler, large frames -- new seeds, 17 240 scenes, ~14 GPU-minutes.
+#   gpurun -- bash tools/fuzz_campaign.sh      -> gpurun_out/fuzz2/*.txt, one summary line per leg on stdout
 mkdir -p gpurun_out/fuzz2
 run() { tag=$1; shift; "$@" > gpurun_out/fuzz2/$tag.txt 2>&1; echo "$tag: $(tail -1 gpurun_out/fuzz2/$tag.txt)"; }
 run g9101 python tools/fuzz_parity.py 3000 9101
