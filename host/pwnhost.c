@@ -28,6 +28,7 @@
  * obj_new / obj_set / obj_free / level_get act on the library's object table (script.h:1-103).
  * -t fixes the clock step (the reference uses wall time, main.c:112-114), which
  * makes a run reproducible; -v 1 prints every frame's hash.
+ * -W WORLD alone row-tiles every frame over WORLD processes that this one forks (rank r on device r);
  * -W WORLD -R RANK -I IDFILE [-T rccl|shm] row-tiles every frame over WORLD processes, one per
  * GPU (pwn_tiled_*: RCCL inside the library): start the same command once per rank with its
  * -R (and -d DEVICE); rank 0 writes the group id to IDFILE, the others wait for it; rank 0
@@ -51,6 +52,7 @@
 #include <unistd.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 
 #include "pwnhip.h"
 #include "game_script.h"
@@ -174,6 +176,7 @@ int main(int argc, char **argv)
 	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL, *luafile = NULL, *keyfile = NULL;
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
 	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL, window = 0, frames_given = 0, hostsink = 0;
+	int rank_given = 0, device_given = 0;
 	const char *idfile = NULL;
 	float turn = 0.0f, fixed_dt = -1.0f;
 	for(int i = 1; i < argc; i++)
@@ -197,10 +200,10 @@ int main(int argc, char **argv)
 			case 'p': pitch = atoi(argv[++i]); break;
 			case 'b': blur = atoi(argv[++i]); break;
 			case 'o': out = argv[++i]; break;
-			case 'd': device = atoi(argv[++i]); break;
+			case 'd': device = atoi(argv[++i]); device_given = 1; break;
 			case 'q': slots = atoi(argv[++i]); break;
 			case 'W': world = atoi(argv[++i]); break;
-			case 'R': rank = atoi(argv[++i]); break;
+			case 'R': rank = atoi(argv[++i]); rank_given = 1; break;
 			case 'I': idfile = argv[++i]; break;
 			case 'H': halo = atoi(argv[++i]); break;
 			case 'M': hostsink = atoi(argv[++i]); break;
@@ -215,9 +218,27 @@ int main(int argc, char **argv)
 			"       [-W WORLD -R RANK -I IDFILE [-T rccl|shm] [-H HALO_ROWS]]\n");
 		return 2;
 	}
+	/* -W WORLD without -R: this process starts the other ranks itself (fork, before anything touches a GPU): rank r
+	   on device r (-d DEVICE: all on that one, for boxes with one GPU and -T shm), the id in a file of its own */
+	pid_t kids[64];
+	int nkids = 0;
+	char idbuf[64];
+	if(world > 1 && !rank_given)
+	{
+		if(world > 64) { fprintf(stderr, "-W takes at most 64 ranks\n"); return 2; }
+		if(idfile == NULL) { snprintf(idbuf, sizeof(idbuf), "/tmp/pwnhost_%d.id", (int)getpid()); idfile = idbuf; unlink(idfile); }
+		for(int r = 1; r < world && rank == 0; r++)
+		{
+			pid_t k = fork();
+			if(k < 0) { perror("fork"); return 1; }
+			if(k == 0) { rank = r; nkids = 0; }
+			else kids[nkids++] = k;
+		}
+		if(!device_given) device = rank;
+	}
 	if(world < 1 || rank < 0 || rank >= world || (world > 1 && idfile == NULL))
 	{
-		fprintf(stderr, "-W WORLD needs -R RANK (0..WORLD-1) and -I IDFILE\n");
+		fprintf(stderr, "-W WORLD: either alone (the ranks are forked), or with -R RANK (0..WORLD-1) and -I IDFILE once per rank\n");
 		return 2;
 	}
 	if(slots != 0 && (slots < 2 || slots > PWN_MAX_SLOTS)) { fprintf(stderr, "-q takes 2..%d\n", PWN_MAX_SLOTS); return 2; }
@@ -412,7 +433,15 @@ int main(int argc, char **argv)
 			if(rank == 0) shm_unlink(shm_name);
 		}
 		free(sph); free(sbuf); free(zbuf); free(surface.pixels);
-		return 0;
+		/* the ranks this process started */
+		int bad = 0;
+		for(int i = 0; i < nkids; i++)
+		{
+			int st = 0;
+			if(waitpid(kids[i], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+		}
+		if(nkids > 0 && idfile == idbuf) unlink(idfile);
+		return bad;
 	}
 	if(slots > 0)
 	{

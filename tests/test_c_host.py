@@ -137,6 +137,14 @@ def test_host_row_tiled_over_three_processes(host_bin, tmp_path):
             assert re.search(r"surface fnv64 ([0-9a-f]{16})", o.decode()).group(1) == sa
 
 
+    # -W 3 alone: the host forks the ranks itself (all on device 0 here)
+    p = subprocess.run(base[:-2] + ["-W", "3", "-d", "0", "-T", "shm", "-M", "1"], capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    o = p.stdout.decode()
+    assert re.search(r"surface fnv64 ([0-9a-f]{16})", o).group(1) == sa
+    assert all(("rank %d of 3" % r) in o for r in range(3))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["blocking", "in_flight"])
 def test_host_interactive_walk_every_frame_is_the_oracles(host_bin, mode, oracle_lib):
