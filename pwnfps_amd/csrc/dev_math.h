@@ -141,10 +141,29 @@ __device__ __forceinline__ uint32_t ftoint_lane(float f)
 	i = min(max(i, 0), 255);
 	return (s < 2147483648.0f) ? (uint32_t)i : 0u;
 }
-__device__ __forceinline__ uint32_t col_pack(v4 c)
+// The four lanes of a colour at once.  v_cvt_pk_u8_f32 (round to nearest even, clamp to [0,255], insert as byte k) IS
+// that chain for every fp32 input except s >= 2^31 and +inf, where it gives 255 and the reference's "integer
+// indefinite" ends as 0: exhaustive over all 2^32 bit patterns, tools/ubench/cvt_pk_u8.hip.  Those are patched in
+// behind one wave-uniform branch (v_max ignores a NaN lane, which both forms send to 0).
+__device__ __forceinline__ uint32_t col_pack4(float x, float y, float z, float w)
 {
-	return ftoint_lane(c.x) | (ftoint_lane(c.y) << 8) | (ftoint_lane(c.z) << 16) | (ftoint_lane(c.w) << 24);
+	const float sx = x * 255.0f, sy = y * 255.0f, sz = z * 255.0f, sw = w * 255.0f;
+	uint32_t pk = 0u;
+	asm("v_cvt_pk_u8_f32 %0, %1, 0, %0" : "+v"(pk) : "v"(sx));
+	asm("v_cvt_pk_u8_f32 %0, %1, 1, %0" : "+v"(pk) : "v"(sy));
+	asm("v_cvt_pk_u8_f32 %0, %1, 2, %0" : "+v"(pk) : "v"(sz));
+	asm("v_cvt_pk_u8_f32 %0, %1, 3, %0" : "+v"(pk) : "v"(sw));
+	const bool over = fmaxf(fmaxf(sx, sy), fmaxf(sz, sw)) >= 2147483648.0f;
+	if(__builtin_expect(__ballot(over) != 0ull, 0))
+	{
+		if(sx >= 2147483648.0f) pk &= ~0x000000ffu;
+		if(sy >= 2147483648.0f) pk &= ~0x0000ff00u;
+		if(sz >= 2147483648.0f) pk &= ~0x00ff0000u;
+		if(sw >= 2147483648.0f) pk &= ~0xff000000u;
+	}
+	return pk;
 }
+__device__ __forceinline__ uint32_t col_pack(v4 c) { return col_pack4(c.x, c.y, c.z, c.w); }
 
 // ---- glibc 2.35 sinf / cosf ------------------------------------------------
 // Published algorithm of sysdeps/ieee754/flt-32/s_sincosf.h (ARM optimized

@@ -433,7 +433,7 @@ pwn_trace_kernel(pwn_trace_params P)
 			float ox, oy, oz, ow;
 			const size_t o = (size_t)y * (size_t)P.w + (size_t)x;
 			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
-			P.sbuf[o] = ftoint_lane(ox) | (ftoint_lane(oy) << 8) | (ftoint_lane(oz) << 16) | (ftoint_lane(ow) << 24);
+			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
 		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
 	}

@@ -244,7 +244,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 					}
 				}
 				// screen.h:22 (col_ftoint, util.h:48-59)
-				P.sbuf[o] = ftoint_lane(vx) | (ftoint_lane(vy) << 8) | (ftoint_lane(vz) << 16) | (ftoint_lane(vw + w_acc) << 24);
+				P.sbuf[o] = col_pack4(vx, vy, vz, vw + w_acc);
 				ev = EV_IDLE;
 			}
 		}

@@ -101,8 +101,20 @@ def test_sqrt_and_divide_are_ieee(R):
     assert (got[ok] == want.view(np.uint32)[ok]).all()
 
 
-def test_ftoint_randfs_kat(R):
+def test_ftoint_randfs_kat(R, oracle_lib):
     from pwnfps_amd import _lib
     k = np.load(os.path.join(GOLD, "helpers_kat.npz"))
     assert (R.probe(_lib.PROBE_FTOINT, _f(k["col_in"]).ravel()) == k["col_out"]).all()
+    # the pack is v_cvt_pk_u8_f32 + a wave-uniform patch for s >= 2^31 (dev_math.h col_pack4): batches with and
+    # without such lanes, ties, NaN, infinities, against the oracle's restatement of util.h:48-59
+    L = oracle_lib.lib()
+    rng = np.random.default_rng(5)
+    tame = np.concatenate([rng.uniform(-0.5, 1.5, (4096, 4)), (rng.integers(-3, 260, (2048, 4)) + 0.5) / 255.0,
+                           rng.standard_normal((2048, 4)) * 40]).astype(np.float32)
+    wild = tame.copy()
+    idx = rng.integers(0, wild.size, 3000)
+    wild.reshape(-1)[idx] = rng.choice(np.array([np.nan, np.inf, -np.inf, 8.5e6, 8421505.0, 8421504.0, 1e30, -1e30, 3e38, 2.0 ** 23], np.float32), len(idx))
+    for batch in (tame, wild):
+        want = np.array([L.pwno_col_ftoint(np.ascontiguousarray(v).ctypes.data) for v in batch], np.uint32)
+        assert (R.probe(_lib.PROBE_FTOINT, batch.ravel()) == want).all()
     assert (R.probe(_lib.PROBE_RANDFS, k["seeds"]) == k["randfs"].view(np.uint32)).all()
