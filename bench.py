@@ -9,9 +9,9 @@ reference's level.txt scene (its 14 game.lua spheres, camera at the spawn
 pose, sec_current = 0) at 3840x2160 with the post-process blur on, i.e. one
 level_prepare_render() + trace_screen_centred() (main.c:95,107; screen.h:31-124).  With N > 1 the frame is row-tiled
 behind the C ABI (pwn_tiled_*, pwnfps_amd/csrc/pwn_tiled.cpp): rank r traces rows
-[r*per, (r+1)*per), one grouped RCCL send/recv launch per frame carries this frame's
-pre-blur halo rows between neighbour strips and the finished strips of the frame two
-back to rank 0, each rank blurs its strip; three frames are in flight.  Level/sphere
+[r*per, (r+1)*per), two grouped RCCL send/recv launches per frame carry the finished strips
+of the frame two back to rank 0 and this frame's pre-blur halo rows between neighbour
+strips, each rank blurs its strip; three frames are in flight.  Level/sphere
 tables and all frame buffers are resident in HBM before the timed region; in the
 timed region of `value` the frame stays on the device (rank 0's for N > 1).  The rate with every frame handed over to the host (what
 trace_screen_centred does with sbuf, main.c:107) is measured in the same run
@@ -477,7 +477,7 @@ def main():
             strip_pix, par = pix, "rows/1, %d frames in flight" % nres
         else:
             strip_pix = (tinfo["y1"] - tinfo["y0"]) * w
-            par = "rows/%d, one grouped %s send/recv per frame (%s + gather of the strips of the frame two back), 3 frames in flight" % (
+            par = "rows/%d, two grouped %s send/recv launches per frame (%s; the gather of the strips of the frame two back), 3 frames in flight" % (
                 world, transport.upper(), ("%d halo rows per neighbour" % tinfo["halo_rows"]) if tinfo["halo_rows"] else "whole pre-blur strips to every rank")
         achieved = TRACE_BYTES_PER_PIXEL * strip_pix / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         line = {

@@ -230,7 +230,7 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
 
 /*
  * Row tiling behind the ABI: the choreography of the strip forms with the exchange done by
- * the library -- RCCL over xGMI, one grouped ncclSend/ncclRecv launch per frame.  One
+ * the library -- RCCL over xGMI, two grouped ncclSend/ncclRecv launches per frame.  One
  * process per GPU, each with its own context of the FULL frame size; every rank makes the
  * same calls in the same order (level and sphere uploads included: tables are per rank).
  *   pwn_tiled_unique_id  rank 0: the id of the group (an ncclUniqueId for PWN_TRANSPORT_RCCL);
@@ -244,9 +244,10 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
  *                        whole strips are used from then on: delivered frames are always exact.
  *                        POSTPROC_BLUR 0 or 1.
  *   pwn_tiled_submit     enqueue one frame on every rank: trace own strip, blur the previous frame's
- *                        strip, ONE grouped exchange (this frame's halo rows + the finished strips of
- *                        the frame two back to rank 0 + its miss words).  At most three frames in
- *                        flight (PWN_EBUSY): a frame then costs max(kernels, exchange), not their sum.
+ *                        strip, two grouped exchanges (the finished strips of the frame two back to rank 0
+ *                        with its miss words; then this frame's halo rows).  At most three frames in
+ *                        flight (PWN_EBUSY): a frame then costs max(kernels, exchange), not their sum, and
+ *                        waiting for frame f-2 right after submitting f does not wait for f's trace.
  *   pwn_tiled_wait       every rank: block until the oldest frame in flight is complete; on rank 0
  *                        out->d_sbuf is the full frame on the device (valid until three more frames
  *                        were submitted) and, with PWN_TILED_HOST, out->sbuf a pinned host copy.

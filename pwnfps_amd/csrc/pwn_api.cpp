@@ -69,6 +69,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	}
 	for(int i = 0; i < PWN_NSTAGE; i++) { c->h_stage[i] = NULL; c->ev_stage[i] = NULL; c->stage_used[i] = false; }
 	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0;
+	c->trace_clear_word = NULL;
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 8; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
 	c->stream = NULL; c->copy_stream = NULL;
@@ -500,6 +501,8 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 {
 	if(!c->have_level) return PWN_ENOLEVEL;
 	if(c->blob_dirty) { int rc = pack_blob(c); if(rc != PWN_OK) return rc; }
+	uint32_t *clear_word = c->trace_clear_word;            // for this launch only
+	c->trace_clear_word = NULL;
 	if(y1 == y0) return PWN_OK;
 	pwn_trace_params P;
 	memset(&P, 0, sizeof(P));
@@ -522,6 +525,7 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 		else HIPCHK(c, hipStreamWaitEvent(stream, c->ev_upload[cur], 0));
 	}
 	P.counters = c->d_counters;
+	P.clear_word = clear_word;
 	// PWN_OPT_WAVE_LOG: every wave of this launch writes its start and end time (at most 8 blocks of 4 waves per CU)
 	P.wave_log = NULL;
 	if(c->wave_log_on)

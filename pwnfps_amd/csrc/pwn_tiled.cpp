@@ -7,20 +7,24 @@
 // (screen.h:100-102), unbounded in depth.  Per submitted frame f (slot s = f mod 4) a rank enqueues
 //
 //   compute stream   trace strip f -> pre[s], z[s]
-//   comm stream      ONE grouped exchange G(f), a single RCCL launch, behind that trace:
-//                      - the H border rows of strip f to / from the neighbour strips, straight out
-//                        of / into the full-frame plane pre[s] (or, without a halo, every strip to
-//                        everybody: an all-gather by send / recv)
-//                      - the FINISHED strip of frame f-2 to rank 0   (the gather)
-//                      - the miss word of frame f-2 to every rank    (see below)
-//   compute stream   blur strip f-1 from pre rows [y0-H, y1+H) -> out, behind G(f-1); taps outside
-//                    those rows are counted in the rank's miss word of that frame
+//   comm stream      TWO grouped exchanges, each a single RCCL launch:
+//                      G2(f-2), behind blur f-2 only: the FINISHED strip of frame f-2 to rank 0 (the gather) and its
+//                               miss word to every rank (see below)
+//                      G1(f), behind that trace: the H border rows of strip f to / from the neighbour strips,
+//                               straight out of / into the full-frame plane pre[s] (or, without a halo, every
+//                               strip to everybody: an all-gather by send / recv)
+//   compute stream   blur strip f-1 from pre rows [y0-H, y1+H) -> out, behind G1(f-1); taps outside those rows are
+//                    counted in the rank's miss word of that frame
 //
-// The blur of a frame is enqueued one submit late, BEHIND the next frame's trace, so the compute
-// stream does not sit waiting for the exchange: G(f) is on the wire while trace f+1 and blur f-1 run,
-// and a frame costs max(kernels, exchange), not their sum.  Frame f is complete on rank 0 when
-// G(f+2) is (pwn_tiled_wait enqueues the outstanding blur and a group with only the second half
-// when no newer frames were submitted); at most three frames are in flight, four buffer sets.
+// The blur of a frame is enqueued one submit late, BEHIND the next frame's trace, so the compute stream does not
+// sit waiting for the exchange: G1(f) is on the wire while trace f+1 and blur f-1 run, and a frame costs
+// max(kernels, exchange), not their sum.  The gather is a group of its own, in front of G1(f), so that it does not
+// wait for trace f: the host that collects frame f-2 after submitting f has it while trace f still runs and is back
+// with frame f+1's launches before the GPU is idle.  (As ONE group per frame -- the first form -- every delivery
+// waited for the newest trace and the host's enqueue time, 40-60 us per frame, was added to every frame: 108 -> 90
+// us per frame on one GPU with frames so small that nothing else counts.)  Frame f is complete on rank 0 when
+// G2(f) is (pwn_tiled_wait enqueues the outstanding blur and that group itself when no newer frames were
+// submitted); at most three frames are in flight, four buffer sets.
 // Every rank then holds every rank's miss word of frame f: if one is non-zero the bounded halo was
 // not enough for that frame and ALL ranks, having the same words, repeat its exchange with whole
 // strips, its blur and its gather before it is delivered, and use whole strips from then on.  A
@@ -554,10 +558,10 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	uint32_t *plane = c->blur_passes ? t->pre[s] : ((t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->pre[s]);
 	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
+	c->trace_clear_word = t->missw[s];           // the frame's miss word is cleared by its trace launch (no memset between the kernels)
 	int rc = pwn_i_launch_trace(c, cam, sec, t->y0, t->y1, plane, t->z[s], cs);
 	if(rc != PWN_OK) return rc;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
-	HIPCHK(c, hipMemsetAsync(t->missw[s], 0, 4, cs));
 	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
 
 	// ---- the blur of the frames before this one, behind this frame's trace (normally just f-1)
@@ -567,46 +571,58 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 		if(rc != PWN_OK) return rc;
 	}
 
-	// ---- G(f) on the comm stream: this frame's pre-blur rows, and the gather of what is blurred and
-	// not gathered yet except the newest blur (its kernel was enqueued a moment ago: next group), i.e.
-	// normally of frame f-2
-	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
+	// ---- on the comm stream, two grouped launches.  First the second half of the frames that are blurred and not
+	// gathered yet except the newest blur (its kernel was enqueued a moment ago: next time), i.e. normally of
+	// frame f-2: it waits for that frame's blur only, NOT for the trace enqueued above -- a host that waits for
+	// frame f-2 after this call gets it while trace f runs, and is back with frame f+1 before the GPU is idle.
+	// (As ONE group with the halo rows below, which need trace f, every delivery waited for the newest trace:
+	// the host's enqueue time, ~40-60 us per frame, was added to every frame instead of hidden.)
 	const unsigned long long g_end = f >= 1 ? f - 1 : 0;        // gather frames [gathered, g_end)
-	for(unsigned long long g = t->gathered; g < g_end; g++)
+	if(g_end > t->gathered)
 	{
-		HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
-		if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));       // the word goes out behind the copy
+		for(unsigned long long g = t->gathered; g < g_end; g++)
+		{
+			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
+			if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));       // the word goes out behind the copy
+		}
+		if(t->world > 1)
+		{
+			TPCHK(c, t->tp->begin(t->comm));
+			for(unsigned long long g = t->gathered; g < g_end; g++) { rc = add_gather(c, t, g); if(rc != PWN_OK) return rc; }
+			TPCHK(c, t->tp->end());
+			t->info.groups++;
+		}
+		hipEvent_t done = t->ev_d[(g_end - 1) % NSLOT];
+		HIPCHK(c, hipEventRecord(done, t->comm));
+		for(unsigned long long g = t->gathered; g < g_end; g++) t->gathered_by[g % NSLOT] = done;
+		t->gathered = g_end;
 	}
-	if(t->world > 1)
+	// ---- then this frame's pre-blur rows, behind its trace
+	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
+	if(t->world > 1 && c->blur_passes)
 	{
 		TPCHK(c, t->tp->begin(t->comm));
-		if(c->blur_passes)
+		if(t->halo)
 		{
-			if(t->halo)
+			const int H = t->halo;
+			if(t->rank > 0)
 			{
-				const int H = t->halo;
-				if(t->rank > 0)
-				{
-					TPCHK(c, t->tp->send(t->pre[s] + (size_t)t->y0 * c->w, (size_t)H * w4, t->rank - 1));
-					TPCHK(c, t->tp->recv(t->pre[s] + (size_t)(t->y0 - H) * c->w, (size_t)H * w4, t->rank - 1));
-					t->info.bytes_sent += (unsigned long long)H * w4; t->info.bytes_received += (unsigned long long)H * w4;
-				}
-				if(t->rank < t->world - 1 && t->y1 < c->h)
-				{
-					TPCHK(c, t->tp->send(t->pre[s] + (size_t)(t->y1 - H) * c->w, (size_t)H * w4, t->rank + 1));
-					TPCHK(c, t->tp->recv(t->pre[s] + (size_t)t->y1 * c->w, (size_t)H * w4, t->rank + 1));
-					t->info.bytes_sent += (unsigned long long)H * w4; t->info.bytes_received += (unsigned long long)H * w4;
-				}
+				TPCHK(c, t->tp->send(t->pre[s] + (size_t)t->y0 * c->w, (size_t)H * w4, t->rank - 1));
+				TPCHK(c, t->tp->recv(t->pre[s] + (size_t)(t->y0 - H) * c->w, (size_t)H * w4, t->rank - 1));
+				t->info.bytes_sent += (unsigned long long)H * w4; t->info.bytes_received += (unsigned long long)H * w4;
 			}
-			else { rc = add_allgather(c, t, s); if(rc != PWN_OK) return rc; }
+			if(t->rank < t->world - 1 && t->y1 < c->h)
+			{
+				TPCHK(c, t->tp->send(t->pre[s] + (size_t)(t->y1 - H) * c->w, (size_t)H * w4, t->rank + 1));
+				TPCHK(c, t->tp->recv(t->pre[s] + (size_t)t->y1 * c->w, (size_t)H * w4, t->rank + 1));
+				t->info.bytes_sent += (unsigned long long)H * w4; t->info.bytes_received += (unsigned long long)H * w4;
+			}
 		}
-		for(unsigned long long g = t->gathered; g < g_end; g++) { rc = add_gather(c, t, g); if(rc != PWN_OK) return rc; }
+		else { rc = add_allgather(c, t, s); if(rc != PWN_OK) return rc; }
 		TPCHK(c, t->tp->end());
 		t->info.groups++;
 	}
 	HIPCHK(c, hipEventRecord(t->ev_x[s], t->comm));
-	for(unsigned long long g = t->gathered; g < g_end; g++) t->gathered_by[g % NSLOT] = t->ev_x[s];
-	if(g_end > t->gathered) t->gathered = g_end;
 	t->submitted = f + 1;
 	return PWN_OK;
 }

@@ -144,6 +144,8 @@ struct pwn_trace_params
 	// work queues of the wave scheduler (trace_kernel.hip): PWN_QUEUES counters, one per 128 B,
 	// for this launch; the set of the next launch, which this one clears
 	uint32_t *tickets, *tickets_next;
+	uint32_t *clear_word;                     // NULL, or a word this launch sets to 0 (the row tiling's miss word of the frame:
+	                                          // the blur of the same frame, behind this launch on the stream, counts in it)
 };
 
 #ifndef PWN_QUEUES

@@ -316,6 +316,7 @@ pwn_trace_kernel(pwn_trace_params P)
 	const uint32_t units_x = ((uint32_t)P.w + 15u) >> 4;
 	const uint32_t units = units_x * (((uint32_t)(P.y1 - P.y0) + 3u) >> 2);
 	if(blockIdx.x == 0 && threadIdx.x < PWN_QUEUES) P.tickets_next[threadIdx.x * PWN_QUEUE_STRIDE] = 0u;
+	if(blockIdx.x == 0 && threadIdx.x == PWN_QUEUES && P.clear_word != NULL) *P.clear_word = 0u;
 	uint32_t q = (blockIdx.x * (PWN_BLOCK / 64) + (uint32_t)wave) % PWN_QUEUES;
 	uint32_t ticket;
 	{

@@ -79,6 +79,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 	const uint32_t rows_u = ((uint32_t)(P.y1 - P.y0) + 3u) >> 2;
 	const uint32_t units = units_x * rows_u;
 	if(blockIdx.x == 0 && threadIdx.x < PWN_QUEUES) P.tickets_next[threadIdx.x * PWN_QUEUE_STRIDE] = 0u;
+	if(blockIdx.x == 0 && threadIdx.x == PWN_QUEUES && P.clear_word != NULL) *P.clear_word = 0u;
 	uint32_t q = (blockIdx.x * (PWN_BLOCK / 64) + (uint32_t)wave) % PWN_QUEUES;
 	uint32_t ticket_v = 0;                 // lane 0: the ticket drawn ahead for queue q
 	if(lane == 0) ticket_v = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], 1u);

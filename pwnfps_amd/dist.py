@@ -24,16 +24,15 @@ trace pass needs no exchange.  The blur does: its taps reach 0.002*h*(depth-1) r
     trace strip f -> pre[s], z[s]
     blur strip f-1 from pre rows [y0-H, y1+H) -> out (behind the group that brought its halo rows);
         taps outside those rows are counted in the rank's miss word of that frame
-    ONE grouped exchange G(f):
-        the H border rows of strip f to / from the neighbour strips (or, without a halo,
-            every strip to everybody)
-        the FINISHED strip of frame f-2 to rank 0
-        the miss word of frame f-2 to every rank
+    two grouped exchanges:
+        G2(f-2): the FINISHED strip of frame f-2 to rank 0 and its miss word to every rank (behind blur f-2 only)
+        G1(f):   the H border rows of strip f to / from the neighbour strips (or, without a halo,
+                 every strip to everybody), behind trace f
 
 (In the C code the blur of a frame sits behind the next frame's trace on the compute stream so
 that the stream never waits for the exchange; here everything is synchronous and only the order
-matters.)  Frame f is complete on rank 0 when G(f+2) is (``wait`` enqueues the outstanding blur and
-a group with only the second half when no newer frames were submitted); three frames in flight at
+matters.)  Frame f is complete on rank 0 when G2(f) is, which rides with submit f+2 (``wait`` enqueues the outstanding blur
+and that group itself when no newer frames were submitted); three frames in flight at
 most.  Every rank then holds every rank's miss word of frame f: if one is non-zero ALL ranks repeat
 that frame's exchange with whole strips, its blur and its gather before it is delivered, and use
 whole strips from then on.
@@ -228,25 +227,29 @@ class TiledFrames:
         while self.blurred < f:
             self._enqueue_blur(self.blurred)
             self.blurred += 1
-        # G(f): this frame's pre-blur rows, and the gather of what is blurred except the newest blur
+        # two groups, like pwn_tiled_submit: first the gather of what is blurred except the newest blur (it does not
+        # depend on this frame's trace), then this frame's pre-blur rows
         g_end = f - 1 if f >= 1 else 0
-        if self.world > 1:
+        if g_end > self.gathered:
+            if self.world > 1:
+                self._begin()
+                for g in range(self.gathered, g_end):
+                    self._add_gather(g)
+                self._end()
+            self.gathered = g_end
+        if self.world > 1 and self.blur_passes:
             self._begin()
-            if self.blur_passes:
-                if self.halo:
-                    H = self.halo
-                    if self.rank > 0:
-                        self._send(self.pre[s][self.y0:self.y0 + H], self.rank - 1, TAG_HALO)
-                        self._recv(self.pre[s][self.y0 - H:self.y0], self.rank - 1, TAG_HALO)
-                    if self.rank < self.world - 1 and self.y1 < self.h:
-                        self._send(self.pre[s][self.y1 - H:self.y1], self.rank + 1, TAG_HALO)
-                        self._recv(self.pre[s][self.y1:self.y1 + H], self.rank + 1, TAG_HALO)
-                else:
-                    self._add_allgather(s)
-            for g in range(self.gathered, g_end):
-                self._add_gather(g)
+            if self.halo:
+                H = self.halo
+                if self.rank > 0:
+                    self._send(self.pre[s][self.y0:self.y0 + H], self.rank - 1, TAG_HALO)
+                    self._recv(self.pre[s][self.y0 - H:self.y0], self.rank - 1, TAG_HALO)
+                if self.rank < self.world - 1 and self.y1 < self.h:
+                    self._send(self.pre[s][self.y1 - H:self.y1], self.rank + 1, TAG_HALO)
+                    self._recv(self.pre[s][self.y1:self.y1 + H], self.rank + 1, TAG_HALO)
+            else:
+                self._add_allgather(s)
             self._end()
-        self.gathered = max(self.gathered, g_end)
         self.submitted = f + 1
 
     # ---- pwn_tiled_wait -------------------------------------------------------------------------

@@ -84,8 +84,8 @@ def test_tiled_frames_are_the_oracles_frames(world, tmp_path, oracle_lib):
             assert all(i["halo_rows"] == 0 for i in infos)
         if world > 1 and halo == -1:
             assert all(i["halo_rows"] == int(0.002 * h * 24) + 2 for i in infos)
-            # one grouped exchange per frame plus two that drain the last two frames
-            assert all(i["groups"] == frames + 2 for i in infos)
+            # two grouped launches per frame: its halo rows, and (two frames later, or when the run drains) its gather
+            assert all(i["groups"] == 2 * frames for i in infos)
 
 
 def test_tiled_without_blur_and_uneven_strips(tmp_path, oracle_lib):
