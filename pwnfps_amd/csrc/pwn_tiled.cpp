@@ -232,7 +232,7 @@ struct pwn_tiled
 	hipStream_t comm;
 	uint32_t *pre[NSLOT], *out[NSLOT], *fin[NSLOT]; float *z[NSLOT];     // full-frame planes per frame slot (fin: rank 0)
 	uint32_t *missw[NSLOT], *missv[NSLOT];   // this rank's miss word of the slot's frame; every rank's (world words)
-	uint32_t *h_missv;                  // pinned
+	uint32_t *h_missv;                  // pinned: per slot, every rank's miss word of the slot's frame (world words) and then this rank's own
 	uint32_t *h_frame;                  // pinned host copy of a delivered frame (rank 0, PWN_TILED_HOST)
 	// per slot: behind the frame's trace; behind the group G(f) it opened; behind its blur; behind the
 	// group that carried its gather (that is G(f+2)'s event or the drain group's)
@@ -385,7 +385,8 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 			   hipEventCreate(&t->ev_k2[s]) != hipSuccess) { rc = PWN_EHIP; break; }
 		}
 		if(rc != PWN_OK) break;
-		if(hipHostMalloc((void **)&t->h_missv, (size_t)world * 4 + 64, hipHostMallocDefault) != hipSuccess) { rc = PWN_ENOMEM; break; }
+		if(hipHostMalloc((void **)&t->h_missv, (size_t)NSLOT * ((size_t)world + 1) * 4, hipHostMallocDefault) != hipSuccess) { rc = PWN_ENOMEM; break; }
+		memset(t->h_missv, 0, (size_t)NSLOT * ((size_t)world + 1) * 4);
 		// one round trip through the transport before the first frame depends on it: every rank sends a
 		// word to its right-hand neighbour (to itself when alone) and checks what arrives from the left
 		{
@@ -485,6 +486,18 @@ static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 			TPCHK(c, t->tp->send(t->missw[s], 4, r));
 			TPCHK(c, t->tp->recv(t->missv[s] + r, 4, r));
 		}
+	return PWN_OK;
+}
+
+// behind a group that carried frame g's words: bring them (and this rank's own) to pinned host memory on the comm
+// stream, so that pwn_tiled_wait reads them there instead of making two blocking copies per frame
+static int fetch_words(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
+{
+	const int s = (int)(g % NSLOT);
+	if(!t->fhalo[s]) return PWN_OK;
+	uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1);
+	HIPCHK(c, hipMemcpyAsync(h, t->missv[s], (size_t)t->world * 4, hipMemcpyDeviceToHost, t->comm));
+	HIPCHK(c, hipMemcpyAsync(h + t->world, t->missw[s], 4, hipMemcpyDeviceToHost, t->comm));
 	return PWN_OK;
 }
 
@@ -592,6 +605,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 			TPCHK(c, t->tp->end());
 			t->info.groups++;
 		}
+		for(unsigned long long g = t->gathered; g < g_end; g++) { rc = fetch_words(c, t, g); if(rc != PWN_OK) return rc; }
 		hipEvent_t done = t->ev_d[(g_end - 1) % NSLOT];
 		HIPCHK(c, hipEventRecord(done, t->comm));
 		for(unsigned long long g = t->gathered; g < g_end; g++) t->gathered_by[g % NSLOT] = done;
@@ -657,6 +671,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 			TPCHK(c, t->tp->end());
 			t->info.groups++;
 		}
+		for(unsigned long long g = t->gathered; g <= d; g++) { rc = fetch_words(c, t, g); if(rc != PWN_OK) return rc; }
 		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
 		for(unsigned long long g = t->gathered; g <= d; g++) t->gathered_by[g % NSLOT] = t->ev_d[s];
 		t->gathered = d + 1;
@@ -669,11 +684,9 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	bool miss = false;
 	if(t->fhalo[s])
 	{
-		HIPCHK(c, hipMemcpy(t->h_missv, t->missv[s], (size_t)t->world * 4, hipMemcpyDeviceToHost));
-		uint32_t own = 0;
-		HIPCHK(c, hipMemcpy(&own, t->missw[s], 4, hipMemcpyDeviceToHost));
-		t->h_missv[t->rank] = own;
-		for(int r = 0; r < t->world; r++) miss = miss || t->h_missv[r] != 0;
+		// (the words came to pinned memory behind the group that carried them: fetch_words)
+		const uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1);
+		for(int r = 0; r < t->world; r++) miss = miss || (r == t->rank ? h[t->world] : h[r]) != 0;
 	}
 	if(miss)
 	{
