@@ -56,7 +56,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	pwn_ctx *c = new(std::nothrow) pwn_ctx();
 	if(c == NULL) return PWN_ENOMEM;
 	c->device = device; c->w = width; c->h = height;
-	c->blur_passes = 1; c->counters_on = 0; c->scheduler = PWN_SCHED_DEFAULT; c->refill_limit = PWN_REFILL_LIMIT_DEFAULT; c->have_level = false;
+	c->blur_passes = 1; c->counters_on = 0; c->scheduler = PWN_SCHED_DEFAULT; c->refill_limit = PWN_REFILL_LIMIT_DEFAULT; c->have_level = false; c->cell_base_ok = false;
 	// experiments and the test suite pick the trace scheduler for every context of a process
 	if(const char *e = getenv("PWN_SCHEDULER")) c->scheduler = (strcmp(e, "refill") == 0 || strcmp(e, "1") == 0) ? PWN_SCHED_REFILL : PWN_SCHED_UNITS;
 	if(const char *e = getenv("PWN_REFILL_LIMIT")) { int v = atoi(e); if(v >= 1 && v <= 64000) c->refill_limit = v; }
@@ -217,25 +217,33 @@ static int pack_blob(pwn_ctx *c)
 	uint8_t *b = c->blob.data();
 	uint32_t *ci = (uint32_t *)(b + PWN_T_CELLINFO);
 	uint16_t *bi = (uint16_t *)(b + PWN_T_BINIDX);
-	uint32_t at = 0;
-	for(int z = 0; z < 64; z++)
-	for(int x = 0; x < 64; x++)
+	// the level's part of the cell words (char + class bits) is the same until the level changes: built once,
+	// copied per upload and patched where a cell has spheres
+	if(!c->cell_base_ok)
 	{
-		int i = z * 64 + x;
-		uint32_t word = (uint32_t)c->cells[i] | pwn_cell_class(c->cells[i]);
+		uint32_t *cb = c->cell_base;
+		memset(cb, 0, sizeof(c->cell_base));
+		for(int z = 0; z < 64; z++)
+		for(int x = 0; x < 64; x++)
+			cb[z * PWN_GRID_PITCH + x] = (uint32_t)c->cells[z * 64 + x] | pwn_cell_class(c->cells[z * 64 + x]);
+		// row / column 64 = what get_cell returns outside the grid on that axis (util.h:151-158),
+		// never with spheres (the sphere loop runs for in-grid cells only, trace.h:252)
+		for(int z = 0; z < 64; z++) cb[z * PWN_GRID_PITCH + 64] = cb[z * PWN_GRID_PITCH];
+		for(int x = 0; x <= 64; x++) cb[64 * PWN_GRID_PITCH + x] = cb[x];
+		c->cell_base_ok = true;
+	}
+	memcpy(ci, c->cell_base, sizeof(c->cell_base));
+	uint32_t at = 0;
+	for(int i = 0; i < 4096; i++)
+	{
 		int32_t k0 = c->bin_off[i], k1 = c->bin_off[i + 1];
 		if(k1 > k0)
 		{
-			word |= PWN_C_SPH | (at << 16);
+			ci[(i >> 6) * PWN_GRID_PITCH + (i & 63)] |= PWN_C_SPH | (at << 16);
 			for(int32_t k = k0; k < k1; k++) bi[at++] = (uint16_t)(c->bin_idx[k] * 32);
 			bi[at++] = (uint16_t)PWN_LIST_END;
 		}
-		ci[z * PWN_GRID_PITCH + x] = word;
 	}
-	// row / column 64 = what get_cell returns outside the grid on that axis (util.h:151-158),
-	// never with spheres (the sphere loop runs for in-grid cells only, trace.h:252)
-	for(int z = 0; z < 64; z++) ci[z * PWN_GRID_PITCH + 64] = ci[z * PWN_GRID_PITCH] & ~(PWN_C_SPH | 0x7fff0000u);
-	for(int x = 0; x <= 64; x++) ci[64 * PWN_GRID_PITCH + x] = ci[x] & ~(PWN_C_SPH | 0x7fff0000u);
 	memcpy(b + PWN_T_RCP, c->tabs, 4096);
 	memcpy(b + PWN_T_RSQ, c->tabs + 2048, 4096);
 	pwn_fill_faces((float *)(b + PWN_T_FACES));
@@ -300,6 +308,7 @@ extern "C" int pwn_upload_level(pwn_ctx *c, const uint8_t data[4096], const pwn_
 	memcpy(c->cells, data, 4096);
 	memcpy(c->pmap, pmap, sizeof(c->pmap));
 	c->have_level = true;
+	c->cell_base_ok = false;
 	c->blob_dirty = true;
 	return pack_blob(c);
 }
@@ -310,6 +319,7 @@ extern "C" int pwn_level_load_mem(pwn_ctx *c, const char *text, int len)
 	(void)hipSetDevice(c->device);
 	if(pwn_parse_level(text, len, c->cells, c->pmap, c->spawn) != 0) return PWN_EINVAL;
 	c->have_level = true;
+	c->cell_base_ok = false;
 	c->blob_dirty = true;
 	return pack_blob(c);
 }

@@ -62,6 +62,8 @@ struct pwn_ctx
 	bool have_level;
 
 	uint8_t cells[4096];
+	uint32_t cell_base[65 * 65];      // the level's part of every cell word (char + class bits; row / column 64 = the clamp copies): built
+	bool cell_base_ok;               // by pack_blob when the level changed, patched per upload with the cells' sphere lists
 	pwn_portal pmap[26];
 	int32_t spawn[2];
 	std::vector<pwn_sphere> spheres;          // the live spheres the current lists index
