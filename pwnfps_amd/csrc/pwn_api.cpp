@@ -69,7 +69,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	}
 	for(int i = 0; i < PWN_NSTAGE; i++) { c->h_stage[i] = NULL; c->ev_stage[i] = NULL; c->stage_used[i] = false; }
 	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0;
-	c->trace_clear_word = NULL;
+	c->trace_clear_word = NULL; c->grid_reserve = 0;
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 8; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
 	c->stream = NULL; c->copy_stream = NULL;
@@ -581,6 +581,10 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	if(per_cu < 1) per_cu = 1;
 	if(const char *cap = getenv("PWN_DBG_BLOCKS_PER_CU")) { if(atoi(cap) > 0) per_cu = atoi(cap); }   // experiments
 	int grid = c->num_cus * per_cu;
+	// row tiling over RCCL: a persistent grid that fills every CU leaves RCCL's send / recv kernels no registers
+	// to start with (5 waves x 96 VGPRs of 512 per SIMD), and the exchange would only run in the gaps between the
+	// kernels; a few workgroups fewer leave room on some CUs (pwn_tiled.cpp sets the number)
+	if(c->grid_reserve > 0 && grid > 2 * c->grid_reserve) grid -= c->grid_reserve;
 	if(grid > P.tiles_total) grid = P.tiles_total;
 	if(refill) HIPCHK(c, pwn_launch_trace_refill(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	else HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));

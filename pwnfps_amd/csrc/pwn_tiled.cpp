@@ -305,6 +305,7 @@ void pwn_tiled_destroy(pwn_ctx *c)
 	if(t->comm) (void)hipStreamDestroy(t->comm);
 	delete t;
 	c->tiled = NULL;
+	c->grid_reserve = 0;
 }
 
 extern "C" void pwn_tiled_shutdown(pwn_ctx *c) { if(c != NULL) pwn_tiled_destroy(c); }
@@ -409,6 +410,15 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 		}
 	} while(0);
 	if(rc != PWN_OK) { char keep[256]; memcpy(keep, c->err, sizeof(keep)); pwn_tiled_destroy(c); memcpy(c->err, keep, sizeof(keep)); return rc; }
+	// Room for RCCL's kernels beside the persistent trace grid (pwn_api.cpp): 16 workgroups of ~1280, i.e. one less
+	// on 16 CUs, 1.25 % of the grid.  Not measurable without several GPUs; PWN_TILED_RESERVE=n overrides it
+	// (0 = fill every CU) for the sweep that the first multi-GPU run should make.
+	c->grid_reserve = 0;
+	if(world > 1 && transport == PWN_TRANSPORT_RCCL)
+	{
+		c->grid_reserve = 16;
+		if(const char *e = getenv("PWN_TILED_RESERVE")) { int v = atoi(e); if(v >= 0 && v <= 512) c->grid_reserve = v; }
+	}
 	t->info.rank = rank; t->info.world = world; t->info.y0 = t->y0; t->info.y1 = t->y1; t->info.rows_per_rank = t->per;
 	t->info.halo_rows = t->halo; t->info.transport = transport;
 	return PWN_OK;
