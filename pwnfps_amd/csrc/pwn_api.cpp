@@ -60,6 +60,11 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	// experiments and the test suite pick the trace scheduler for every context of a process
 	if(const char *e = getenv("PWN_SCHEDULER")) c->scheduler = (strcmp(e, "refill") == 0 || strcmp(e, "1") == 0) ? PWN_SCHED_REFILL : PWN_SCHED_UNITS;
 	if(const char *e = getenv("PWN_REFILL_LIMIT")) { int v = atoi(e); if(v >= 1 && v <= 64000) c->refill_limit = v; }
+	// test / experiment hooks, read once: every camera through the general 4-lane variant (tests/test_gpu_fuzz.py);
+	// workgroups per CU of the persistent grid
+	c->dbg_force_hasw = getenv("PWN_DBG_FORCE_HASW") != NULL;
+	c->dbg_blocks_per_cu = 0;
+	if(const char *e = getenv("PWN_DBG_BLOCKS_PER_CU")) { int v = atoi(e); if(v > 0) c->dbg_blocks_per_cu = v; }
 	c->blob_cur = 0; c->blob_dirty = true; c->off_sph = 0; c->stage_next = 0; c->up_stream = NULL;
 	for(int i = 0; i < PWN_NBLOB; i++)
 	{
@@ -554,7 +559,7 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	// 3-lane specialisation for them that is arithmetically identical
 	P.has_w = !(cam[3] == 0.0f && cam[7] == 0.0f && cam[11] == 0.0f && cam[15] == 1.0f);
 	// test hook (tests/test_gpu_fuzz.py): send every camera through the general variant
-	if(getenv("PWN_DBG_FORCE_HASW")) P.has_w = 1;
+	if(c->dbg_force_hasw) P.has_w = 1;
 	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), stream));
 	// persistent grid: as many workgroups as are resident at once, each striding over tiles
 	const bool refill = c->scheduler == PWN_SCHED_REFILL;
@@ -579,7 +584,7 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 		if(per_cu > lds_fit) per_cu = lds_fit;
 	}
 	if(per_cu < 1) per_cu = 1;
-	if(const char *cap = getenv("PWN_DBG_BLOCKS_PER_CU")) { if(atoi(cap) > 0) per_cu = atoi(cap); }   // experiments
+	if(c->dbg_blocks_per_cu > 0) per_cu = c->dbg_blocks_per_cu;                                      // experiments
 	int grid = c->num_cus * per_cu;
 	// row tiling over RCCL: a persistent grid that fills every CU leaves RCCL's send / recv kernels no registers
 	// to start with (5 waves x 96 VGPRs of 512 per SIMD), and the exchange would only run in the gaps between the

@@ -91,6 +91,7 @@ struct pwn_ctx
 	uint2 *d_skip;                   // blur LCG skip-ahead, w/4 entries
 	unsigned long long *d_counters;
 	unsigned long long *d_wave_log; int wave_log_on;   // PWN_OPT_WAVE_LOG
+	bool dbg_force_hasw; int dbg_blocks_per_cu;      // PWN_DBG_* hooks, read at pwn_init
 	int grid_reserve;                // workgroups the persistent trace grid leaves free (row tiling over RCCL), else 0
 	uint32_t *trace_clear_word;      // set by a caller of pwn_i_launch_trace for its next launch: see pwn_trace_params.clear_word
 	uint32_t *d_tickets; unsigned ticket_set;  // two sets of work-queue counters of the trace kernel, used alternately

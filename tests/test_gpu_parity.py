@@ -85,7 +85,7 @@ def test_golden_cases_through_the_general_four_lane_variant(oracle_lib, cases, m
     """The goldens' cameras carry no w components and take the 3-lane specialisation.  The general (HAS_W)
     kernel variants are only reached by unusual cameras -- and were the ones with the layout-dependent
     miscompile of round 1 (dev_math.h) -- so the fixed goldens are also rendered through them
-    (PWN_DBG_FORCE_HASW, read at every launch): both schedulers, sizes up to 4K."""
+    (PWN_DBG_FORCE_HASW, read when a context is created): both schedulers, sizes up to 4K."""
     monkeypatch.setenv("PWN_DBG_FORCE_HASW", "1")
     import pwnfps_amd
     names = ("level_spawn_320x240", "level_pose1_1280x720", "synth64_cam0_1920x1080", "level_spawn_3840x2160", "synth256_cam1_480x272")
