@@ -50,3 +50,29 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     hs = d["d2h_inclusive"]
     assert hs["value"] > 0 and hs["pcie_links"] == world and hs["last_frame_equals_resident_frame"] is True
     assert hs["bytes_over_pcie_per_frame_and_rank"] == t["rows_per_rank"] * size[0] * 4
+
+
+def test_bench_line_on_one_gpu():
+    """The contract of the one-GPU line (the driver's BENCH run): one JSON line with the metric, the roofline object of
+    the dominant kernel, the D2H-inclusive leg and the work counters; the last frame is the golden frame."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--min-time", "0.2",
+           "--width", "1280", "--height", "720", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["value"] > 0 and d["unit"] == "Mpixels/s"
+    assert abs(d["value"] - 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6
+    assert abs(rf["achieved"] - 8 * 1280 * 720 / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 0.02 * rf["achieved"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["frame_fnv64"] == "078fb94a5cd068f5" and d["parity_vs_reference_golden"] is True
+    assert d["d2h_inclusive"]["value"] > 0 and d["d2h_inclusive"]["last_frame_equals_resident_frame"] is True
+    assert abs(d["work"]["steps_per_ray"] - 4.007) < 0.001 and d["work"]["rays_per_pixel"] == 3.0
