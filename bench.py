@@ -146,6 +146,120 @@ def cpu_baseline(w, h, cam, spheres, level_file, target_s=10.0):
                       "with table-emulated rcpps/rsqrtps, OpenMP over rows" % (reps + 1, w, h, reps + 1)}
 
 
+def d2h_leg_one_gpu(r, args, w, h, cam, sec, spheres, blocking_best, same_as_resident):
+    """The metric as SURVEY.md 8(d) words it, on one GPU: every frame handed over to the host.  Same step as the
+    resident loop (re-bin + upload, trace, blur) plus the D2H into the library's pinned sbuf, `slots` frames in
+    flight; the same K-step blocks, median block."""
+    import torch
+    nsl = max(2, min(args.slots, 4))
+    r.frames_config(nsl, sbuf=True)
+    held = {"f": None}
+
+    def d2h_block(n):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for f in range(n + nsl - 1):
+            if f >= nsl - 1:
+                held["f"] = r.wait_frame((f - nsl + 1) % nsl)
+            if f < n:
+                r.set_objects(spheres)
+                r.submit_frame(cam, sec, f % nsl)
+        return time.perf_counter() - t1
+    d2h_block(args.warmup)
+    d2h_s = []
+    while sum(d2h_s) < args.min_time and len(d2h_s) < 500:
+        d2h_s.append(d2h_block(args.steps))
+    d2h_dt = float(np.median(d2h_s))
+    d2h_ok = bool(same_as_resident(held["f"]["sbuf"])) if same_as_resident is not None else None
+    pcie = {"value": round(w * h * args.steps / d2h_dt / 1e6, 3), "unit": "Mpixels/s",
+            "ms_per_step": round(d2h_dt / args.steps * 1e3, 4), "frames_in_flight": nsl,
+            "blocks": len(d2h_s), "block_ms_p10_p50_p90": [round(float(np.percentile(d2h_s, q)) * 1e3, 3) for q in (10, 50, 90)],
+            "bytes_over_pcie_per_frame": 4 * w * h,
+            "pcie_gbs": round(4 * w * h * args.steps / d2h_dt / 1e9, 2),
+            "blocking_call_mpix_s": round(w * h / blocking_best / 1e6, 2),
+            "last_frame_equals_resident_frame": d2h_ok,
+            "what": "set_objects + pwn_submit_frame / pwn_wait_frame: trace + blur + D2H of sbuf into pinned host memory; "
+                    "blocking_call = one pwn_trace_screen_centred into pageable memory at a time"}
+    r.frames_config(0)
+    return pcie
+
+
+def host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks, same_as_resident):
+    """The same metric with every frame delivered to the HOST on N > 1 GPUs (main.c:107-109 presents
+    every frame there): pwn_tiled_host_sink -- every rank copies its finished strip straight into ONE frame in POSIX
+    shared memory over its own PCIe link, there is no gather to rank 0.  Collective: every rank calls it."""
+    import torch
+    import torch.distributed as dist
+    import pwnfps_amd
+    import mmap
+    barrier()
+    r.tiled_shutdown()
+    shm_name = [("/dev/shm/pwn_bench_frames_%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None]
+    if rank == 0:
+        with open(shm_name[0], "wb") as f:
+            f.truncate(_lib_slots() * 4 * w * h)
+    uid2 = [pwnfps_amd.Renderer.tiled_unique_id(transport) if rank == 0 else None]
+    dist.broadcast_object_list(shm_name, src=0)
+    dist.broadcast_object_list(uid2, src=0)
+    fd = os.open(shm_name[0], os.O_RDWR)
+    frames_mm = mmap.mmap(fd, _lib_slots() * 4 * w * h)
+    os.close(fd)
+    r.tiled_init(rank, world, uid2[0], transport, args.halo)
+    sink_err = None
+    try:
+        r.tiled_host_sink(frames_mm)
+    except Exception as e:                                       # noqa: BLE001 -- reported in the line
+        sink_err = "rank %d: %s" % (rank, e)
+    ok = torch.tensor([0.0 if sink_err else 1.0], dtype=torch.float64)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    sink_ok = float(ok.item()) == 1.0                            # every rank takes the same branch
+    held = {"f": None}
+
+    def host_block(n):
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(n):
+            r.set_objects(spheres)
+            r.tiled_submit(cam, sec)
+            if i >= 2:
+                held["f"] = r.tiled_wait()
+        for _ in range(min(n, 2)):
+            held["f"] = r.tiled_wait()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t1)
+    if not sink_ok:
+        pcie = {"value": None, "error": sink_err or "pwn_tiled_host_sink failed on another rank"}
+    else:
+        host_block(args.warmup)
+        host_s = []
+        while True:
+            host_s.append(host_block(args.steps))
+            if sum(host_s) >= args.min_time or len(host_s) >= 500:
+                break
+        host_dt = float(np.median(host_s))
+        hinfo = r.tiled_info()
+        host_ok = bool(same_as_resident(held["f"]["sbuf"])) if same_as_resident is not None else None
+        pcie = {"value": round(w * h * args.steps / host_dt / 1e6, 3), "unit": "Mpixels/s",
+                "ms_per_step": round(host_dt / args.steps * 1e3, 4), "frames_in_flight": 3,
+                "blocks": len(host_s), "block_ms_p10_p50_p90": [round(float(np.percentile(host_s, q)) * 1e3, 3) for q in (10, 50, 90)],
+                "bytes_over_pcie_per_frame_and_rank": int(hinfo["bytes_to_host"] // max(hinfo["frames"] + hinfo["frames_redone"], 1)),
+                "pcie_links": world,
+                "host_frame_gbs": round(4 * w * h * args.steps / host_dt / 1e9, 2),
+                "frames_repeated_with_whole_strips": int(max_over_ranks(float(hinfo["frames_redone"]))),
+                "last_frame_equals_resident_frame": host_ok,
+                "what": "pwn_tiled_host_sink: set_objects + pwn_tiled_submit / pwn_tiled_wait; every rank copies its finished strip "
+                        "into one frame in POSIX shared memory over its own PCIe link, no gather to rank 0"}
+    barrier()
+    held["f"] = None
+    r.tiled_shutdown()
+    if rank == 0:
+        try:
+            os.unlink(shm_name[0])
+        except OSError:
+            pass
+    return pcie
+
+
 def _lib_slots():
     from pwnfps_amd import _lib
     return _lib.PWN_TILED_SLOTS
@@ -360,116 +474,11 @@ def main():
         st = r.stats()                     # kernel times of an uncounted frame
         kernel_ms = {"trace": round(st["trace_ms"], 4), "blur": round(st["blur_ms"], 4)}
     if world == 1 and not args.no_d2h:
-        # The metric as SURVEY.md 8(d) words it: every frame handed over to the host.  Same
-        # step as above (re-bin + upload, trace, blur) plus the D2H into the library's pinned
-        # sbuf, `slots` frames in flight; the same K-step blocks, median block.
-        nsl = max(2, min(args.slots, 4))
-        r.frames_config(nsl, sbuf=True)
-        held = {"f": None}
-
-        def d2h_block(n):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for f in range(n + nsl - 1):
-                if f >= nsl - 1:
-                    held["f"] = r.wait_frame((f - nsl + 1) % nsl)
-                if f < n:
-                    r.set_objects(spheres)
-                    r.submit_frame(cam, sec, f % nsl)
-            return time.perf_counter() - t1
-        d2h_block(args.warmup)
-        d2h_s = []
-        while sum(d2h_s) < args.min_time and len(d2h_s) < 500:
-            d2h_s.append(d2h_block(args.steps))
-        d2h_dt = float(np.median(d2h_s))
-        d2h_ok = None
-        if oracle is not None and frame_hash is not None:
-            d2h_ok = bool(oracle.fnv64(held["f"]["sbuf"]) == frame_hash)
-        pcie = {"value": round(w * h * args.steps / d2h_dt / 1e6, 3), "unit": "Mpixels/s",
-                "ms_per_step": round(d2h_dt / args.steps * 1e3, 4), "frames_in_flight": nsl,
-                "blocks": len(d2h_s), "block_ms_p10_p50_p90": [round(float(np.percentile(d2h_s, q)) * 1e3, 3) for q in (10, 50, 90)],
-                "bytes_over_pcie_per_frame": 4 * w * h,
-                "pcie_gbs": round(4 * w * h * args.steps / d2h_dt / 1e9, 2),
-                "blocking_call_mpix_s": round(w * h / blocking_best / 1e6, 2),
-                "last_frame_equals_resident_frame": d2h_ok,
-                "what": "set_objects + pwn_submit_frame / pwn_wait_frame: trace + blur + D2H of sbuf into pinned host memory; "
-                        "blocking_call = one pwn_trace_screen_centred into pageable memory at a time"}
-        r.frames_config(0)
-
+        pcie = d2h_leg_one_gpu(r, args, w, h, cam, sec, spheres, blocking_best,
+                               (lambda buf: oracle.fnv64(buf) == frame_hash) if (oracle is not None and frame_hash is not None) else None)
     if world > 1 and not args.no_d2h:
-        # The same metric with every frame delivered to the HOST (main.c:107-109 presents every
-        # frame there): pwn_tiled_host_sink -- every rank copies its finished strip straight into ONE frame in
-        # POSIX shared memory over its own PCIe link, there is no gather to rank 0; the grouped exchange carries
-        # the halo rows and one word per pair of ranks.  Same K-step blocks between barriers, median block.
-        import mmap
-        barrier()
-        r.tiled_shutdown()
-        shm_name = [("/dev/shm/pwn_bench_frames_%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None]
-        if rank == 0:
-            with open(shm_name[0], "wb") as f:
-                f.truncate(_lib_slots() * 4 * w * h)
-        uid2 = [pwnfps_amd.Renderer.tiled_unique_id(transport) if rank == 0 else None]
-        dist.broadcast_object_list(shm_name, src=0)
-        dist.broadcast_object_list(uid2, src=0)
-        fd = os.open(shm_name[0], os.O_RDWR)
-        frames_mm = mmap.mmap(fd, _lib_slots() * 4 * w * h)
-        os.close(fd)
-        r.tiled_init(rank, world, uid2[0], transport, args.halo)
-        sink_err = None
-        try:
-            r.tiled_host_sink(frames_mm)
-        except Exception as e:                                       # noqa: BLE001 -- reported in the line
-            sink_err = "rank %d: %s" % (rank, e)
-        ok = torch.tensor([0.0 if sink_err else 1.0], dtype=torch.float64)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        sink_ok = float(ok.item()) == 1.0                            # every rank takes the same branch
-        held = {"f": None}
-
-        def host_block(n):
-            barrier()
-            t1 = time.perf_counter()
-            for i in range(n):
-                r.set_objects(spheres)
-                r.tiled_submit(cam, sec)
-                if i >= 2:
-                    held["f"] = r.tiled_wait()
-            for _ in range(min(n, 2)):
-                held["f"] = r.tiled_wait()
-            barrier()
-            return max_over_ranks(time.perf_counter() - t1)
-        if not sink_ok:
-            pcie = {"value": None, "error": sink_err or "pwn_tiled_host_sink failed on another rank"}
-        else:
-            host_block(args.warmup)
-            host_s = []
-            while True:
-                host_s.append(host_block(args.steps))
-                if sum(host_s) >= args.min_time or len(host_s) >= 500:
-                    break
-            host_dt = float(np.median(host_s))
-            hinfo = r.tiled_info()
-            host_ok = None
-            if rank == 0 and oracle is not None and frame_hash is not None:
-                host_ok = bool(oracle.fnv64(held["f"]["sbuf"]) == frame_hash)
-            pcie = {"value": round(w * h * args.steps / host_dt / 1e6, 3), "unit": "Mpixels/s",
-                    "ms_per_step": round(host_dt / args.steps * 1e3, 4), "frames_in_flight": 3,
-                    "blocks": len(host_s), "block_ms_p10_p50_p90": [round(float(np.percentile(host_s, q)) * 1e3, 3) for q in (10, 50, 90)],
-                    "bytes_over_pcie_per_frame_and_rank": int(hinfo["bytes_to_host"] // max(hinfo["frames"] + hinfo["frames_redone"], 1)),
-                    "pcie_links": world,
-                    "host_frame_gbs": round(4 * w * h * args.steps / host_dt / 1e9, 2),
-                    "frames_repeated_with_whole_strips": int(max_over_ranks(float(hinfo["frames_redone"]))),
-                    "last_frame_equals_resident_frame": host_ok,
-                    "what": "pwn_tiled_host_sink: set_objects + pwn_tiled_submit / pwn_tiled_wait; every rank copies its finished strip "
-                            "into one frame in POSIX shared memory over its own PCIe link, no gather to rank 0"}
-        barrier()
-        held["f"] = None
-        r.tiled_shutdown()
-        if rank == 0:
-            try:
-                os.unlink(shm_name[0])
-            except OSError:
-                pass
-        # (bring the resident configuration's info back for the line below)
+        pcie = host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks,
+                             (lambda buf: oracle.fnv64(buf) == frame_hash) if (rank == 0 and oracle is not None and frame_hash is not None) else None)
 
     if rank == 0:
         pix = w * h
