@@ -17,6 +17,7 @@
  */
 #ifndef PWNHIP_H
 #define PWNHIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
