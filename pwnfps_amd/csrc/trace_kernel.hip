@@ -329,6 +329,12 @@ pwn_trace_kernel(pwn_trace_params P)
 	// only when that is empty), so this costs parallelism at the very end at worst and makes
 	// sure every wave's loop ends whatever the loads return.
 	int misses = 0;
+	// Tickets are drawn two at a time when the launch is long (>= 16 units per wave): the returning atomic is a
+	// 32-byte write at the memory side, 4 MB per 4K frame with one per unit, 2 MB with pairs.  Strips and small
+	// frames keep single tickets for the balance of their tail; three per draw measured 2.5 % slower at 4K (the
+	// tail) for another 0.6 MB.  `left` = tickets in hand after the current one (wave-uniform).
+	const uint32_t draw_n = units >= 16u * (PWN_BLOCK / 64u) * gridDim.x ? 2u : 1u;
+	uint32_t left = 0u;
 	for(;;)
 	{
 		// units of queue q: q, q + Q, ...  below `units`
@@ -336,6 +342,7 @@ pwn_trace_kernel(pwn_trace_params P)
 		if(ticket >= qlen)
 		{
 			if(++misses > 2 * (int)PWN_QUEUES) break;
+			left = 0u;
 			// this queue is empty: find one that is not (plain loads; a stale value can only
 			// look fuller than the queue is, and then the atomic below says so)
 			uint32_t seen = 0xffffffffu;
@@ -367,8 +374,9 @@ pwn_trace_kernel(pwn_trace_params P)
 		}
 		misses = 0;
 		const uint32_t unit = ticket * PWN_QUEUES + q;
-		uint32_t next_raw = 0;
-		if(lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], 1u);
+		const bool draw = left == 0u;
+		uint32_t next_raw = ticket + 1u;
+		if(draw && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n);
 		// rows from the middle outwards: the horizon band, where rays run longest,
 		// is started first and the cheap top and bottom edges make up the tail
 		// (this arithmetic is the same for the whole wave, but the compiler does it per lane because q starts
@@ -437,6 +445,7 @@ pwn_trace_kernel(pwn_trace_params P)
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
 		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
+		left = draw ? draw_n - 1u : left - 1u;
 	}
 
 	if(COUNT)
