@@ -49,6 +49,30 @@ __device__ __forceinline__ int blur_coord(float f, int hi)
 	return r - 1;
 }
 
+// The same, left one up: [1, hi].  The tiled kernel folds the "- 1" into the constants the coordinate meets.
+__device__ __forceinline__ int blur_coord1(float f, int hi)
+{
+	int t, r;
+	asm("v_cvt_i32_f32 %0, %1" : "=v"(t) : "v"(f));
+	t = (int)((uint32_t)t + 1u);
+	asm("v_med3_i32 %0, %1, 1, %2" : "=v"(r) : "v"(t), "v"(hi));
+	return r;
+}
+
+// lcg_fs (dev_math.h; util.h:33-45 of the reference) on the DOUBLED state t = 2 s: the "& 0x7FFFFFFF" of every
+// step is then the wrap of 32-bit arithmetic (2 ((25739 s + 4) mod 2^31) = (25739 t + 8) mod 2^32), the quotient
+// s / 3759 is the same multiply-high (t M >> 44 = s M >> 43, M = ceil(2^43 / 3759), exact for every s < 2^31), the
+// remainder comes out doubled from one 24-bit multiply-add (the quotient has 20 bits), and (float)(2 r) * (inv / 2)
+// rounds exactly as (float)r * inv.  Two instructions per draw fewer; same bits.
+__device__ __forceinline__ float blur_lcg_fs(uint32_t &t)
+{
+	t = t * 25739u + 8u;
+	const uint32_t q = __umulhi(t, 0x8b79b351u) >> 12;
+	const uint32_t r2 = (uint32_t)(__mul24((int)q, -7518) + (int)t);
+	const float u = (float)r2 * (0.5f * (1.0f / 3759.0f));
+	return __builtin_fmaf(u, 2.0f, -1.0f);
+}
+
 __global__ void __launch_bounds__(256)
 pwn_blur_kernel(pwn_blur_params P)
 {
@@ -158,6 +182,16 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	const size_t row = (size_t)cy * (size_t)P.w;
 	const float4 zv = *(const float4 *)(P.zbuf + row + cx);
 	const float z[4] = { zv.x - 1.0f, zv.y - 1.0f, zv.z - 1.0f, zv.w - 1.0f };
+	const float fcx[4] = { (float)cx, (float)(cx + 1), (float)(cx + 2), (float)(cx + 3) };
+	const float fcy = (float)cy;
+	// Tap coordinates are kept ONE UP, as blur_coord1 leaves them ([1, w] x [1, h]); the constants they meet
+	// absorb the difference: the staged rectangle's origin, the rows this rank holds, and the frame's base
+	// address (moved back by one row and one pixel -- as an integer, no pointer outside the allocation is formed
+	// until the offset of a real tap, >= w + 1, has been added).
+	const int lx1 = lx0 + 1, ly1 = ly0 + 1;
+	const uint32_t w1 = (uint32_t)P.w + 1u;
+	const uintptr_t pre1 = (uintptr_t)P.pre - (uintptr_t)w1 * 4u;
+	uint32_t t2 = seed << 1;                               // the LCG state doubled (see blur_lcg_fs)
 	uint32_t tap[4][4];
 	bool missed = false;
 #pragma unroll
@@ -167,22 +201,24 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 		for(int j = 0; j < 4; j++)
 		{
 			// screen.h:101-106
-			const float fx = (float)(cx + j) + (lcg_fs(seed) * fstr) * z[j];
-			const float fy = (float)cy + (lcg_fs(seed) * fstr) * z[j];
-			const int x = blur_coord(fx, P.w), y = blur_coord(fy, P.h);
-			if(CHECK) missed |= (unsigned)(y - P.avail_y0) >= (unsigned)(P.avail_y1 - P.avail_y0);
+			const float fx = fcx[j] + (blur_lcg_fs(t2) * fstr) * z[j];
+			const float fy = fcy + (blur_lcg_fs(t2) * fstr) * z[j];
+			const int x1 = blur_coord1(fx, P.w), y1 = blur_coord1(fy, P.h);
+			if(CHECK) missed |= (unsigned)(y1 - (P.avail_y0 + 1)) >= (unsigned)(P.avail_y1 - P.avail_y0);
 			// from the staged rectangle (every lane reads LDS, at a clamped index); a tap outside it is
 			// fetched from the frame afterwards
-			const unsigned tx = (unsigned)(x - lx0), ty = (unsigned)(y - ly0);
+			const unsigned tx = (unsigned)(x1 - lx1), ty = (unsigned)(y1 - ly1);
 			uint32_t v = tile[min(ty * BLUR_PITCH + tx, (unsigned)(BLUR_PITCH * BLUR_LH - 1))];
 			if(!(tx < (unsigned)BLUR_LW && ty < (unsigned)BLUR_LH))
 			{
 				// a real branch around the address arithmetic of the rare case (left alone the compiler selects between
 				// the two pointers with both computed).  What it emits is still ONE flat load after the branch, through
 				// an LDS-aperture or a global address; forcing a ds_read plus a separate global load serialises the
-				// taps on their waits: 46.2 against 45.5 us
+				// taps on their waits: 46.2 against 45.5 us.  Without the branch -- every lane loading from the frame
+				// as well, staged lanes all from one address, then a select -- there are 5 % fewer vector instructions
+				// and all 32 loads are in flight together, and the kernel is 1-2 us SLOWER (42.2 us).
 				asm volatile("");
-				v = P.pre[(size_t)y * (size_t)P.w + (size_t)x];
+				v = *(const uint32_t *)(pre1 + ((uintptr_t)__umul24((unsigned)y1, (unsigned)P.w) + (uintptr_t)(unsigned)x1) * 4u);
 			}
 			tap[i][j] = v;
 		}
