@@ -286,7 +286,13 @@ typedef struct frame_ctx
 	float sec_current;
 	pwno_stats st;
 	int dbg;
+	uint16_t *smap;   /* this pixel's slots of the step map, or NULL */
 } frame_ctx;
+
+/* analysis aid (tools/unit_shapes.py): pwno_step_map(m) makes the next pwno_trace_rows calls store the
+   walk-loop iterations of every ray segment, m[(y*w + x)*3 + depth]; NULL switches it off */
+static uint16_t *step_map = NULL;
+void pwno_step_map(uint16_t *m) { step_map = m; }
 
 /* debugging aid for oracle-vs-reference hunts: pwno_debug_pixel(x,y) makes the
    next renders print the event chain of that pixel to stderr */
@@ -640,7 +646,9 @@ static v4 trace_pixel(frame_ctx *fc, uint32_t *seed, v4 from, v4 iray, float *di
 		hit h;
 		memset(&h, 0, sizeof(h));
 		DBG(fc, " segment %d from %a %a %a %a dir %a %a %a %a\n", depth, from.x, from.y, from.z, from.w, iray.x, iray.y, iray.z, iray.w);
+		const int64_t steps0 = fc->st.steps;
 		walk(fc, from, iray, &h);
+		if(fc->smap != NULL) fc->smap[depth] = (uint16_t)(fc->st.steps - steps0);
 		DBG(fc, " -> ev %d ldir %d dist %a fog %a pos %a %a %a col %a %a %a refl %a\n", h.ev, h.ldir, h.dist, h.fog, h.pos.x, h.pos.y, h.pos.z, h.col.x, h.col.y, h.col.z, h.refl);
 		if(h.ev == EV_EXHAUSTED) { value = h.ray; break; }
 		if(depth == 0) *dist = h.dist;
@@ -787,7 +795,7 @@ int pwno_trace_rows(const pwno_level *lv, int w, int h, int y0, int y1,
 	{
 		unsigned csr = fast_math_on();
 		frame_ctx fc;
-		fc.lv = lv; fc.sec_current = sec_current; fc.dbg = 0;
+		fc.lv = lv; fc.sec_current = sec_current; fc.dbg = 0; fc.smap = NULL;
 		memset(&fc.st, 0, sizeof(fc.st));
 #pragma omp for schedule(dynamic, 4)
 		for(int y = y0; y < y1; y++)
@@ -803,6 +811,7 @@ int pwno_trace_rows(const pwno_level *lv, int w, int h, int y0, int y1,
 					float dist = 0.0f;
 					float *dp = zbuf != NULL ? &zbuf[(size_t)y*w + x] : &dist;
 					fc.dbg = (x == dbg_x && y == dbg_y);
+					fc.smap = step_map != NULL ? step_map + ((size_t)y*w + x)*(REFLECT_MAX + 1) : NULL;
 					v4 c = trace_pixel(&fc, &seed, from, rayl, dp);
 					DBG(&fc, "pixel %d,%d value %a %a %a %a -> %08x\n", x, y, c.x, c.y, c.z, c.w, col_pack(c));
 					sbuf[(size_t)y*w + x] = col_pack(c);

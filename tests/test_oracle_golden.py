@@ -127,6 +127,33 @@ def test_thread_count_invariance(oracle_lib):
     assert (a == b).all() and (za.view(np.uint32) == zb.view(np.uint32)).all()
 
 
+def test_step_map_adds_up(oracle_lib):
+    """pwno_step_map (the analysis aid behind tools/unit_shapes.py): the per-pixel, per-segment walk iterations
+    add up to the frame's step counter, every pixel has a primary segment, and the 16x4 units of the level.txt
+    frame at 4K cost what the GPU kernel's own wave-iteration counter reports for that shape (1 741 949: checked
+    in the tool's output, too long for this suite) -- here a 320x240 frame keeps the bookkeeping honest."""
+    import ctypes as C
+    O = oracle_lib.Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    O.set_spheres(load_spheres("t0"))
+    cam = np.eye(4, dtype=np.float32)
+    cam[3, :3] = (9.5, 0.5, 4.5)
+    L = oracle_lib.lib()
+    L.pwno_step_map.argtypes = [C.c_void_p]
+    L.pwno_step_map.restype = None
+    m = np.zeros((240, 320, 3), np.uint16)
+    L.pwno_step_map(m.ctypes.data)
+    try:
+        sb, zb, st = O.trace_rows(320, 240, 0, 240, cam)
+    finally:
+        L.pwno_step_map(None)
+    assert int(m.sum(dtype=np.int64)) == st.steps
+    assert (m[:, :, 0] > 0).all()
+    assert int((m > 0).sum()) == st.rays
+    sb2, _, st2 = O.trace_rows(320, 240, 0, 240, cam)            # switched off again: same frame, nothing written
+    assert (sb == sb2).all() and st2.steps == st.steps
+
+
 def test_loader_edge_cases(oracle_lib):
     O = oracle_lib.Oracle()
     # empty text: all wall, spawn 0,0 (level_new, level.h:85-105)
