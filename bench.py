@@ -366,9 +366,39 @@ def main():
                 transport = "shm"
                 transport_note = transport_note or "librccl could not be loaded on another rank"
                 print("bench.py rank %d: %s -- falling back to the shared-memory transport" % (rank, transport_note), file=sys.stderr)
-        uid = [pwnfps_amd.Renderer.tiled_unique_id(transport) if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        r.tiled_init(rank, world, uid[0], transport, args.halo)
+        def bring_up(tp):
+            """Communicator plus four frames through every leg of the exchange (halo group, gather group, miss
+            words); every rank learns whether ALL ranks got through."""
+            u = [pwnfps_amd.Renderer.tiled_unique_id(tp) if rank == 0 else None]
+            dist.broadcast_object_list(u, src=0)
+            err = None
+            try:
+                r.tiled_init(rank, world, u[0], tp, args.halo)
+                for i in range(4):
+                    r.set_objects(spheres)
+                    r.tiled_submit(cam, sec)
+                    if i >= 2:
+                        r.tiled_wait()
+                r.tiled_wait()
+                r.tiled_wait()
+                torch.cuda.synchronize()
+            except Exception as e:                                   # noqa: BLE001 -- reported in the line
+                err = "rank %d: %s" % (rank, e)
+            good = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            return float(good.item()) == 1.0, err
+
+        up, err = bring_up(transport)
+        if not up and transport == "rccl":
+            # (an error every rank can return from -- a communicator that cannot be made in this environment --
+            # not a peer that died inside a collective: that ends in the control plane's timeout)
+            transport_note = "the RCCL transport did not come up (%s)" % (err or "on another rank")
+            print("bench.py rank %d: %s -- falling back to the shared-memory transport" % (rank, transport_note), file=sys.stderr)
+            r.tiled_shutdown()
+            transport = "shm"
+            up, err = bring_up(transport)
+        if not up:
+            sys.exit("bench.py rank %d: the row tiling did not come up over %s: %s" % (rank, transport, err or "error on another rank"))
         tinfo = r.tiled_info()
 
     launch_ms = []

@@ -52,6 +52,25 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     assert hs["bytes_over_pcie_per_frame_and_rank"] == t["rows_per_rank"] * size[0] * 4
 
 
+def test_bench_falls_back_when_rccl_does_not_come_up():
+    """RCCL asked for with two ranks on ONE device -- a communicator that cannot be made here: every rank gets an
+    error back (or librccl is missing altogether), the ranks agree on the shared-memory transport, and the line says
+    what happened instead of the job dying without one."""
+    env = dict(os.environ)
+    env.update(PWN_BENCH_ONE_DEVICE="1", PWN_BENCH_TRANSPORT="rccl", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--min-time", "0.1",
+           "--width", "1280", "--height", "720", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["frame_fnv64"] == "078fb94a5cd068f5"
+    assert d["tiling"]["transport"] == "shm" and "transport_note" in d["tiling"], d["tiling"]
+
+
 def test_bench_line_on_one_gpu():
     """The contract of the one-GPU line (the driver's BENCH run): one JSON line with the metric, the roofline object of
     the dominant kernel, the D2H-inclusive leg and the work counters; the last frame is the golden frame."""
