@@ -69,12 +69,12 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	for(int i = 0; i < PWN_NBLOB; i++)
 	{
 		c->d_blob[i] = NULL; c->blob_has_static[i] = false;
-		c->ev_tables[i] = NULL; c->tables_in_use[i] = false;
+		c->ev_tables[i] = NULL; c->tables_in_use[i] = false; c->tables_wait[i] = NULL;
 		c->ev_upload[i] = NULL; c->upload_pending[i] = false;
 	}
 	for(int i = 0; i < PWN_NSTAGE; i++) { c->h_stage[i] = NULL; c->ev_stage[i] = NULL; c->stage_used[i] = false; }
 	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0;
-	c->trace_clear_word = NULL; c->grid_reserve = 0;
+	c->trace_clear_word = NULL; c->trace_tables_event = NULL; c->grid_reserve = 0;
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 8; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
 	c->stream = NULL; c->copy_stream = NULL;
@@ -283,7 +283,7 @@ static int pack_blob(pwn_ctx *c)
 	if(c->stage_used[st]) HIPCHK(c, hipEventSynchronize(c->ev_stage[st]));
 	memcpy(c->h_stage[st], b + from, total - from);
 	// launches still reading that copy (two uploads ago) finish first -- a wait between streams
-	if(c->tables_in_use[nb]) HIPCHK(c, hipStreamWaitEvent(c->up_stream, c->ev_tables[nb], 0));
+	if(c->tables_in_use[nb]) HIPCHK(c, hipStreamWaitEvent(c->up_stream, c->tables_wait[nb], 0));
 	// (a kernel that reads the pinned buffer, not a DMA copy: see pwn_upload_kernel; total and from are multiples of 16)
 	HIPCHK(c, pwn_launch_upload(c->h_stage[st], c->d_blob[nb] + from, total - from, c->up_stream));
 	HIPCHK(c, hipEventRecord(c->ev_stage[st], c->up_stream));
@@ -514,10 +514,12 @@ static void frame_setup(int w, int h, const float cam[16], pwn_trace_params *P)
 int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y1,
 	uint32_t *d_sbuf, float *d_zbuf, hipStream_t stream)
 {
-	if(!c->have_level) return PWN_ENOLEVEL;
-	if(c->blob_dirty) { int rc = pack_blob(c); if(rc != PWN_OK) return rc; }
 	uint32_t *clear_word = c->trace_clear_word;            // for this launch only
 	c->trace_clear_word = NULL;
+	hipEvent_t caller_event = c->trace_tables_event;       // (pwn_internal.h)
+	c->trace_tables_event = NULL;
+	if(!c->have_level) return PWN_ENOLEVEL;
+	if(c->blob_dirty) { int rc = pack_blob(c); if(rc != PWN_OK) return rc; }
 	if(y1 == y0) return PWN_OK;
 	pwn_trace_params P;
 	memset(&P, 0, sizeof(P));
@@ -594,7 +596,12 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	if(refill) HIPCHK(c, pwn_launch_trace_refill(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	else HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	c->ticket_set++;                     // only a launch that went out has cleared the other set
-	HIPCHK(c, hipEventRecord(c->ev_tables[cur], stream));
+	if(caller_event != NULL) c->tables_wait[cur] = caller_event;
+	else
+	{
+		HIPCHK(c, hipEventRecord(c->ev_tables[cur], stream));
+		c->tables_wait[cur] = c->ev_tables[cur];
+	}
 	c->tables_in_use[cur] = true;
 	return PWN_OK;
 }
@@ -689,6 +696,13 @@ static void slot_release(pwn_slot &sl)
 
 static void frames_release(pwn_ctx *c)
 {
+	// A slot's "kernels done" event may be what an upload would wait for (pwn_ctx.trace_tables_event): no frame
+	// is in flight here, so once the compute stream is empty no copy of the tables is in use any more
+	if(c->nslots > 0)
+	{
+		if(c->stream) (void)hipStreamSynchronize(c->stream);
+		for(int i = 0; i < PWN_NBLOB; i++) c->tables_in_use[i] = false;
+	}
 	for(int i = 0; i < PWN_MAX_SLOTS; i++) slot_release(c->slot[i]);
 	c->nslots = 0;
 }
@@ -753,6 +767,7 @@ extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int 
 	// the last pass writes into the slot's own plane, which is what the copy stream reads while
 	// the next frame's kernels reuse the context's d_pre / d_out
 	uint32_t *cur = c->blur_passes > 0 ? c->d_pre : sl.d_out;
+	c->trace_tables_event = sl.ev_k[2];        // recorded below, behind the frame's last kernel
 	int rc = pwn_i_launch_trace(c, cam, sec, 0, c->h, cur, sl.d_z, s);
 	if(rc != PWN_OK) return rc;
 	if(timing) HIPCHK(c, hipEventRecord(sl.ev_k[1], s));
@@ -760,7 +775,7 @@ extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int 
 	{
 		uint32_t *dst = (p == c->blur_passes - 1) ? sl.d_out : (cur == c->d_pre ? c->d_out : c->d_pre);
 		rc = pwn_i_launch_blur(c, 0, c->h, cur, sl.d_z, dst, s, 0, 0, NULL);
-		if(rc != PWN_OK) return rc;
+		if(rc != PWN_OK) { (void)hipEventRecord(sl.ev_k[2], s); return rc; }     // (the trace launch counts on this event)
 		cur = dst;
 	}
 	HIPCHK(c, hipEventRecord(sl.ev_k[2], s));

@@ -78,6 +78,12 @@ struct pwn_ctx
 	uint8_t *d_blob[PWN_NBLOB]; int blob_cur;
 	bool blob_has_static[PWN_NBLOB];                                   // the rcp / rsqrt tables are in place
 	hipEvent_t ev_tables[PWN_NBLOB]; bool tables_in_use[PWN_NBLOB];    // behind the last trace launch reading that copy
+	hipEvent_t tables_wait[PWN_NBLOB];                                 // ... the event to wait for: ev_tables[i], or the caller's (below)
+	// Set by a caller of pwn_i_launch_trace for its next launch: an event the caller records itself right behind
+	// that launch anyway (its frame's "kernels done").  The launcher then records none of its own -- every
+	// event between two kernels costs the queue a few microseconds.  Such an event may be recorded again later
+	// (its slot's next frame); the upload that waits for it then waits a frame longer, never shorter.
+	hipEvent_t trace_tables_event;
 	hipEvent_t ev_upload[PWN_NBLOB]; bool upload_pending[PWN_NBLOB];   // behind the last upload into that copy
 	uint8_t *h_stage[PWN_NSTAGE]; hipEvent_t ev_stage[PWN_NSTAGE]; bool stage_used[PWN_NSTAGE]; unsigned stage_next;
 	hipStream_t up_stream;

@@ -284,6 +284,9 @@ void pwn_tiled_destroy(pwn_ctx *c)
 	if(t == NULL) return;
 	(void)hipSetDevice(c->device);
 	(void)hipDeviceSynchronize();
+	// (the device is idle: no copy of the tables is in use, and the events that said so -- ev_t, handed to the trace
+	// launches as pwn_ctx.trace_tables_event -- are destroyed below)
+	for(int i = 0; i < PWN_NBLOB; i++) c->tables_in_use[i] = false;
 	delete t->tp;
 	for(int s = 0; s < NSLOT; s++)
 	{
@@ -582,8 +585,9 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
 	c->trace_clear_word = t->missw[s];           // the frame's miss word is cleared by its trace launch (no memset between the kernels)
+	c->trace_tables_event = t->ev_t[s];          // ... and ev_t, recorded right behind it, also tells when its tables are free again
 	int rc = pwn_i_launch_trace(c, cam, sec, t->y0, t->y1, plane, t->z[s], cs);
-	if(rc != PWN_OK) return rc;
+	if(rc != PWN_OK) { (void)hipEventRecord(t->ev_t[s], cs); return rc; }
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
 	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
 

@@ -74,6 +74,8 @@ def test_frames_in_flight_are_the_oracles_frames(slots, oracle_lib):
     sb, zb = r.trace_screen_centred(cam, sec)
     assert (sb == got[1][0]).all()
     r.frames_config(2, sbuf=True)
+    for _ in range(5):
+        r.set_objects(sph)          # every copy of the tables is uploaded again: none may still be waiting for an event of the old slots
     r.submit_frame(cam, sec, 0)
     with pytest.raises(pwnfps_amd.PwnError):
         r.frames_config(3, sbuf=True)                       # a frame is in flight
