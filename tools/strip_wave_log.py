@@ -43,6 +43,7 @@ units = ((w + 15) // 16) * ((y1 - y0 + 3) // 4)
 print("strip %d of %d, rows [%d,%d): %d units, %d waves logged, span %.1f us, mean residency %.3f" % (
     rank, n, y0, y1, units, len(log), e.max(), life.sum() / (len(log) * e.max())))
 q = [0, 10, 25, 50, 75, 90, 99, 100]
+print("wave start us", dict(zip(q, np.round(np.percentile(b, q), 1))))
 print("wave end us  ", dict(zip(q, np.round(np.percentile(e, q), 1))))
 print("wave life us ", dict(zip(q, np.round(np.percentile(life, q), 1))))
 late = np.sort(e)[::-1][:12]
