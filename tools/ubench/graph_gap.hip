@@ -3,8 +3,11 @@
 // per workgroup like the trace kernel, B 40 us on 2048 workgroups of 1024 threads like the blur) launched as frames
 //   mode 0: A, B on one stream, nothing else                      mode 1: ... plus one event record per frame
 //   mode 2: ... plus a wait for an event of another stream        mode 3: a captured graph of 8 frames, replayed
+//   mode 4: like 1, but the event rides on B's own dispatch packet (hipExtLaunchKernelGGL's stopEvent) and the host
+//           waits for it every eighth frame; mode 5: mode 1 with the same host waits (the control for 4)
 //   hipcc --offload-arch=gfx950 -O2 -o graph_gap graph_gap.hip && ./graph_gap
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <chrono>
@@ -49,10 +52,12 @@ int main()
 			CHECK(hipStreamWaitEvent(s, ev2, 0));
 		}
 		hipLaunchKernelGGL(spin_a, dim3(1280), dim3(256), 27 * 1024, s, TA, sink);
-		hipLaunchKernelGGL(spin_b, dim3(512), dim3(1024), 0, s, TB, sink);
-		if(mode == 1 || mode == 2) CHECK(hipEventRecord(ev[i & 7], s));
+		if(mode == 4) hipExtLaunchKernelGGL(spin_b, dim3(512), dim3(1024), 0, s, NULL, ev[i & 7], 0, TB, sink);
+		else hipLaunchKernelGGL(spin_b, dim3(512), dim3(1024), 0, s, TB, sink);
+		if(mode == 1 || mode == 2 || mode == 5) CHECK(hipEventRecord(ev[i & 7], s));
+		if((mode == 4 || mode == 5) && i >= 3 && (i & 7) == 7) CHECK(hipEventSynchronize(ev[(i - 3) & 7]));
 	};
-	for(int mode = 0; mode < 4; mode++)
+	for(int mode = 0; mode < 6; mode++)
 	{
 		hipGraph_t g = NULL; hipGraphExec_t ge = NULL;
 		if(mode == 3)
