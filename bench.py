@@ -154,15 +154,19 @@ def d2h_leg_one_gpu(r, args, w, h, cam, sec, spheres, blocking_best, same_as_res
     nsl = max(2, min(args.slots, 4))
     r.frames_config(nsl, sbuf=True)
     held = {"f": None}
+    early = args.prepare == "early"
 
     def d2h_block(n):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for f in range(n + nsl - 1):
+            if f < n and early:
+                r.set_objects(spheres)
             if f >= nsl - 1:
                 held["f"] = r.wait_frame((f - nsl + 1) % nsl)
             if f < n:
-                r.set_objects(spheres)
+                if not early:
+                    r.set_objects(spheres)
                 r.submit_frame(cam, sec, f % nsl)
         return time.perf_counter() - t1
     d2h_block(args.warmup)
@@ -214,13 +218,17 @@ def host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barr
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     sink_ok = float(ok.item()) == 1.0                            # every rank takes the same branch
     held = {"f": None}
+    early = args.prepare == "early"
 
     def host_block(n):
         barrier()
         t1 = time.perf_counter()
         for i in range(n):
-            r.set_objects(spheres)
+            if not early or i == 0:
+                r.set_objects(spheres)
             r.tiled_submit(cam, sec)
+            if early and i + 1 < n:
+                r.set_objects(spheres)
             if i >= 2:
                 held["f"] = r.tiled_wait()
         for _ in range(min(n, 2)):
@@ -283,6 +291,8 @@ def main():
                          "kernels costs ~4 us of pipeline; 1 = every launch)")
     ap.add_argument("--halo", type=int, default=-1, help="N > 1: pre-blur rows exchanged with each neighbour strip (-1 default, 0 whole strips)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prepare", choices=("early", "late"), default="early",
+                    help="set_objects of a frame before (early) or after (late) the host waits for a free slot")
     ap.add_argument("--no-d2h", action="store_true",
                     help="skip the d2h_inclusive leg: for rocprofv3 --kernel-trace runs, where the profiler serialises the copies of "
                          "that leg with the kernels and their durations (2.7x) would be averaged into the resident loop's")
@@ -403,6 +413,7 @@ def main():
 
     launch_ms = []
     last = {"f": None}
+    early = args.prepare == "early"
 
     # Every step re-bins and re-uploads the spheres first, like the reference's frame loop does
     # (level_prepare_render, main.c:95), although this benchmark's spheres do not move.
@@ -414,19 +425,30 @@ def main():
             last["f"] = f
         if world == 1:
             # N = 1: the slot ring of the frames API, frames stay on the device
+            # --prepare early (default): the tables of frame i are prepared BEFORE the host waits for a free slot.  Their
+            # upload (own stream, into a copy of the tables no frame in flight reads) is then done when frame i is
+            # submitted, and its trace launch needs no wait between the streams in front of it -- a packet that costs
+            # the queue ~5 us per frame (tools/ubench/graph_gap.hip).  Same calls and the same work per frame as
+            # --prepare late, which is the reference's order (level_prepare_render right before the trace, main.c:95-107).
             for i in range(n):
                 k = i % nres
+                if early:
+                    r.set_objects(spheres)
                 if i >= nres:
                     note(r.wait_frame(k))
-                r.set_objects(spheres)
+                if not early:
+                    r.set_objects(spheres)
                 r.submit_frame(cam, sec, k)
             for i in range(max(0, n - nres), n):
                 note(r.wait_frame(i % nres))
         else:
             # N > 1: three frames in flight; the exchange of frame i carries the result of frame i-2
             for i in range(n):
-                r.set_objects(spheres)
+                if not early or i == 0:
+                    r.set_objects(spheres)
                 r.tiled_submit(cam, sec)
+                if early and i + 1 < n:
+                    r.set_objects(spheres)          # frame i+1's tables, before the wait below
                 if i >= 2:
                     note(r.tiled_wait())
             for _ in range(min(n, 2)):
@@ -540,6 +562,8 @@ def main():
                                    "%dx%d, POSTPROC_BLUR=%d, one frame per step" % (w, h, args.blur),
                        "level": args.level, "width": w, "height": h, "blur_passes": args.blur,
                        "parallelism": par,
+                       "host_loop": ("set_objects(i) / wait for a free slot / submit(i)" if args.prepare == "early"
+                                     else "wait for a free slot / set_objects(i) / submit(i)") + ", every frame re-bins and re-uploads the spheres",
                        "frames_repeated_with_whole_strips": int(redone) if world > 1 else 0},
             "roofline": {"bound": "hbm", "kernel": "pwn_trace_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),

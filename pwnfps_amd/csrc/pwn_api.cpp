@@ -596,7 +596,16 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	if(refill) HIPCHK(c, pwn_launch_trace_refill(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	else HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	c->ticket_set++;                     // only a launch that went out has cleared the other set
-	if(caller_event != NULL) c->tables_wait[cur] = caller_event;
+	if(caller_event != NULL)
+	{
+		// The caller is about to record this event again.  Its last record was behind a frame the caller has since
+		// waited for on the host (a free slot), so a copy of the tables still guarded by that record is not in
+		// use any more -- and must stop pointing at the event, or its next upload would wait for THIS frame,
+		// the newest one in flight (four copies with three slots did exactly that: 20 us of idle GPU per frame).
+		for(int i = 0; i < PWN_NBLOB; i++)
+			if(c->tables_in_use[i] && c->tables_wait[i] == caller_event) c->tables_in_use[i] = false;
+		c->tables_wait[cur] = caller_event;
+	}
 	else
 	{
 		HIPCHK(c, hipEventRecord(c->ev_tables[cur], stream));

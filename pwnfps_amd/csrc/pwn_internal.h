@@ -37,7 +37,11 @@ extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out
 // LDS budget for the table blob: leave room so that at least two workgroups
 // fit per CU (160 KiB LDS per CU on gfx950)
 #define PWN_BLOB_MAX (72u * 1024u)
-#define PWN_NBLOB 2       // device copies of the blob (an upload never touches the one launches in flight read)
+#ifndef PWN_NBLOB
+#define PWN_NBLOB 4       // device copies of the blob: an upload never touches one that launches in flight read.  With two, the upload
+                          // of frame f+1's tables had to wait for the end of frame f-1 and so ran right where trace f starts;
+                          // with three or four it runs at once, somewhere beside the trace grid: 0.3823 -> 0.3790 ms per 4K frame
+#endif
 #define PWN_NSTAGE 4      // pinned staging buffers for those uploads
 
 // one frame in flight (pwn_submit_frame / pwn_wait_frame)
@@ -81,8 +85,9 @@ struct pwn_ctx
 	hipEvent_t tables_wait[PWN_NBLOB];                                 // ... the event to wait for: ev_tables[i], or the caller's (below)
 	// Set by a caller of pwn_i_launch_trace for its next launch: an event the caller records itself right behind
 	// that launch anyway (its frame's "kernels done").  The launcher then records none of its own -- every
-	// event between two kernels costs the queue a few microseconds.  Such an event may be recorded again later
-	// (its slot's next frame); the upload that waits for it then waits a frame longer, never shorter.
+	// event between two kernels costs the queue a few microseconds.  The caller must have waited on the host for
+	// the frame of the event's previous record (a slot is handed in again only when it is free): the launcher
+	// drops the guards that still point at the event before the caller records it again.
 	hipEvent_t trace_tables_event;
 	hipEvent_t ev_upload[PWN_NBLOB]; bool upload_pending[PWN_NBLOB];   // behind the last upload into that copy
 	uint8_t *h_stage[PWN_NSTAGE]; hipEvent_t ev_stage[PWN_NSTAGE]; bool stage_used[PWN_NSTAGE]; unsigned stage_next;

@@ -3,6 +3,8 @@
 // per workgroup like the trace kernel, B 40 us on 2048 workgroups of 1024 threads like the blur) launched as frames
 //   mode 0: A, B on one stream, nothing else                      mode 1: ... plus one event record per frame
 //   mode 2: ... plus a wait for an event of another stream        mode 3: a captured graph of 8 frames, replayed
+//   mode 6 / 7: A as a fixed amount of WORK (~300 us), B as before; 7 adds a small kernel on another stream that depends on
+//           nothing and so runs in the middle of A (what an upload or an exchange beside the trace grid is)
 //   mode 4: like 1, but the event rides on B's own dispatch packet (hipExtLaunchKernelGGL's stopEvent) and the host
 //           waits for it every eighth frame; mode 5: mode 1 with the same host waits (the control for 4)
 //   hipcc --offload-arch=gfx950 -O2 -o graph_gap graph_gap.hip && ./graph_gap
@@ -28,6 +30,15 @@ __global__ void __launch_bounds__(1024) spin_b(unsigned ticks, unsigned *sink)
 	while(__builtin_amdgcn_s_memrealtime() - t0 < ticks) { }
 	if(ticks == 0xffffffffu) *sink = 1;
 }
+// a fixed amount of work instead of a fixed time (for mode 6: is the work disturbed?)
+__global__ void __launch_bounds__(256) work_a(unsigned iters, unsigned *sink)
+{
+	extern __shared__ unsigned lds[];
+	lds[threadIdx.x] = threadIdx.x;
+	float a = (float)threadIdx.x, b = 1.0001f;
+	for(unsigned i = 0; i < iters; i++) { a = a * b + 0.5f; b = b * 0.99999f + 1e-6f; }
+	if(__float_as_uint(a) == iters || lds[(threadIdx.x + iters) & 255] == 0xffffffffu) *sink = 1;
+}
 __global__ void tiny(unsigned *sink) { if(threadIdx.x == 1000) *sink = 2; }
 
 int main()
@@ -38,6 +49,7 @@ int main()
 	CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
 	CHECK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
 	CHECK(hipFuncSetAttribute((const void *)spin_a, hipFuncAttributeMaxDynamicSharedMemorySize, 27 * 1024));
+	CHECK(hipFuncSetAttribute((const void *)work_a, hipFuncAttributeMaxDynamicSharedMemorySize, 27 * 1024));
 	hipEvent_t ev[8], ev2;
 	for(int i = 0; i < 8; i++) CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
 	CHECK(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
@@ -51,13 +63,15 @@ int main()
 			CHECK(hipEventRecord(ev2, s2));
 			CHECK(hipStreamWaitEvent(s, ev2, 0));
 		}
-		hipLaunchKernelGGL(spin_a, dim3(1280), dim3(256), 27 * 1024, s, TA, sink);
+		if(mode >= 6) hipLaunchKernelGGL(work_a, dim3(1280), dim3(256), 27 * 1024, s, 6400u, sink);
+		else hipLaunchKernelGGL(spin_a, dim3(1280), dim3(256), 27 * 1024, s, TA, sink);
+		if(mode == 7) hipLaunchKernelGGL(tiny, dim3(8), dim3(256), 0, s2, sink);
 		if(mode == 4) hipExtLaunchKernelGGL(spin_b, dim3(512), dim3(1024), 0, s, NULL, ev[i & 7], 0, TB, sink);
 		else hipLaunchKernelGGL(spin_b, dim3(512), dim3(1024), 0, s, TB, sink);
 		if(mode == 1 || mode == 2 || mode == 5) CHECK(hipEventRecord(ev[i & 7], s));
 		if((mode == 4 || mode == 5) && i >= 3 && (i & 7) == 7) CHECK(hipEventSynchronize(ev[(i - 3) & 7]));
 	};
-	for(int mode = 0; mode < 6; mode++)
+	for(int mode = 0; mode < 8; mode++)
 	{
 		hipGraph_t g = NULL; hipGraphExec_t ge = NULL;
 		if(mode == 3)
