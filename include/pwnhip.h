@@ -174,7 +174,10 @@ int pwn_trace_screen_centred(pwn_ctx *ctx, const float cam[16], float sec_curren
  *                      once.  Uses the tables of the last pwn_upload_spheres /
  *                      pwn_prepare_render / level call, which may be called between
  *                      submits without waiting for anything.  PWN_EBUSY if the slot's
- *                      previous frame has not been waited for.
+ *                      previous frame has not been waited for.  (A host that is short of
+ *                      microseconds prepares the next frame's tables BEFORE it waits for the
+ *                      slot it wants to reuse: their upload runs on its own stream during that
+ *                      wait and the trace launch then queues no wait for it -- ~5 us per frame.)
  *   pwn_wait_frame     block until the slot's frame is on the host; the pointers in
  *                      *out stay valid until the next submit on that slot.
  *   pwn_frame_ready    1 / 0 without blocking.
