@@ -145,6 +145,35 @@ def test_raw_frames_and_strips():
     r.close()
 
 
+def test_ragged_large_frames_vs_oracle(oracle_lib):
+    """Frames long enough for the wave scheduler to draw its tickets in PAIRS (>= 16 units per resident wave, the
+    4K and 8K goldens' regime) at sizes that are multiples of nothing: partial units at the right and bottom edges,
+    queues of unequal length, a last pair whose second ticket is past the end.  Every pixel and depth against the
+    oracle, twice through the same context (the second launch uses the ticket set the first one cleared); with the
+    blur where the width is a multiple of 4 (the library takes POSTPROC_BLUR only then: 16-byte stores, screen.h:88)."""
+    import pwnfps_amd
+    from oracle import Oracle
+    O = Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    O.set_spheres(load_spheres("t0"))
+    for (w, h), ang in (((3001, 2003), 0.4), ((4099, 1301), -1.1), ((3004, 2002), 2.3)):
+        cam = pwnfps_amd.spawn_camera((9, 4), ang_y=ang, ang_x=0.05)
+        ob0, oz0 = O.render(w, h, cam, sec=0.3, blur=0)
+        r = _renderer(w, h)
+        r.level_load(level_path("pwnfps_level"))
+        r.set_objects(load_spheres("t0"))
+        for rep in range(2):
+            r.set_blur_passes(0)
+            sb, zb = r.trace_screen_centred(cam, 0.3)
+            assert (sb == ob0).all() and (zb.view(np.uint32) == oz0.view(np.uint32)).all(), (w, h, rep)
+        if w % 4 == 0:
+            ob1, _ = O.render(w, h, cam, sec=0.3, blur=1)
+            r.set_blur_passes(1)
+            sb, _ = r.trace_screen_centred(cam, 0.3)
+            assert (sb == ob1).all(), (w, h)
+        r.close()
+
+
 def test_campaign(oracle_lib):
     c = np.load(os.path.join(GOLD, "campaign.npz"))
     ctxs = {}
