@@ -84,6 +84,11 @@ typedef struct pwn_stats
 #define PWN_REFILL_LIMIT_DEFAULT 256
 #define PWN_OPT_WAVE_LOG     6 /* 1: every wave64 of the trace kernel stamps its start and end (two clock reads and one
                                   store per wave); pwn_get_stats then fills wave_time / kernel_span / waves */
+#define PWN_OPT_FRAME_OVERLAP 7 /* frames in flight: 1 (default) = the kernels of successive frames alternate between two compute
+                                  streams, so that the next frame's trace grid fills the CUs the current one's tail leaves idle
+                                  and its blur runs beside it; 0 = all frames on one stream, strictly one after the other.
+                                  PWN_EBUSY while frames are in flight.  Frames still complete in submission order as far as
+                                  pwn_wait_frame is concerned (every slot has its own event). */
 #define PWN_OPT_FRAME_TIMING 5 /* frames in flight: record HIP events around the trace and blur kernels of every N-th
                                   frame (pwn_frame.timed, .trace_ms ...); 1 = every frame (default), 0 = never.  An event
                                   between two kernels costs a few microseconds of pipeline */
@@ -209,8 +214,9 @@ int pwn_frame_ready(pwn_ctx *ctx, int slot);
 int pwn_read_plane(pwn_ctx *ctx, const void *d_src, void *dst, size_t bytes);
 
 /*
- * Strip forms for row tiling across GPUs (one process per GPU; the exchange
- * between them is the caller's RCCL all-gather).
+ * Strip forms: the two passes restricted to a band of rows, for callers that run their own
+ * choreography (the library's own row tiling, pwn_tiled_* below, is built from the same two
+ * launches and does the exchange between the GPUs itself: RCCL send / recv inside the library).
  * Pointers are DEVICE pointers to FULL frames (pitch = width); only rows
  * [y0,y1) are written.  Stream-ordered on `stream` (a hipStream_t, NULL =
  * default stream); they do not synchronise.
@@ -240,7 +246,8 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
  *   pwn_tiled_unique_id  rank 0: the id of the group (an ncclUniqueId for PWN_TRANSPORT_RCCL);
  *                        the host hands its 128 bytes to the other ranks (a file, a pipe, MPI ...)
  *   pwn_tiled_init       collective.  Rank r owns rows [r*per, (r+1)*per), per = ceil(h/world)
- *                        rounded up to 8 (the OpenMP loops of screen.h:63,77 split by rows).
+ *                        rounded up to 8 (the OpenMP loops of screen.h:63,77 split by rows) -- to begin with: the cuts move
+ *                        with what the rows cost (pwn_tiled_balance below).
  *                        halo_rows: pre-blur rows exchanged with each neighbour strip; < 0 = default
  *                        (depth 24: 0.002*h*24 + 2 rows, screen.h:100-102), 0 = every strip to
  *                        everybody (an all-gather).  The blur counts taps that leave the halo; a frame
@@ -274,6 +281,7 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
 #define PWN_TRANSPORT_SHM  1
 #define PWN_TILED_HOST     1
 #define PWN_TILED_SLOTS    4       /* frames a host sink holds (three in flight and the one being reused) */
+#define PWN_TILED_MAX_WORLD 64
 typedef struct pwn_tiled_frame
 {
 	const void *d_sbuf;          /* rank 0: the frame on the device, BGRA8, pitch = width; NULL elsewhere */
@@ -282,14 +290,25 @@ typedef struct pwn_tiled_frame
 	int redone;                  /* 1: a tap left the halo and the frame was repeated with whole strips */
 	int timed;                   /* PWN_OPT_FRAME_TIMING sampled this frame: */
 	float trace_ms, frame_ms;    /*   this rank's trace kernel; its trace .. blur incl. waiting for the exchange */
+	float blur_ms;               /*   its blur kernel */
+	float halo_ms, gather_ms;    /*   the two grouped exchanges on the comm stream: this frame's halo rows (G1); the gather that
+	                                  carried this frame's strips and words (G2; 0 when pwn_tiled_wait had to launch it itself) */
+	float enqueue_us;            /* host time inside pwn_tiled_submit for this frame (every frame) */
+	int y0, y1;                  /* the rows this rank traced of this frame (the cuts move: pwn_tiled_balance) */
+	uint32_t cost;               /* what they cost: sum of the trace waves' lifetimes, ticks of the GPU's 100 MHz clock */
 } pwn_tiled_frame;
 typedef struct pwn_tiled_info
 {
-	int rank, world, y0, y1, rows_per_rank, halo_rows, transport;
+	int rank, world, y0, y1, rows_per_rank, halo_rows, transport;      /* y0, y1: this rank's rows of the NEXT frame */
 	uint64_t frames, frames_redone, groups;        /* delivered frames; repeated ones; grouped exchanges launched */
 	uint64_t bytes_sent, bytes_received;           /* by this rank */
 	uint64_t bytes_to_host;                        /* host sink: copied into the host frame by this rank */
 	int host_sink;                                 /* 1: every rank delivers its strip to the host (pwn_tiled_host_sink) */
+	int max_rows;                                  /* the tallest strip a rank may be given (1.5 equal strips) */
+	int balance_every;                             /* pwn_tiled_balance */
+	int grid_reserve;                              /* workgroups the trace grid leaves free for RCCL's kernels (pwn_tiled_set_reserve) */
+	int two_streams;                               /* 1: frames alternate between two compute streams (PWN_OPT_FRAME_OVERLAP at init) */
+	uint64_t recuts;                               /* how often the cuts moved */
 } pwn_tiled_info;
 int pwn_tiled_unique_id(void *id128, int transport);
 int pwn_tiled_init(pwn_ctx *ctx, int rank, int world, const void *id128, int transport, int halo_rows);
@@ -298,6 +317,33 @@ int pwn_tiled_wait(pwn_ctx *ctx, int flags, pwn_tiled_frame *out);
 int pwn_tiled_host_sink(pwn_ctx *ctx, void *base, size_t bytes);
 int pwn_tiled_get_info(pwn_ctx *ctx, pwn_tiled_info *out);
 void pwn_tiled_shutdown(pwn_ctx *ctx);
+/*
+ * Moving cuts.  Equal strips are not equal work (the horizon band of level.txt costs 1.2-1.3x the mean strip of an
+ * 8-way tiling), and the reference's answer to that -- OpenMP's static schedule over 32-row chunks, screen.h:63-64 --
+ * is the equal split.  Here every rank's trace launch measures what its rows cost (the sum of its waves' lifetimes),
+ * the number travels to every rank with the frame's miss word, and every `every_frames` delivered frames all ranks
+ * compute the same new cuts from the same numbers: piecewise-linear cost over the rows, cut k where it reaches k / world
+ * of the total, multiples of 8 rows, every strip at least the halo and at most pwn_tiled_info.max_rows rows.  New cuts
+ * take effect with the next submitted frame; a frame in flight keeps the cuts it was traced with (exchange, blur,
+ * gather, host-sink copies, and the repeat after a missed halo all use the frame's own).
+ *   pwn_tiled_balance   collective (the same call on every rank, between frames): the period in delivered frames,
+ *                       0 = the cuts stay where they are.  Default 8 (PWN_TILED_BALANCE=k in the environment
+ *                       overrides; 0 when a strip of the equal split would be empty, or without blur).
+ *   pwn_tiled_set_cuts  collective: n = world + 1 boundaries, 0 = cuts[0] < cuts[1] < ... < cuts[world] = height,
+ *                       inner ones multiples of 8, strips within [halo, max_rows]; for the next submitted frame.
+ *   pwn_tiled_get_cuts  the cuts of the next frame (world + 1 ints) and, if cost != NULL, every rank's cost word of
+ *                       the last delivered frame (world words); returns world + 1.
+ *   pwn_tiled_set_reserve  this rank, between frames: workgroups the persistent trace grid leaves free so that
+ *                       RCCL's send / recv kernels find a CU to start on (default 16 with the RCCL transport, 0 = fill
+ *                       every CU; PWN_TILED_RESERVE in the environment sets the default).
+ */
+int pwn_tiled_balance(pwn_ctx *ctx, int every_frames);
+int pwn_tiled_set_cuts(pwn_ctx *ctx, const int *cuts, int n);
+int pwn_tiled_get_cuts(pwn_ctx *ctx, int *cuts, uint32_t *cost);
+int pwn_tiled_set_reserve(pwn_ctx *ctx, int workgroups);
+/* the re-cut rule by itself (no context, no device): cuts[world + 1] and the strips' costs in, out[world + 1]; returns 1
+   if the cuts moved, 0 if they stay (balanced within 2 %, a zero cost, constraints that cannot be met) */
+int pwn_tiled_recut(const int *cuts, const uint32_t *cost, int world, int height, int min_rows, int max_rows, int *out);
 
 /* screen_upscale (screen.h:126-149): replicate every pixel scale x scale into
    a surface of `pitch_bytes` per row (SDL_Surface->pitch / ->pixels).

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("PWNHIP_LIB") or os.path.join(_HERE, "libpwnhip.so")
 PWN_OK, PWN_EINVAL, PWN_ENODEV, PWN_ENOMEM, PWN_EIO, PWN_EHIP, PWN_ENOLEVEL, PWN_ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
 PWN_EBUSY, PWN_ENOTSUP = -8, -9
 PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER, PWN_OPT_REFILL_LIMIT, PWN_OPT_FRAME_TIMING, PWN_OPT_WAVE_LOG = 1, 2, 3, 4, 5, 6
+PWN_OPT_FRAME_OVERLAP = 7
 PWN_SCHED_UNITS, PWN_SCHED_REFILL = 0, 1
 PWN_MAX_SLOTS = 4
 PWN_FRAME_SBUF, PWN_FRAME_ZBUF, PWN_FRAME_SURFACE = 1, 2, 4
@@ -45,19 +46,23 @@ class Frame(C.Structure):
 
 class TiledFrame(C.Structure):
     _fields_ = [("d_sbuf", C.c_void_p), ("sbuf", C.c_void_p), ("seq", C.c_uint64), ("redone", C.c_int),
-                ("timed", C.c_int), ("trace_ms", C.c_float), ("frame_ms", C.c_float)]
+                ("timed", C.c_int), ("trace_ms", C.c_float), ("frame_ms", C.c_float), ("blur_ms", C.c_float),
+                ("halo_ms", C.c_float), ("gather_ms", C.c_float), ("enqueue_us", C.c_float),
+                ("y0", C.c_int), ("y1", C.c_int), ("cost", C.c_uint32)]
 
 
 class TiledInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("rank", "world", "y0", "y1", "rows_per_rank", "halo_rows", "transport")] + \
                [(n, C.c_uint64) for n in ("frames", "frames_redone", "groups", "bytes_sent", "bytes_received", "bytes_to_host")] + \
-               [("host_sink", C.c_int)]
+               [(n, C.c_int) for n in ("host_sink", "max_rows", "balance_every", "grid_reserve", "two_streams")] + \
+               [("recuts", C.c_uint64)]
 
 
 PWN_TILED_ID_BYTES = 128
 PWN_TRANSPORT_RCCL, PWN_TRANSPORT_SHM = 0, 1
 PWN_TILED_HOST = 1
 PWN_TILED_SLOTS = 4
+PWN_TILED_MAX_WORLD = 64
 
 # every symbol include/pwnhip.h declares: (name, restype, argtypes)
 _vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
@@ -95,6 +100,11 @@ ABI = [
     ("pwn_tiled_host_sink", _i, [_vp, _vp, C.c_size_t]),
     ("pwn_tiled_get_info", _i, [_vp, C.POINTER(TiledInfo)]),
     ("pwn_tiled_shutdown", None, [_vp]),
+    ("pwn_tiled_balance", _i, [_vp, _i]),
+    ("pwn_tiled_set_cuts", _i, [_vp, _vp, _i]),
+    ("pwn_tiled_get_cuts", _i, [_vp, _vp, _vp]),
+    ("pwn_tiled_set_reserve", _i, [_vp, _i]),
+    ("pwn_tiled_recut", _i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     ("pwn_screen_upscale", _i, [_vp, _vp, _i, _i, _vp]),
     ("pwn_upscale_device", _i, [_vp, _vp, _i, _i, _vp, _vp]),
     ("pwn_get_stats", _i, [_vp, C.POINTER(Stats)]),

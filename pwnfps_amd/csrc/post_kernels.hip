@@ -26,6 +26,11 @@ struct pwn_blur_params
 	// repeats the strip with the whole frame present).  miss == NULL: every row is valid.
 	int avail_y0, avail_y1;
 	uint32_t *miss;
+	int tile_h;                    // rows of a workgroup's tile: 32, 16 or 8 (pwn_launch_blur picks it by the size of the launch)
+	// row tiling with moving cuts: the trace launch in front of this one on the stream added up what its strip cost
+	// in *cost_acc (pwn_trace_params.cost_word); this launch moves the sum to *cost_out, the word that travels with
+	// the frame, and clears the accumulator for the stream's next trace.  Both NULL otherwise.
+	uint32_t *cost_acc, *cost_out;
 };
 
 __device__ __forceinline__ uint32_t avg_u8x4(uint32_t a, uint32_t b)
@@ -130,9 +135,10 @@ pwn_blur_kernel(pwn_blur_params P)
 #ifndef BLUR_TW
 #define BLUR_TW 128
 #endif
-#ifndef BLUR_TH
-#define BLUR_TH 32
-#endif
+// Tile height BLUR_TH is a template parameter: 32 rows (1024 threads) for whole frames -- the least staging per
+// output pixel --, 16 or 8 rows for the short launches of a row tiling (a 272-row strip of a 4K frame is 270 tiles
+// of 32 rows for 256 CUs: one round of workgroups that each run their two phases, staging then taps, with
+// nothing to overlap them with; smaller tiles give every CU several workgroups in different phases).
 #ifndef BLUR_HALO
 #define BLUR_HALO 16        // measured 8 / 16 / 24 / 32: 45.6 / 45.4 / 46.6 / 48.0 us at 4K (less staging beats fewer fall-backs)
 #endif
@@ -141,7 +147,7 @@ pwn_blur_kernel(pwn_blur_params P)
 #define BLUR_PITCH (BLUR_LW + 4)                   // words; +4 keeps rows 16-B aligned and off one bank
 #define BLUR_THREADS (BLUR_TW / 4 * BLUR_TH)       // one thread per 4-pixel group
 
-template<bool CHECK>
+template<bool CHECK, int BLUR_TH>
 __global__ void __launch_bounds__(BLUR_THREADS)
 pwn_blur_tiled_kernel(pwn_blur_params P)
 {
@@ -151,6 +157,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	// contiguous eighth of the tiles in row-major order: the halo re-reads then
 	// hit that XCD's L2 instead of each going out to the Infinity Cache.
 	// (Placement only changes speed, never results.)
+	if(P.cost_acc != NULL && blockIdx.x == 0 && threadIdx.x == 0) { *P.cost_out = *P.cost_acc; *P.cost_acc = 0u; }
 	const int tiles_x = (P.w + BLUR_TW - 1) / BLUR_TW;
 	const int ntiles = tiles_x * ((P.y1 - P.y0 + BLUR_TH - 1) / BLUR_TH);
 	const int per_xcd = (ntiles + 7) >> 3;
@@ -232,13 +239,10 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	if(CHECK) { if(missed) atomicAdd(P.miss, 1u); }
 }
 
-extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream)
+template<bool CHECK, int TH>
+static hipError_t launch_blur_variant(const pwn_blur_params *P, hipStream_t stream)
 {
-	if(P->groups <= 0 || P->y1 <= P->y0) return hipSuccess;
-#ifdef PWN_BLUR_PLAIN
-	dim3 grid((P->groups + 255) / 256, P->y1 - P->y0);
-	hipLaunchKernelGGL(pwn_blur_kernel, grid, dim3(256), 0, stream, *P);
-#else
+	const int BLUR_TH = TH;
 	const size_t lds = (size_t)BLUR_PITCH * BLUR_LH * sizeof(uint32_t);
 	static bool lds_mark[64];
 	static std::mutex lds_lock;      // contexts of several threads share the per-function attribute
@@ -249,18 +253,33 @@ extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stre
 		bool &lds_set = lds_mark[dev & 63];
 		if(!lds_set)
 		{
-			hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-			if(e == hipSuccess) e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<CHECK, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 			if(e != hipSuccess) return e;
 			lds_set = true;
 		}
 	}
 	const int ntiles = ((P->w + BLUR_TW - 1) / BLUR_TW) * ((P->y1 - P->y0 + BLUR_TH - 1) / BLUR_TH);
 	dim3 grid(((ntiles + 7) / 8) * 8);
-	if(P->miss != NULL) hipLaunchKernelGGL(pwn_blur_tiled_kernel<true>, grid, dim3(BLUR_THREADS), lds, stream, *P);
-	else hipLaunchKernelGGL(pwn_blur_tiled_kernel<false>, grid, dim3(BLUR_THREADS), lds, stream, *P);
-#endif
+	hipLaunchKernelGGL((pwn_blur_tiled_kernel<CHECK, TH>), grid, dim3(BLUR_THREADS), lds, stream, *P);
 	return hipGetLastError();
+}
+
+extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream)
+{
+	if(P->groups <= 0 || P->y1 <= P->y0) return hipSuccess;
+#ifdef PWN_BLUR_PLAIN
+	dim3 grid((P->groups + 255) / 256, P->y1 - P->y0);
+	hipLaunchKernelGGL(pwn_blur_kernel, grid, dim3(256), 0, stream, *P);
+	return hipGetLastError();
+#else
+	const bool check = P->miss != NULL;
+	switch(P->tile_h)
+	{
+		case 8: return check ? launch_blur_variant<true, 8>(P, stream) : launch_blur_variant<false, 8>(P, stream);
+		case 16: return check ? launch_blur_variant<true, 16>(P, stream) : launch_blur_variant<false, 16>(P, stream);
+		default: return check ? launch_blur_variant<true, 32>(P, stream) : launch_blur_variant<false, 32>(P, stream);
+	}
+#endif
 }
 
 // -------------------------------------------------------------- upscale ----

@@ -64,6 +64,10 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	// workgroups per CU of the persistent grid
 	c->dbg_force_hasw = getenv("PWN_DBG_FORCE_HASW") != NULL;
 	c->dbg_blocks_per_cu = 0;
+	c->dbg_late_rounds = -1;
+	c->dbg_blur_th = 0;
+	if(const char *e = getenv("PWN_DBG_BLUR_TH")) c->dbg_blur_th = atoi(e);
+	if(const char *e = getenv("PWN_DBG_LATE_ROUNDS")) c->dbg_late_rounds = atoi(e);
 	if(const char *e = getenv("PWN_DBG_BLOCKS_PER_CU")) { int v = atoi(e); if(v > 0) c->dbg_blocks_per_cu = v; }
 	c->blob_cur = 0; c->blob_dirty = true; c->off_sph = 0; c->stage_next = 0; c->up_stream = NULL;
 	for(int i = 0; i < PWN_NBLOB; i++)
@@ -74,13 +78,15 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	}
 	for(int i = 0; i < PWN_NSTAGE; i++) { c->h_stage[i] = NULL; c->ev_stage[i] = NULL; c->stage_used[i] = false; }
 	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0;
-	c->trace_clear_word = NULL; c->trace_tables_event = NULL; c->grid_reserve = 0;
+	c->trace_clear_word = NULL; c->trace_cost_word = NULL; c->trace_tables_event = NULL; c->grid_reserve = 0;
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 8; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
-	c->stream = NULL; c->copy_stream = NULL;
+	c->stream = NULL; c->copy_stream = NULL; c->stream2 = NULL; c->d_pre2 = NULL;
+	c->frame_overlap = 1; c->last_frame_done = NULL; c->serialize_next = false; c->last_frame_stream = NULL;
+	if(const char *e = getenv("PWN_FRAME_OVERLAP")) c->frame_overlap = atoi(e) != 0;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));
-	c->frame_timing = 1; c->wave_log_on = 0; c->d_wave_log = NULL;
+	c->frame_timing = 1; c->wave_log_on = 0; c->d_wave_log = NULL; c->wave_log_cap = 0;
 	c->nslots = 0; c->frame_flags = 0; c->frame_scale = 1; c->frame_pitch = 0; c->frame_seq = 0;
 	memset(c->slot, 0, sizeof(c->slot));
 	c->tiled = NULL;
@@ -105,8 +111,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		   hipMalloc((void **)&c->d_out, n * 4) != hipSuccess ||
 		   hipMalloc((void **)&c->d_z, n * 4) != hipSuccess ||
 		   hipMalloc((void **)&c->d_counters, 24 * sizeof(unsigned long long)) != hipSuccess ||
-		   hipMalloc((void **)&c->d_tickets, 2 * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
-		   hipMemset(c->d_tickets, 0, 2 * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
+		   hipMalloc((void **)&c->d_tickets, PWN_TICKET_SETS * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
+		   hipMemset(c->d_tickets, 0, PWN_TICKET_SETS * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
 		   hipMalloc((void **)&c->d_skip, sizeof(uint2) * (size_t)(width / 4 + 1)) != hipSuccess) { rc = PWN_ENOMEM; break; }
 		for(int i = 0; i < PWN_NBLOB && rc == PWN_OK; i++)
 			if(hipMalloc((void **)&c->d_blob[i], PWN_BLOB_MAX) != hipSuccess) rc = PWN_ENOMEM;
@@ -117,7 +123,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		   hipMemset(c->d_out, 0, n * 4) != hipSuccess) { rc = PWN_EHIP; break; }
 		if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
 		   hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-		   hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+		   hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess ||
+		   hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
 		for(int i = 0; i < 4; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { rc = PWN_EHIP; break; }
 		for(int i = 0; i < PWN_NBLOB && rc == PWN_OK; i++)
 			if(hipEventCreateWithFlags(&c->ev_tables[i], hipEventDisableTiming) != hipSuccess ||
@@ -149,6 +156,7 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 	(void)hipSetDevice(c->device);
 	if(c->tiled) pwn_tiled_destroy(c);
 	if(c->stream) (void)hipStreamSynchronize(c->stream);
+	if(c->stream2) (void)hipStreamSynchronize(c->stream2);
 	if(c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
 	if(c->up_stream) (void)hipStreamSynchronize(c->up_stream);
 	(void)hipDeviceSynchronize();        // strip forms run on the caller's streams
@@ -166,9 +174,10 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 		if(c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
 	}
 	if(c->stream) (void)hipStreamDestroy(c->stream);
+	if(c->stream2) (void)hipStreamDestroy(c->stream2);
 	if(c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	if(c->up_stream) (void)hipStreamDestroy(c->up_stream);
-	(void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z);
+	(void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z); (void)hipFree(c->d_pre2);
 	(void)hipFree(c->d_wave_log);
 	(void)hipFree(c->d_skip); (void)hipFree(c->d_counters); (void)hipFree(c->d_tickets); (void)hipFree(c->d_scratch);
 	delete c;
@@ -179,12 +188,21 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 	if(c == NULL) return PWN_EINVAL;
 	switch(option)
 	{
-		case PWN_OPT_BLUR_PASSES: if(value < 0 || value > 16) return PWN_EINVAL; c->blur_passes = value; return PWN_OK;
+		case PWN_OPT_BLUR_PASSES:
+			if(value < 0 || value > 16) return PWN_EINVAL;
+			// the row tiling fixed its halo, planes and choreography on this at pwn_tiled_init; frames in flight were
+			// enqueued with it
+			if(c->tiled != NULL) return PWN_EBUSY;
+			for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
+			c->blur_passes = value; return PWN_OK;
 		case PWN_OPT_COUNTERS: c->counters_on = value ? 1 : 0; return PWN_OK;
 		case PWN_OPT_SCHEDULER: if(value < 0 || value > PWN_SCHED_REFILL) return PWN_EINVAL; c->scheduler = value; return PWN_OK;
 		case PWN_OPT_WAVE_LOG: c->wave_log_on = value ? 1 : 0; return PWN_OK;
 		case PWN_OPT_FRAME_TIMING: if(value < 0) return PWN_EINVAL; c->frame_timing = value; return PWN_OK;
 		case PWN_OPT_REFILL_LIMIT: if(value < 1 || value > 64000) return PWN_EINVAL; c->refill_limit = value; return PWN_OK;
+		case PWN_OPT_FRAME_OVERLAP:
+			for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
+			c->frame_overlap = value ? 1 : 0; return PWN_OK;
 	}
 	return PWN_EINVAL;
 }
@@ -516,6 +534,8 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 {
 	uint32_t *clear_word = c->trace_clear_word;            // for this launch only
 	c->trace_clear_word = NULL;
+	uint32_t *cost_word = c->trace_cost_word;
+	c->trace_cost_word = NULL;
 	hipEvent_t caller_event = c->trace_tables_event;       // (pwn_internal.h)
 	c->trace_tables_event = NULL;
 	if(!c->have_level) return PWN_ENOLEVEL;
@@ -543,19 +563,14 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	}
 	P.counters = c->d_counters;
 	P.clear_word = clear_word;
-	// PWN_OPT_WAVE_LOG: every wave of this launch writes its start and end time (at most 8 blocks of 4 waves per CU)
+	P.cost_word = cost_word;
 	P.wave_log = NULL;
-	if(c->wave_log_on)
-	{
-		const size_t bytes = ((size_t)c->num_cus * 8 * 4 + 1) * 16;       // entry 0: the number of waves that logged
-		if(c->d_wave_log == NULL) HIPCHK(c, hipMalloc((void **)&c->d_wave_log, bytes));
-		HIPCHK(c, hipMemsetAsync(c->d_wave_log, 0, bytes, stream));
-		P.wave_log = c->d_wave_log;
-	}
-	// the kernel's work queues: this launch counts in one set and clears the other for the next
-	// launch of this context (stream-ordered behind it, include/pwnhip.h)
-	P.tickets = c->d_tickets + (c->ticket_set & 1u) * PWN_QUEUES * PWN_QUEUE_STRIDE;
-	P.tickets_next = c->d_tickets + ((c->ticket_set + 1u) & 1u) * PWN_QUEUES * PWN_QUEUE_STRIDE;
+	// the kernel's work queues: four sets; launch n counts in set n mod 4 and clears set (n + 2) mod 4, the one of
+	// the launch after the next.  Launches of a context are stream-ordered (include/pwnhip.h) -- on ONE stream, or
+	// alternating between the two compute streams of the frames in flight (pwn_submit_frame), where launch n + 2
+	// is behind launch n on its stream and launch n + 1 may run beside it with a set of its own.
+	P.tickets = c->d_tickets + (c->ticket_set % PWN_TICKET_SETS) * PWN_QUEUES * PWN_QUEUE_STRIDE;
+	P.tickets_next = c->d_tickets + ((c->ticket_set + 2u) % PWN_TICKET_SETS) * PWN_QUEUES * PWN_QUEUE_STRIDE;
 	// ordinary cameras (rows x,y,z with w = 0, position w = 1: mat4_iden + rotations,
 	// main.c:61-64) never put anything but 0 / 1 into the w lanes; the kernel has a
 	// 3-lane specialisation for them that is arithmetically identical
@@ -592,7 +607,34 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	// to start with (5 waves x 96 VGPRs of 512 per SIMD), and the exchange would only run in the gaps between the
 	// kernels; a few workgroups fewer leave room on some CUs (pwn_tiled.cpp sets the number)
 	if(c->grid_reserve > 0 && grid > 2 * c->grid_reserve) grid -= c->grid_reserve;
-	if(grid > P.tiles_total) grid = P.tiles_total;
+	// fewer units than resident waves (a 320 x 240 frame is 1200 units for 5120 waves): one unit per wave, a
+	// workgroup per four of them -- a workgroup whose waves find nothing still copies the tables into LDS
+	{
+		const int wg_waves = 4;          // PWN_BLOCK / 64
+		if(!refill && grid > (P.tiles_total + wg_waves - 1) / wg_waves) grid = (P.tiles_total + wg_waves - 1) / wg_waves;
+		if(grid > P.tiles_total) grid = P.tiles_total;
+	}
+	// a wave asks for its next unit ahead of the current one while more tickets than this are left in its queue
+	// (trace_kernel.hip): 0 = always ahead.  Measured (profiles/r3_strips/late_draws.txt): drawing late -- no
+	// commitment to a second unit near the end of the launch -- loses everywhere, because a draw is not ~2 us behind
+	// other waves' work but ~6 us that the SIMD's waves, which run in step, all wait out together.
+	P.late_rounds = 0u;
+	if(c->dbg_late_rounds >= 0) P.late_rounds = (uint32_t)c->dbg_late_rounds;
+	if(c->dbg_late_rounds == -2) P.late_rounds = (uint32_t)((grid * 4 + (int)PWN_QUEUES - 1) / (int)PWN_QUEUES);
+	// PWN_OPT_WAVE_LOG: every wave of this launch writes its start and end time; entry 0 is unused, entry
+	// 1 + 4 * workgroup + SIMD is a wave's (the buffer follows the grid of the launch)
+	if(c->wave_log_on)
+	{
+		const size_t entries = (size_t)grid * 4 + 1;
+		if(entries > c->wave_log_cap)
+		{
+			if(c->d_wave_log) { HIPCHK(c, hipStreamSynchronize(stream)); (void)hipFree(c->d_wave_log); c->d_wave_log = NULL; c->wave_log_cap = 0; }
+			HIPCHK(c, hipMalloc((void **)&c->d_wave_log, entries * 16));
+			c->wave_log_cap = entries;
+		}
+		HIPCHK(c, hipMemsetAsync(c->d_wave_log, 0, c->wave_log_cap * 16, stream));
+		P.wave_log = c->d_wave_log;
+	}
 	if(refill) HIPCHK(c, pwn_launch_trace_refill(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	else HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	c->ticket_set++;                     // only a launch that went out has cleared the other set
@@ -616,7 +658,7 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 }
 
 int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream,
-	int avail_y0, int avail_y1, uint32_t *d_miss)
+	int avail_y0, int avail_y1, uint32_t *d_miss, uint32_t *d_cost_acc, uint32_t *d_cost_out)
 {
 	if((c->w & 3) != 0) return PWN_EINVAL; // screen.h:88,117: aligned 16-B store per group
 	pwn_blur_params B;
@@ -624,6 +666,15 @@ int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const f
 	B.groups = c->w / 4;
 	B.pre = d_pre; B.zbuf = d_z; B.out = d_out; B.skip = c->d_skip;
 	B.avail_y0 = avail_y0; B.avail_y1 = avail_y1; B.miss = d_miss;
+	B.cost_acc = d_cost_acc; B.cost_out = d_cost_out;
+	// rows per workgroup tile (post_kernels.hip): 32 while that still gives every CU a few workgroups, less for
+	// the short launches of a row tiling
+	{
+		const int tiles_x = (c->w + 127) / 128, rows = y1 - y0;
+		B.tile_h = 32;
+		if(tiles_x * ((rows + 31) / 32) < 4 * c->num_cus) B.tile_h = 16;        // (8 rows: no better than 16 on a 272-row strip, 11.5 against 10.7 us)
+		if(c->dbg_blur_th == 8 || c->dbg_blur_th == 16 || c->dbg_blur_th == 32) B.tile_h = c->dbg_blur_th;
+	}
 	HIPCHK(c, pwn_launch_blur(&B, stream));
 	return PWN_OK;
 }
@@ -640,7 +691,7 @@ extern "C" int pwn_blur_rows_device(pwn_ctx *c, int y0, int y1, const void *d_pr
 {
 	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || y0 < 0 || y1 > c->h || y0 > y1 || d_pre == d_out) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
-	return pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream, 0, 0, NULL);
+	return pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream, 0, 0, NULL, NULL, NULL);
 }
 
 extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const void *d_pre, const void *d_zbuf, void *d_out,
@@ -650,7 +701,7 @@ extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const vo
 	   d_pre == d_out || avail_y0 > avail_y1) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	return pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream,
-		avail_y0, avail_y1, (uint32_t *)d_miss);
+		avail_y0, avail_y1, (uint32_t *)d_miss, NULL, NULL);
 }
 
 extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float sec, uint32_t *sbuf, float *zbuf)
@@ -660,6 +711,10 @@ extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float s
 	(void)hipSetDevice(c->device);
 	size_t n = (size_t)c->w * (size_t)c->h;
 	hipStream_t s = c->stream;
+	// behind the frames in flight, whichever compute stream their kernels are on
+	if(c->last_frame_done != NULL && c->last_frame_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->last_frame_done, 0));
+	c->last_frame_done = NULL;       // (this call ends with the stream empty)
+	c->serialize_next = false;
 	HIPCHK(c, hipEventRecord(c->ev[0], s));
 	// trace into d_pre; with blur on, d_pre plays tsbuf and d_out plays sbuf
 	// (the memcpy of screen.h:75 becomes a pointer swap per pass)
@@ -669,7 +724,7 @@ extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float s
 	HIPCHK(c, hipEventRecord(c->ev[1], s));
 	for(int p = 0; p < c->blur_passes; p++)
 	{
-		rc = pwn_i_launch_blur(c, 0, c->h, cur, c->d_z, other, s, 0, 0, NULL);
+		rc = pwn_i_launch_blur(c, 0, c->h, cur, c->d_z, other, s, 0, 0, NULL, NULL, NULL);
 		if(rc != PWN_OK) return rc;
 		uint32_t *t = cur; cur = other; other = t;
 	}
@@ -710,8 +765,10 @@ static void frames_release(pwn_ctx *c)
 	if(c->nslots > 0)
 	{
 		if(c->stream) (void)hipStreamSynchronize(c->stream);
+		if(c->stream2) (void)hipStreamSynchronize(c->stream2);
 		for(int i = 0; i < PWN_NBLOB; i++) c->tables_in_use[i] = false;
 	}
+	c->last_frame_done = NULL; c->serialize_next = false;       // (a slot's event, destroyed below)
 	for(int i = 0; i < PWN_MAX_SLOTS; i++) slot_release(c->slot[i]);
 	c->nslots = 0;
 }
@@ -728,6 +785,7 @@ extern "C" int pwn_frames_config(pwn_ctx *c, int nslots, int flags, int scale, i
 	else { scale = 1; pitch_bytes = 0; }
 	(void)hipSetDevice(c->device);
 	for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
+	if(pwn_tiled_busy(c)) return PWN_EBUSY;            // (frames_release drops the guards of the tables their launches read)
 	frames_release(c);
 	const size_t n = (size_t)c->w * (size_t)c->h;
 	const size_t surf_bytes = (size_t)pitch_bytes * (size_t)c->h * (size_t)scale;
@@ -763,31 +821,52 @@ extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int 
 	if(sl.in_flight) return PWN_EBUSY;
 	(void)hipSetDevice(c->device);
 	const size_t n = (size_t)c->w * (size_t)c->h;
-	// Kernels of all frames on the compute stream, one after the other; the copies to the host on the
-	// copy stream behind their frame's last kernel.  (Blur and sink of frame i on a stream of their own,
-	// beside the trace of frame i+1, were measured: 0.4433 against 0.4429 ms per 4K frame -- the
-	// persistent trace grid leaves them no room and then starts late itself.  Every event between two
-	// kernels costs a few microseconds of pipeline, so only the ones somebody reads are recorded.)
-	hipStream_t s = c->stream;
+	// The kernels of a frame go one after the other on a compute stream, the copies to the host on the copy
+	// stream behind their frame's last kernel.  Frames ALTERNATE between two compute streams (PWN_OPT_FRAME_OVERLAP,
+	// the default): the trace grid of frame f+1 moves onto the CUs as the waves of frame f's grid run out of units
+	// and leave, and the blur of frame f runs beside it -- what a single queue leaves idle in the tail of every
+	// launch (mean wave residency 0.93 at 4K, 0.65 on a strip of an 8-way tiling).  For that a frame has its own
+	// pre-blur plane (by parity), its own set of work-queue counters (four sets, pwn_i_launch_trace) and its own
+	// copy of the tables if they changed (PWN_NBLOB).  (Blur and sink of frame i on a stream of their own beside the
+	// trace of frame i+1 -- the kernels of ONE frame split over two queues -- measured nothing: 0.4433 against
+	// 0.4429 ms per 4K frame.)  Every event between two kernels costs a few microseconds of pipeline, so only the
+	// ones somebody reads are recorded.
+	const bool counted = c->counters_on || c->wave_log_on;           // one set of counters: no second grid beside a counted one
+	const bool overlap = c->frame_overlap && c->nslots >= 2 && !counted && c->blur_passes <= 1;
+	const int par = overlap ? (int)(c->frame_seq & 1u) : 0;
+	hipStream_t s = par ? c->stream2 : c->stream;
+	if(par && c->d_pre2 == NULL && c->blur_passes > 0)
+	{
+		HIPCHK(c, hipMalloc((void **)&c->d_pre2, n * 4));
+		HIPCHK(c, hipMemset(c->d_pre2, 0, n * 4));
+	}
+	uint32_t *pre = par ? c->d_pre2 : c->d_pre;
 	// timing events: on every frame_timing-th frame (each event between two kernels is a few
-	// microseconds of pipeline: 0.428 against 0.417 ms per 4K frame with all frames timed)
+	// microseconds of pipeline: 0.428 against 0.417 ms per 4K frame with all frames timed).  A timed frame runs
+	// ALONE: it starts when the frame before it is done and the frame after it starts when it is done, so that its
+	// durations are those of the kernels and not of two grids sharing the chip (pwn_frame.trace_ms is what the
+	// bench line's roofline is defined on).
 	const bool timing = c->frame_timing > 0 && (c->frame_seq % (uint64_t)c->frame_timing) == 0;
+	if(c->last_frame_done != NULL && c->last_frame_stream != s && (!overlap || timing || c->serialize_next))
+		HIPCHK(c, hipStreamWaitEvent(s, c->last_frame_done, 0));
+	c->serialize_next = timing && overlap;
 	if(timing) HIPCHK(c, hipEventRecord(sl.ev_k[0], s));
 	// the last pass writes into the slot's own plane, which is what the copy stream reads while
 	// the next frame's kernels reuse the context's d_pre / d_out
-	uint32_t *cur = c->blur_passes > 0 ? c->d_pre : sl.d_out;
+	uint32_t *cur = c->blur_passes > 0 ? pre : sl.d_out;
 	c->trace_tables_event = sl.ev_k[2];        // recorded below, behind the frame's last kernel
 	int rc = pwn_i_launch_trace(c, cam, sec, 0, c->h, cur, sl.d_z, s);
 	if(rc != PWN_OK) return rc;
 	if(timing) HIPCHK(c, hipEventRecord(sl.ev_k[1], s));
 	for(int p = 0; p < c->blur_passes; p++)
 	{
-		uint32_t *dst = (p == c->blur_passes - 1) ? sl.d_out : (cur == c->d_pre ? c->d_out : c->d_pre);
-		rc = pwn_i_launch_blur(c, 0, c->h, cur, sl.d_z, dst, s, 0, 0, NULL);
+		uint32_t *dst = (p == c->blur_passes - 1) ? sl.d_out : (cur == c->d_pre ? c->d_out : c->d_pre);      // (several passes: one stream)
+		rc = pwn_i_launch_blur(c, 0, c->h, cur, sl.d_z, dst, s, 0, 0, NULL, NULL, NULL);
 		if(rc != PWN_OK) { (void)hipEventRecord(sl.ev_k[2], s); return rc; }     // (the trace launch counts on this event)
 		cur = dst;
 	}
 	HIPCHK(c, hipEventRecord(sl.ev_k[2], s));
+	c->last_frame_done = sl.ev_k[2]; c->last_frame_stream = s;
 	hipEvent_t last = sl.ev_k[2];
 	if(c->frame_flags & PWN_FRAME_SURFACE)
 	{
@@ -874,7 +953,7 @@ extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 	}
 	if(c->wave_log_on && c->d_wave_log != NULL)
 	{
-		std::vector<unsigned long long> log(((size_t)c->num_cus * 8 * 4 + 1) * 2);
+		std::vector<unsigned long long> log(c->wave_log_cap * 2);
 		HIPCHK(c, hipMemcpy(log.data(), c->d_wave_log, log.size() * 8, hipMemcpyDeviceToHost));
 		unsigned long long sum = 0, first = ~0ull, last = 0, n = 0;
 		for(size_t i = 2; i + 1 < log.size(); i += 2)

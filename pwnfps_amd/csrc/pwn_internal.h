@@ -19,6 +19,8 @@ struct pwn_blur_params
 	const uint2 *skip;
 	int avail_y0, avail_y1;
 	uint32_t *miss;
+	int tile_h;
+	uint32_t *cost_acc, *cost_out;
 };
 
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
@@ -42,6 +44,7 @@ extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out
                           // of frame f+1's tables had to wait for the end of frame f-1 and so ran right where trace f starts;
                           // with three or four it runs at once, somewhere beside the trace grid: 0.3823 -> 0.3790 ms per 4K frame
 #endif
+#define PWN_TICKET_SETS 4u  // launch n counts in set n mod 4 and clears set (n + 2) mod 4 (pwn_i_launch_trace)
 #define PWN_NSTAGE 4      // pinned staging buffers for those uploads
 
 // one frame in flight (pwn_submit_frame / pwn_wait_frame)
@@ -101,14 +104,22 @@ struct pwn_ctx
 	float *d_z;
 	uint2 *d_skip;                   // blur LCG skip-ahead, w/4 entries
 	unsigned long long *d_counters;
-	unsigned long long *d_wave_log; int wave_log_on;   // PWN_OPT_WAVE_LOG
+	unsigned long long *d_wave_log; int wave_log_on; size_t wave_log_cap;   // PWN_OPT_WAVE_LOG; entries (16 B) allocated
 	bool dbg_force_hasw; int dbg_blocks_per_cu;      // PWN_DBG_* hooks, read at pwn_init
+	int dbg_blur_th;                 // PWN_DBG_BLUR_TH: tile height of every blur launch (8 / 16 / 32), 0 = the launcher's choice
+	int dbg_late_rounds;             // PWN_DBG_LATE_ROUNDS: pwn_trace_params.late_rounds for every launch (experiments), -1 = the launcher's choice
 	int grid_reserve;                // workgroups the persistent trace grid leaves free (row tiling over RCCL), else 0
+	uint32_t *trace_cost_word;       // likewise: pwn_trace_params.cost_word for the next launch
 	uint32_t *trace_clear_word;      // set by a caller of pwn_i_launch_trace for its next launch: see pwn_trace_params.clear_word
-	uint32_t *d_tickets; unsigned ticket_set;  // two sets of work-queue counters of the trace kernel, used alternately
+	uint32_t *d_tickets; unsigned ticket_set;  // PWN_TICKET_SETS sets of work-queue counters of the trace kernel, used in turn
 	uint32_t *d_scratch; size_t scratch_cap;   // upscale / probe staging
 
 	hipStream_t stream;              // compute
+	hipStream_t stream2;             // frames in flight alternate between `stream` and this one (PWN_OPT_FRAME_OVERLAP)
+	uint32_t *d_pre2;                // the pre-blur plane of the frames on stream2 (allocated with the first of them)
+	int frame_overlap;               // PWN_OPT_FRAME_OVERLAP
+	hipEvent_t last_frame_done; hipStream_t last_frame_stream;   // "kernels done" of the frame submitted last, and its stream
+	bool serialize_next;             // the next frame starts behind last_frame_done (the last one was a timed frame, which runs alone)
 	hipStream_t copy_stream;         // frames in flight: D2H of finished frames
 	hipEvent_t ev[4];
 	pwn_stats stats;
@@ -129,5 +140,6 @@ struct pwn_ctx
 // pwn_api.cpp internals used by pwn_tiled.cpp
 int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y1, uint32_t *d_sbuf, float *d_zbuf, hipStream_t stream);
 int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream,
-	int avail_y0, int avail_y1, uint32_t *d_miss);
+	int avail_y0, int avail_y1, uint32_t *d_miss, uint32_t *d_cost_acc, uint32_t *d_cost_out);
 void pwn_tiled_destroy(pwn_ctx *c);
+bool pwn_tiled_busy(pwn_ctx *c);        // frames of the row tiling in flight

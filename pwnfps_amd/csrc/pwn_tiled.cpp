@@ -223,27 +223,46 @@ struct shm_transport : pwn_transport
 
 // ---------------------------------------------------------------- state ----
 #define NSLOT 4          // buffer sets: three frames in flight and the one being reused
+#define MAXW PWN_TILED_MAX_WORLD
 struct pwn_tiled
 {
-	int rank, world, per, y0, y1;
+	int rank, world, per;
+	int max_rows;                       // the tallest strip a rank may be given (what the shared-memory mailboxes are sized for)
+	// Strip r = rows [cuts[r], cuts[r + 1]): `cuts` for the next submitted frame, `fcuts[s]` as used for the frame in
+	// slot s -- the cuts move (pwn_tiled_balance), and a frame is exchanged, blurred, gathered and, after a missed
+	// halo, repeated with the cuts it was traced with.  Every rank holds the same numbers for the same frame.
+	int cuts[MAXW + 1], fcuts[NSLOT][MAXW + 1];
+	int want_halo;                      // the halo asked for at init; moving cuts keep every strip at least this tall
 	int halo;                           // rows exchanged with each neighbour; 0 = whole strips to everybody
 	int fhalo[NSLOT];                   // ... as used for the frame in that slot (the mode changes after a miss)
+	int balance_every;                  // re-cut every this many delivered frames from the ranks' cost words; 0 = never
+	uint32_t last_cost[MAXW];           // the cost words of the last delivered frame (pwn_tiled_get_cuts)
 	pwn_transport *tp;
 	hipStream_t comm;
+	// Compute: the kernels of frame f (trace f, later blur f) on cs[f & 1] -- two streams, so that the trace grid of
+	// frame f+1 moves onto the CUs while frame f's runs out of units (a strip of an 8-way tiling of a 4K frame is
+	// three units per wave: the mean wave is resident for 2/3 of such a launch) and a stream that waits for its
+	// frame's halo rows does not hold up the other.  Without PWN_OPT_FRAME_OVERLAP both are the context's one stream.
+	hipStream_t cs[2];
+	uint32_t *cost_acc;                 // device, two words 64 B apart: what the trace launch in flight on cs[i] cost so far (tables.h cost_word)
 	uint32_t *pre[NSLOT], *out[NSLOT], *fin[NSLOT]; float *z[NSLOT];     // full-frame planes per frame slot (fin: rank 0)
-	uint32_t *missw[NSLOT], *missv[NSLOT];   // this rank's miss word of the slot's frame; every rank's (world words)
-	uint32_t *h_missv;                  // pinned: per slot, every rank's miss word of the slot's frame (world words) and then this rank's own
+	// the two words a rank says about a frame: [0] taps that left its halo (miss), [1] what its strip cost (the sum of
+	// its trace waves' lifetimes, 100 MHz ticks); missw = this rank's, missv = every rank's (world x 2)
+	uint32_t *missw[NSLOT], *missv[NSLOT];
+	uint32_t *h_missv;                  // pinned: per slot, every rank's two words of the slot's frame (world x 2) and then this rank's own
 	uint32_t *h_frame;                  // pinned host copy of a delivered frame (rank 0, PWN_TILED_HOST)
 	// per slot: behind the frame's trace; behind the group G(f) it opened; behind its blur; behind the
 	// group that carried its gather (that is G(f+2)'s event or the drain group's)
 	hipEvent_t ev_t[NSLOT], ev_x[NSLOT], ev_b[NSLOT], ev_d[NSLOT];
-	hipEvent_t ev_k0[NSLOT], ev_k1[NSLOT], ev_k2[NSLOT];      // timing (PWN_OPT_FRAME_TIMING): around the trace, behind the blur
+	hipEvent_t ev_k0[NSLOT], ev_k1[NSLOT], ev_k2[NSLOT], ev_k3[NSLOT];      // timing (PWN_OPT_FRAME_TIMING): around the trace, around the blur
+	hipEvent_t ev_g0[NSLOT], ev_g1[NSLOT], ev_g2[NSLOT];                    // ... on the comm stream: in front of the gather group, between the groups, behind the halo group
 	hipEvent_t gathered_by[NSLOT];      // which of the above marks the slot's gather as done
 	// host sink: NSLOT whole frames in host memory shared by the ranks; this rank's copies on their own stream
 	uint8_t *host_base; void *host_registered;   // the frames; what this context registered with the device (or NULL)
 	hipStream_t copy;
 	hipEvent_t ev_h[NSLOT];             // behind the copy of the slot's strip into the host frame
-	bool timed[NSLOT];
+	bool timed[NSLOT]; bool timed_g2[NSLOT];
+	float enqueue_us[NSLOT];            // host time spent inside pwn_tiled_submit for the slot's frame
 	// frames: submitted (traced, group opened), blurred (blur enqueued), gathered (gather in a group), delivered
 	unsigned long long submitted, blurred, gathered, delivered;
 	pwn_tiled_info info;
@@ -256,6 +275,75 @@ static int strip_rows(int h, int world)
 {
 	int per = (h + world - 1) / world;
 	return (per + 7) / 8 * 8;
+}
+
+static void equal_cuts(int h, int world, int *cuts)
+{
+	const int per = strip_rows(h, world);
+	for(int r = 0; r <= world; r++) cuts[r] = r * per < h ? r * per : h;
+	cuts[world] = h;
+}
+
+// Cuts for the next frames from what the strips of a delivered frame cost.  The cost of a row is taken as constant
+// inside a strip (cost[r] / rows of r), which makes the cost up to row y piecewise linear; the new cut k sits where
+// that reaches k / world of the total, rounded to the 8 rows the kernels tile by.  Rows are not equally expensive
+// inside a strip either (the horizon band is 3x the floor), so one step does not land on the balance point; a few
+// re-cuts do, each from the costs measured with the cuts before.  Every strip keeps at least min_rows rows (the halo
+// it has to send) and at most max_rows.  All ranks run this on the same numbers and get the same cuts.
+static bool recut(const int *old, const uint32_t *cost, int world, int h, int min_rows, int max_rows, int *out)
+{
+	double total = 0.0, top = 0.0;
+	for(int r = 0; r < world; r++)
+	{
+		if(cost[r] == 0u || old[r + 1] <= old[r]) return false;      // a rank that does not measure, an empty strip: leave it
+		total += (double)cost[r];
+		if((double)cost[r] > top) top = (double)cost[r];
+	}
+	if(top * world < total * 1.02) return false;                     // within 2 % of the mean already
+	int cut[MAXW + 1];
+	cut[0] = 0; cut[world] = h;
+	double acc = 0.0;
+	int r = 0;
+	for(int k = 1; k < world; k++)
+	{
+		const double want = total * (double)k / (double)world;
+		while(r < world - 1 && acc + (double)cost[r] < want) { acc += (double)cost[r]; r++; }
+		double y = (double)old[r] + (want - acc) / (double)cost[r] * (double)(old[r + 1] - old[r]);
+		// (three quarters of the way: the rows next to a cut are the ones whose cost the strip's mean misrepresents most)
+		y = (double)old[k] + 0.75 * (y - (double)old[k]);
+		int y8 = (int)(y / 8.0 + 0.5) * 8;
+		cut[k] = y8;
+	}
+	// every strip at least min_rows and at most max_rows tall: push the cuts apart from the top, then from the bottom
+	min_rows = (min_rows + 7) / 8 * 8; if(min_rows < 8) min_rows = 8;
+	if((long long)min_rows * world > h || (long long)max_rows * world < h) return false;
+	for(int k = 1; k < world; k++) { if(cut[k] < cut[k - 1] + min_rows) cut[k] = cut[k - 1] + min_rows; if(cut[k] > cut[k - 1] + max_rows) cut[k] = cut[k - 1] + max_rows; }
+	for(int k = world - 1; k >= 1; k--) { if(cut[k] > cut[k + 1] - min_rows) cut[k] = (cut[k + 1] - min_rows) / 8 * 8; if(cut[k] < cut[k + 1] - max_rows) cut[k] = (cut[k + 1] - max_rows + 7) / 8 * 8; }
+	for(int k = 1; k <= world; k++) if(cut[k] - cut[k - 1] < min_rows || cut[k] - cut[k - 1] > max_rows) return false;
+	bool moved = false;
+	for(int k = 0; k <= world; k++) { if(cut[k] != old[k]) moved = true; out[k] = cut[k]; }
+	return moved;
+}
+
+// (the rule by itself, for hosts and tests that want to know what the library would do)
+extern "C" int pwn_tiled_recut(const int *cuts, const uint32_t *cost, int world, int h, int min_rows, int max_rows, int *out)
+{
+	if(cuts == NULL || cost == NULL || out == NULL || world < 1 || world > MAXW || h < 1) return PWN_EINVAL;
+	if(recut(cuts, cost, world, h, min_rows, max_rows, out)) return 1;
+	memcpy(out, cuts, sizeof(int) * (size_t)(world + 1));
+	return 0;
+}
+
+static bool valid_cuts(const pwn_tiled *t, int h, const int *cuts, int min_rows)
+{
+	if(cuts[0] != 0 || cuts[t->world] != h) return false;
+	for(int r = 0; r < t->world; r++)
+	{
+		const int rows = cuts[r + 1] - cuts[r];
+		if(rows < min_rows || rows < 1 || rows > t->max_rows) return false;
+		if(r + 1 < t->world && (cuts[r + 1] & 7) != 0) return false;
+	}
+	return true;
 }
 
 extern "C" int pwn_tiled_unique_id(void *id, int transport)
@@ -292,15 +380,11 @@ void pwn_tiled_destroy(pwn_ctx *c)
 	{
 		(void)hipFree(t->pre[s]); (void)hipFree(t->out[s]); (void)hipFree(t->fin[s]); (void)hipFree(t->z[s]);
 		(void)hipFree(t->missw[s]); (void)hipFree(t->missv[s]);
-		if(t->ev_t[s]) (void)hipEventDestroy(t->ev_t[s]);
-		if(t->ev_x[s]) (void)hipEventDestroy(t->ev_x[s]);
-		if(t->ev_b[s]) (void)hipEventDestroy(t->ev_b[s]);
-		if(t->ev_d[s]) (void)hipEventDestroy(t->ev_d[s]);
-		if(t->ev_k0[s]) (void)hipEventDestroy(t->ev_k0[s]);
-		if(t->ev_k1[s]) (void)hipEventDestroy(t->ev_k1[s]);
-		if(t->ev_k2[s]) (void)hipEventDestroy(t->ev_k2[s]);
+		hipEvent_t *evs[] = { &t->ev_t[s], &t->ev_x[s], &t->ev_b[s], &t->ev_d[s], &t->ev_k0[s], &t->ev_k1[s], &t->ev_k2[s], &t->ev_k3[s],
+			&t->ev_g0[s], &t->ev_g1[s], &t->ev_g2[s], &t->ev_h[s] };
+		for(size_t i = 0; i < sizeof(evs) / sizeof(evs[0]); i++) if(*evs[i]) (void)hipEventDestroy(*evs[i]);
 	}
-	for(int s = 0; s < NSLOT; s++) if(t->ev_h[s]) (void)hipEventDestroy(t->ev_h[s]);
+	(void)hipFree(t->cost_acc);
 	if(t->copy) (void)hipStreamDestroy(t->copy);
 	if(t->host_registered) (void)hipHostUnregister(t->host_registered);
 	if(t->h_missv) (void)hipHostFree(t->h_missv);
@@ -313,36 +397,46 @@ void pwn_tiled_destroy(pwn_ctx *c)
 
 extern "C" void pwn_tiled_shutdown(pwn_ctx *c) { if(c != NULL) pwn_tiled_destroy(c); }
 
+bool pwn_tiled_busy(pwn_ctx *c) { return c->tiled != NULL && c->tiled->submitted != c->tiled->delivered; }
+
 extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, int transport, int halo_rows)
 {
-	if(c == NULL || id == NULL || world < 1 || world > 64 || rank < 0 || rank >= world) return PWN_EINVAL;
+	if(c == NULL || id == NULL || world < 1 || world > MAXW || rank < 0 || rank >= world) return PWN_EINVAL;
 	if(c->tiled != NULL) return PWN_EBUSY;
+	for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
 	if(c->blur_passes > 1) { snprintf(c->err, sizeof(c->err), "row tiling supports POSTPROC_BLUR 0 or 1"); return PWN_EINVAL; }
 	if(c->blur_passes > 0 && (c->w & 3) != 0) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
+	// (frames of the frames-in-flight API may have used the second compute stream)
+	if(c->stream2 && hipStreamSynchronize(c->stream2) != hipSuccess) return PWN_EHIP;
+	c->last_frame_done = NULL; c->serialize_next = false;
 	pwn_tiled *t = new(std::nothrow) pwn_tiled();
 	if(t == NULL) return PWN_ENOMEM;
 	memset(t, 0, sizeof(*t));
 	t->rank = rank; t->world = world;
 	t->per = strip_rows(c->h, world);
-	t->y0 = rank * t->per < c->h ? rank * t->per : c->h;
-	t->y1 = t->y0 + t->per < c->h ? t->y0 + t->per : c->h;
+	equal_cuts(c->h, world, t->cuts);
+	for(int s = 0; s < NSLOT; s++) memcpy(t->fcuts[s], t->cuts, sizeof(t->cuts));
+	// a rank's strip may grow to one and a half equal strips when the cuts move
+	t->max_rows = (t->per + t->per / 2 + 7) / 8 * 8;
+	if(t->max_rows > c->h) t->max_rows = c->h;
 	// bounded halo: H rows per neighbour, possible when every strip has at least H rows; the default
 	// covers depth 24 (taps reach 0.002 * h * (depth - 1) rows, screen.h:100-102)
 	int H = halo_rows < 0 ? (int)(0.002 * c->h * 24.0) + 2 : halo_rows;
 	int shortest = c->h;
-	for(int r = 0; r < world; r++)
-	{
-		int a = r * t->per < c->h ? r * t->per : c->h, b = a + t->per < c->h ? a + t->per : c->h;
-		if(b - a < shortest) shortest = b - a;
-	}
+	for(int r = 0; r < world; r++) if(t->cuts[r + 1] - t->cuts[r] < shortest) shortest = t->cuts[r + 1] - t->cuts[r];
 	if(world == 1 || c->blur_passes == 0 || H > shortest || H <= 0) H = 0;
-	t->halo = H;
+	t->halo = H; t->want_halo = H;
+	// moving cuts: on unless a strip of the equal split is empty (more ranks than 8-row bands); PWN_TILED_BALANCE=k
+	// sets the period in delivered frames, 0 switches it off; pwn_tiled_balance() does the same from the host
+	t->balance_every = (world > 1 && shortest >= 16 && c->blur_passes == 1) ? 8 : 0;
+	if(const char *e = getenv("PWN_TILED_BALANCE")) { int v = atoi(e); if(v >= 0 && v <= 100000 && (v == 0 || t->balance_every > 0)) t->balance_every = v; }
+	t->cs[0] = c->stream; t->cs[1] = (c->frame_overlap && c->stream2 != NULL) ? c->stream2 : c->stream;
 	c->tiled = t;
 
 	int rc = PWN_OK;
 	const size_t n = (size_t)c->w * (size_t)c->h;
-	const size_t strip_bytes = (size_t)c->w * (size_t)t->per * 4;
+	const size_t strip_bytes = (size_t)c->w * (size_t)t->max_rows * 4;
 	do
 	{
 		if(transport == PWN_TRANSPORT_RCCL)
@@ -371,26 +465,30 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 		else { rc = PWN_EINVAL; break; }
 
 		if(hipStreamCreateWithFlags(&t->comm, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+		if(hipMalloc((void **)&t->cost_acc, 128) != hipSuccess) { rc = PWN_ENOMEM; break; }
+		if(hipMemset(t->cost_acc, 0, 128) != hipSuccess) { rc = PWN_EHIP; break; }
 		for(int s = 0; s < NSLOT && rc == PWN_OK; s++)
 		{
 			if(hipMalloc((void **)&t->pre[s], n * 4) != hipSuccess || hipMalloc((void **)&t->out[s], n * 4) != hipSuccess ||
 			   hipMalloc((void **)&t->z[s], n * 4) != hipSuccess || hipMalloc((void **)&t->missw[s], 64) != hipSuccess ||
-			   hipMalloc((void **)&t->missv[s], (size_t)world * 4 + 64) != hipSuccess ||
+			   hipMalloc((void **)&t->missv[s], (size_t)world * 8 + 64) != hipSuccess ||
 			   (rank == 0 && hipMalloc((void **)&t->fin[s], n * 4) != hipSuccess)) { rc = PWN_ENOMEM; break; }
 			if(hipMemset(t->pre[s], 0, n * 4) != hipSuccess || hipMemset(t->out[s], 0, n * 4) != hipSuccess ||
 			   hipMemset(t->z[s], 0, n * 4) != hipSuccess || hipMemset(t->missw[s], 0, 64) != hipSuccess ||
-			   hipMemset(t->missv[s], 0, (size_t)world * 4 + 64) != hipSuccess ||
+			   hipMemset(t->missv[s], 0, (size_t)world * 8 + 64) != hipSuccess ||
 			   (rank == 0 && hipMemset(t->fin[s], 0, n * 4) != hipSuccess)) { rc = PWN_EHIP; break; }
 			if(hipEventCreateWithFlags(&t->ev_t[s], hipEventDisableTiming) != hipSuccess ||
 			   hipEventCreateWithFlags(&t->ev_x[s], hipEventDisableTiming) != hipSuccess ||
 			   hipEventCreateWithFlags(&t->ev_b[s], hipEventDisableTiming) != hipSuccess ||
 			   hipEventCreateWithFlags(&t->ev_d[s], hipEventDisableTiming) != hipSuccess ||
 			   hipEventCreate(&t->ev_k0[s]) != hipSuccess || hipEventCreate(&t->ev_k1[s]) != hipSuccess ||
-			   hipEventCreate(&t->ev_k2[s]) != hipSuccess) { rc = PWN_EHIP; break; }
+			   hipEventCreate(&t->ev_k2[s]) != hipSuccess || hipEventCreate(&t->ev_k3[s]) != hipSuccess ||
+			   hipEventCreate(&t->ev_g0[s]) != hipSuccess || hipEventCreate(&t->ev_g1[s]) != hipSuccess ||
+			   hipEventCreate(&t->ev_g2[s]) != hipSuccess) { rc = PWN_EHIP; break; }
 		}
 		if(rc != PWN_OK) break;
-		if(hipHostMalloc((void **)&t->h_missv, (size_t)NSLOT * ((size_t)world + 1) * 4, hipHostMallocDefault) != hipSuccess) { rc = PWN_ENOMEM; break; }
-		memset(t->h_missv, 0, (size_t)NSLOT * ((size_t)world + 1) * 4);
+		if(hipHostMalloc((void **)&t->h_missv, (size_t)NSLOT * ((size_t)world + 1) * 8, hipHostMallocDefault) != hipSuccess) { rc = PWN_ENOMEM; break; }
+		memset(t->h_missv, 0, (size_t)NSLOT * ((size_t)world + 1) * 8);
 		// one round trip through the transport before the first frame depends on it: every rank sends a
 		// word to its right-hand neighbour (to itself when alone) and checks what arrives from the left
 		{
@@ -415,16 +513,58 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	if(rc != PWN_OK) { char keep[256]; memcpy(keep, c->err, sizeof(keep)); pwn_tiled_destroy(c); memcpy(c->err, keep, sizeof(keep)); return rc; }
 	// Room for RCCL's kernels beside the persistent trace grid (pwn_api.cpp): 16 workgroups of ~1280, i.e. one less
 	// on 16 CUs, 1.25 % of the grid.  Not measurable without several GPUs; PWN_TILED_RESERVE=n overrides it
-	// (0 = fill every CU) for the sweep that the first multi-GPU run should make.
+	// (0 = fill every CU), pwn_tiled_set_reserve() changes it between frames: bench.py --gpus N sweeps it.
 	c->grid_reserve = 0;
 	if(world > 1 && transport == PWN_TRANSPORT_RCCL)
 	{
 		c->grid_reserve = 16;
 		if(const char *e = getenv("PWN_TILED_RESERVE")) { int v = atoi(e); if(v >= 0 && v <= 512) c->grid_reserve = v; }
 	}
-	t->info.rank = rank; t->info.world = world; t->info.y0 = t->y0; t->info.y1 = t->y1; t->info.rows_per_rank = t->per;
+	t->info.rank = rank; t->info.world = world; t->info.y0 = t->cuts[rank]; t->info.y1 = t->cuts[rank + 1]; t->info.rows_per_rank = t->per;
 	t->info.halo_rows = t->halo; t->info.transport = transport;
+	t->info.max_rows = t->max_rows; t->info.grid_reserve = c->grid_reserve; t->info.two_streams = t->cs[1] != t->cs[0];
 	return PWN_OK;
+}
+
+extern "C" int pwn_tiled_balance(pwn_ctx *c, int every_frames)
+{
+	if(c == NULL || c->tiled == NULL || every_frames < 0) return PWN_EINVAL;
+	c->tiled->balance_every = every_frames;
+	return PWN_OK;
+}
+
+extern "C" int pwn_tiled_set_reserve(pwn_ctx *c, int workgroups)
+{
+	if(c == NULL || c->tiled == NULL || workgroups < 0 || workgroups > 512) return PWN_EINVAL;
+	c->grid_reserve = workgroups;
+	c->tiled->info.grid_reserve = workgroups;
+	return PWN_OK;
+}
+
+extern "C" int pwn_tiled_set_cuts(pwn_ctx *c, const int *cuts, int n)
+{
+	if(c == NULL || c->tiled == NULL || cuts == NULL) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	if(n != t->world + 1) return PWN_EINVAL;
+	// (a strip shorter than the halo it has to send would mean whole strips from now on: not through this call)
+	if(!valid_cuts(t, c->h, cuts, t->halo > 0 ? t->halo : 1))
+	{
+		snprintf(c->err, sizeof(c->err), "cuts: 0 = c[0] < ... < c[%d] = %d in multiples of 8, every strip %d..%d rows", t->world, c->h,
+			t->halo > 0 ? t->halo : 1, t->max_rows);
+		return PWN_EINVAL;
+	}
+	memcpy(t->cuts, cuts, sizeof(int) * (size_t)n);
+	t->info.y0 = t->cuts[t->rank]; t->info.y1 = t->cuts[t->rank + 1];
+	return PWN_OK;
+}
+
+extern "C" int pwn_tiled_get_cuts(pwn_ctx *c, int *cuts, uint32_t *cost)
+{
+	if(c == NULL || c->tiled == NULL || cuts == NULL) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	memcpy(cuts, t->cuts, sizeof(int) * (size_t)(t->world + 1));
+	if(cost != NULL) memcpy(cost, t->last_cost, sizeof(uint32_t) * (size_t)t->world);
+	return t->world + 1;
 }
 
 extern "C" int pwn_tiled_host_sink(pwn_ctx *c, void *base, size_t bytes)
@@ -451,55 +591,52 @@ extern "C" int pwn_tiled_host_sink(pwn_ctx *c, void *base, size_t bytes)
 extern "C" int pwn_tiled_get_info(pwn_ctx *c, pwn_tiled_info *out)
 {
 	if(c == NULL || out == NULL || c->tiled == NULL) return PWN_EINVAL;
-	c->tiled->info.halo_rows = c->tiled->halo;
-	*out = c->tiled->info;
+	pwn_tiled *t = c->tiled;
+	t->info.halo_rows = t->halo;
+	t->info.y0 = t->cuts[t->rank]; t->info.y1 = t->cuts[t->rank + 1];
+	t->info.balance_every = t->balance_every;
+	*out = t->info;
 	return PWN_OK;
 }
 
-static void rows_of(pwn_ctx *c, pwn_tiled *t, int r, int *a, int *b)
+// strip r of the frame in slot s
+static inline void rows_of(const pwn_tiled *t, int s, int r, int *a, int *b) { *a = t->fcuts[s][r]; *b = t->fcuts[s][r + 1]; }
+
+// the two words of every rank to every rank
+static int add_words(pwn_ctx *c, pwn_tiled *t, int s)
 {
-	*a = r * t->per < c->h ? r * t->per : c->h;
-	*b = *a + t->per < c->h ? *a + t->per : c->h;
+	for(int r = 0; r < t->world; r++)
+	{
+		if(r == t->rank) continue;
+		TPCHK(c, t->tp->send(t->missw[s], 8, r));
+		TPCHK(c, t->tp->recv(t->missv[s] + 2 * r, 8, r));
+	}
+	return PWN_OK;
 }
 
-// the second half of a group: frame `g`'s finished strips to rank 0, its miss words to everybody
+// the second half of a group: frame `g`'s finished strips to rank 0, its words to everybody
 static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 {
 	const int s = (int)(g % NSLOT);
 	const size_t w4 = (size_t)c->w * 4;
 	uint32_t *mine = c->blur_passes ? t->out[s] : t->pre[s];
-	if(t->host_base != NULL)
-	{
-		// host sink: no strips; the word of every rank to every rank, behind that rank's copy to the host
-		for(int r = 0; r < t->world; r++)
-		{
-			if(r == t->rank) continue;
-			TPCHK(c, t->tp->send(t->missw[s], 4, r));
-			TPCHK(c, t->tp->recv(t->missv[s] + r, 4, r));
-		}
-		return PWN_OK;
-	}
+	int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
+	// host sink: no strips; the words go out behind this rank's copy to the host
+	if(t->host_base != NULL) return add_words(c, t, s);
 	if(t->rank == 0)
 	{
 		for(int r = 1; r < t->world; r++)
 		{
-			int a, b; rows_of(c, t, r, &a, &b);
+			int a, b; rows_of(t, s, r, &a, &b);
 			if(b > a) { TPCHK(c, t->tp->recv(t->fin[s] + (size_t)a * c->w, (size_t)(b - a) * w4, r)); t->info.bytes_received += (unsigned long long)(b - a) * w4; }
 		}
 	}
-	else if(t->y1 > t->y0)
+	else if(y1 > y0)
 	{
-		TPCHK(c, t->tp->send(mine + (size_t)t->y0 * c->w, (size_t)(t->y1 - t->y0) * w4, 0));
-		t->info.bytes_sent += (unsigned long long)(t->y1 - t->y0) * w4;
+		TPCHK(c, t->tp->send(mine + (size_t)y0 * c->w, (size_t)(y1 - y0) * w4, 0));
+		t->info.bytes_sent += (unsigned long long)(y1 - y0) * w4;
 	}
-	if(t->fhalo[s])
-		for(int r = 0; r < t->world; r++)
-		{
-			if(r == t->rank) continue;
-			TPCHK(c, t->tp->send(t->missw[s], 4, r));
-			TPCHK(c, t->tp->recv(t->missv[s] + r, 4, r));
-		}
-	return PWN_OK;
+	return add_words(c, t, s);
 }
 
 // behind a group that carried frame g's words: bring them (and this rank's own) to pinned host memory on the comm
@@ -507,10 +644,9 @@ static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 static int fetch_words(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 {
 	const int s = (int)(g % NSLOT);
-	if(!t->fhalo[s]) return PWN_OK;
-	uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1);
-	HIPCHK(c, hipMemcpyAsync(h, t->missv[s], (size_t)t->world * 4, hipMemcpyDeviceToHost, t->comm));
-	HIPCHK(c, hipMemcpyAsync(h + t->world, t->missw[s], 4, hipMemcpyDeviceToHost, t->comm));
+	uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1) * 2;
+	HIPCHK(c, hipMemcpyAsync(h, t->missv[s], (size_t)t->world * 8, hipMemcpyDeviceToHost, t->comm));
+	HIPCHK(c, hipMemcpyAsync(h + 2 * t->world, t->missw[s], 8, hipMemcpyDeviceToHost, t->comm));
 	return PWN_OK;
 }
 
@@ -518,11 +654,12 @@ static int fetch_words(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 static int add_allgather(pwn_ctx *c, pwn_tiled *t, int s)
 {
 	const size_t w4 = (size_t)c->w * 4;
+	int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
 	for(int r = 0; r < t->world; r++)
 	{
 		if(r == t->rank) continue;
-		int a, b; rows_of(c, t, r, &a, &b);
-		if(t->y1 > t->y0) { TPCHK(c, t->tp->send(t->pre[s] + (size_t)t->y0 * c->w, (size_t)(t->y1 - t->y0) * w4, r)); t->info.bytes_sent += (unsigned long long)(t->y1 - t->y0) * w4; }
+		int a, b; rows_of(t, s, r, &a, &b);
+		if(y1 > y0) { TPCHK(c, t->tp->send(t->pre[s] + (size_t)y0 * c->w, (size_t)(y1 - y0) * w4, r)); t->info.bytes_sent += (unsigned long long)(y1 - y0) * w4; }
 		if(b > a) { TPCHK(c, t->tp->recv(t->pre[s] + (size_t)a * c->w, (size_t)(b - a) * w4, r)); t->info.bytes_received += (unsigned long long)(b - a) * w4; }
 	}
 	return PWN_OK;
@@ -531,40 +668,53 @@ static int add_allgather(pwn_ctx *c, pwn_tiled *t, int s)
 // host sink: this rank's finished strip of the slot's frame into the host frame, behind its blur
 static int copy_strip_to_host(pwn_ctx *c, pwn_tiled *t, int s)
 {
-	if(t->y1 <= t->y0) { HIPCHK(c, hipEventRecord(t->ev_h[s], t->copy)); return PWN_OK; }
+	int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
+	if(y1 <= y0) { HIPCHK(c, hipEventRecord(t->ev_h[s], t->copy)); return PWN_OK; }
 	const size_t w4 = (size_t)c->w * 4, frame = w4 * (size_t)c->h;
 	const uint32_t *src = c->blur_passes ? t->out[s] : t->pre[s];
 	HIPCHK(c, hipStreamWaitEvent(t->copy, t->ev_b[s], 0));
-	HIPCHK(c, hipMemcpyAsync(t->host_base + (size_t)s * frame + (size_t)t->y0 * w4, src + (size_t)t->y0 * c->w,
-		(size_t)(t->y1 - t->y0) * w4, hipMemcpyDeviceToHost, t->copy));
+	HIPCHK(c, hipMemcpyAsync(t->host_base + (size_t)s * frame + (size_t)y0 * w4, src + (size_t)y0 * c->w,
+		(size_t)(y1 - y0) * w4, hipMemcpyDeviceToHost, t->copy));
 	HIPCHK(c, hipEventRecord(t->ev_h[s], t->copy));
-	t->info.bytes_to_host += (unsigned long long)(t->y1 - t->y0) * w4;
+	t->info.bytes_to_host += (unsigned long long)(y1 - y0) * w4;
 	return PWN_OK;
 }
 
-// the blur of frame k, behind the group that brought its halo rows
+// the blur of frame k on that frame's compute stream, behind the group that brought its halo rows
 static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 {
 	const int s = (int)(k % NSLOT);
-	hipStream_t cs = c->stream;
+	hipStream_t cs = t->cs[k & 1u];
+	int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
 	if(c->blur_passes)
 	{
 		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
+		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k2[s], cs));
 		uint32_t *dst = (t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->out[s];
+		// the trace of this frame, in front of this launch on the stream, added up what the strip cost: the blur
+		// moves that into the frame's second word and clears the accumulator for the stream's next trace
+		uint32_t *acc = t->cost_acc + 16 * (k & 1u);
 		int rc;
 		if(t->fhalo[s])
 		{
 			const int H = t->fhalo[s];
-			const int a0 = t->rank > 0 ? t->y0 - H : 0, a1 = (t->rank < t->world - 1 && t->y1 < c->h) ? t->y1 + H : c->h;
-			rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, a0, a1, t->missw[s]);
+			const int a0 = t->rank > 0 ? y0 - H : 0, a1 = (t->rank < t->world - 1 && y1 < c->h) ? y1 + H : c->h;
+			rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->z[s], dst, cs, a0, a1, t->missw[s], acc, t->missw[s] + 1);
 		}
-		else rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL);
+		else rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL, acc, t->missw[s] + 1);
 		if(rc != PWN_OK) return rc;
+		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k3[s], cs));
 	}
-	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k2[s], cs));
 	HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
 	if(t->host_base != NULL) return copy_strip_to_host(c, t, s);
 	return PWN_OK;
+}
+
+static double now_us(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
 }
 
 extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
@@ -573,25 +723,32 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	pwn_tiled *t = c->tiled;
 	if(t->submitted - t->delivered >= NSLOT - 1) return PWN_EBUSY;
 	(void)hipSetDevice(c->device);
+	const double t_in = now_us();
 	const unsigned long long f = t->submitted;
 	const int s = (int)(f % NSLOT);
 	const size_t w4 = (size_t)c->w * 4;
-	hipStream_t cs = c->stream;
+	hipStream_t cs = t->cs[f & 1u];
 	t->fhalo[s] = t->halo;
+	memcpy(t->fcuts[s], t->cuts, sizeof(t->cuts));
+	const int y0 = t->cuts[t->rank], y1 = t->cuts[t->rank + 1];
 	// The slot's buffers were frame f-4's.  Its blur ran on this stream; its strips left in G(f-4) and in
 	// the group that carried its gather, and the frame was delivered (three in flight at most), which
 	// waited for that group on the host: nothing to wait for here.
 	uint32_t *plane = c->blur_passes ? t->pre[s] : ((t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->pre[s]);
 	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
+	t->timed_g2[s] = false;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
 	c->trace_clear_word = t->missw[s];           // the frame's miss word is cleared by its trace launch (no memset between the kernels)
+	c->trace_cost_word = c->blur_passes ? t->cost_acc + 16 * (f & 1u) : NULL;      // (the blur moves it on: enqueue_blur)
 	c->trace_tables_event = t->ev_t[s];          // ... and ev_t, recorded right behind it, also tells when its tables are free again
-	int rc = pwn_i_launch_trace(c, cam, sec, t->y0, t->y1, plane, t->z[s], cs);
+	int rc = pwn_i_launch_trace(c, cam, sec, y0, y1, plane, t->z[s], cs);
 	if(rc != PWN_OK) { (void)hipEventRecord(t->ev_t[s], cs); return rc; }
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
 	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
 
-	// ---- the blur of the frames before this one, behind this frame's trace (normally just f-1)
+	// ---- the blur of the frames before this one (normally just f-1), each on its frame's stream.  With one
+	// compute stream that puts the blur of f-1 BEHIND the trace of f, so that the stream does not sit waiting for
+	// the halo rows of f-1 while it could trace; with two, the other stream waits for them and this one traces.
 	for(; t->blurred < f; t->blurred++)
 	{
 		rc = enqueue_blur(c, t, t->blurred);
@@ -612,6 +769,8 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
 			if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));       // the word goes out behind the copy
 		}
+		const int gs = (int)((g_end - 1) % NSLOT);
+		if(t->timed[gs]) { HIPCHK(c, hipEventRecord(t->ev_g0[gs], t->comm)); }
 		if(t->world > 1)
 		{
 			TPCHK(c, t->tp->begin(t->comm));
@@ -619,6 +778,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 			TPCHK(c, t->tp->end());
 			t->info.groups++;
 		}
+		if(t->timed[gs]) { HIPCHK(c, hipEventRecord(t->ev_g1[gs], t->comm)); t->timed_g2[gs] = true; }
 		for(unsigned long long g = t->gathered; g < g_end; g++) { rc = fetch_words(c, t, g); if(rc != PWN_OK) return rc; }
 		hipEvent_t done = t->ev_d[(g_end - 1) % NSLOT];
 		HIPCHK(c, hipEventRecord(done, t->comm));
@@ -627,6 +787,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	}
 	// ---- then this frame's pre-blur rows, behind its trace
 	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
+	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g2[s], t->comm));
 	if(t->world > 1 && c->blur_passes)
 	{
 		TPCHK(c, t->tp->begin(t->comm));
@@ -635,14 +796,14 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 			const int H = t->halo;
 			if(t->rank > 0)
 			{
-				TPCHK(c, t->tp->send(t->pre[s] + (size_t)t->y0 * c->w, (size_t)H * w4, t->rank - 1));
-				TPCHK(c, t->tp->recv(t->pre[s] + (size_t)(t->y0 - H) * c->w, (size_t)H * w4, t->rank - 1));
+				TPCHK(c, t->tp->send(t->pre[s] + (size_t)y0 * c->w, (size_t)H * w4, t->rank - 1));
+				TPCHK(c, t->tp->recv(t->pre[s] + (size_t)(y0 - H) * c->w, (size_t)H * w4, t->rank - 1));
 				t->info.bytes_sent += (unsigned long long)H * w4; t->info.bytes_received += (unsigned long long)H * w4;
 			}
-			if(t->rank < t->world - 1 && t->y1 < c->h)
+			if(t->rank < t->world - 1 && y1 < c->h)
 			{
-				TPCHK(c, t->tp->send(t->pre[s] + (size_t)(t->y1 - H) * c->w, (size_t)H * w4, t->rank + 1));
-				TPCHK(c, t->tp->recv(t->pre[s] + (size_t)t->y1 * c->w, (size_t)H * w4, t->rank + 1));
+				TPCHK(c, t->tp->send(t->pre[s] + (size_t)(y1 - H) * c->w, (size_t)H * w4, t->rank + 1));
+				TPCHK(c, t->tp->recv(t->pre[s] + (size_t)y1 * c->w, (size_t)H * w4, t->rank + 1));
 				t->info.bytes_sent += (unsigned long long)H * w4; t->info.bytes_received += (unsigned long long)H * w4;
 			}
 		}
@@ -652,6 +813,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	}
 	HIPCHK(c, hipEventRecord(t->ev_x[s], t->comm));
 	t->submitted = f + 1;
+	t->enqueue_us[s] = (float)(now_us() - t_in);
 	return PWN_OK;
 }
 
@@ -694,14 +856,17 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	HIPCHK(c, hipEventSynchronize(t->ev_b[s]));               // (world 1, and rank 0's own strip)
 	if(t->host_base != NULL) HIPCHK(c, hipEventSynchronize(t->ev_h[s]));      // this rank's own strip is in the host frame
 
-	// ---- was the bounded halo enough for this frame, on every rank?
+	// ---- the ranks' words of this frame (they came to pinned memory behind the group that carried them: fetch_words)
+	const uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1) * 2;
+	uint32_t cost[MAXW];
 	bool miss = false;
-	if(t->fhalo[s])
+	for(int r = 0; r < t->world; r++)
 	{
-		// (the words came to pinned memory behind the group that carried them: fetch_words)
-		const uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1);
-		for(int r = 0; r < t->world; r++) miss = miss || (r == t->rank ? h[t->world] : h[r]) != 0;
+		const uint32_t *wr = r == t->rank ? h + 2 * t->world : h + 2 * r;
+		if(t->fhalo[s] && wr[0] != 0u) miss = true;           // was the bounded halo enough for this frame, on every rank?
+		cost[r] = wr[1];
 	}
+	memcpy(t->last_cost, cost, sizeof(uint32_t) * (size_t)t->world);
 	if(miss)
 	{
 		// Every rank sees the same words and comes here together: the frame's exchange again with
@@ -709,7 +874,8 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		// On the comm stream, behind the groups of the newer frames that are already in it.
 		t->info.frames_redone++;
 		t->halo = 0; t->fhalo[s] = 0;
-		hipStream_t cs = c->stream;
+		hipStream_t cs = t->cs[d & 1u];
+		int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
 		TPCHK(c, t->tp->begin(t->comm));
 		rc = add_allgather(c, t, s);
 		if(rc != PWN_OK) return rc;
@@ -717,7 +883,9 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
 		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_d[s], 0));
 		uint32_t *dst = (t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->out[s];
-		rc = pwn_i_launch_blur(c, t->y0, t->y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL);
+		// (this stream's cost accumulator may hold the trace of frame d+2 by now: it is left alone, the frame's
+		// cost word was moved by its first blur)
+		rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL, NULL, NULL);
 		if(rc != PWN_OK) return rc;
 		HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
 		HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[s], 0));
@@ -736,6 +904,18 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		HIPCHK(c, hipStreamSynchronize(cs));
 		if(t->host_base != NULL) HIPCHK(c, hipStreamSynchronize(t->copy));
 	}
+	// ---- moving cuts: every balance_every delivered frames, new cuts from what this frame's strips cost.  Every
+	// rank has the same words and the same cuts of this frame, so every rank computes the same new cuts, and they
+	// take effect with the same frame: the next one submitted.
+	if(t->balance_every > 0 && t->world > 1 && ((d + 1) % (unsigned long long)t->balance_every) == 0)
+	{
+		int nc[MAXW + 1];
+		if(recut(t->fcuts[s], cost, t->world, c->h, t->halo > 0 ? t->halo : 8, t->max_rows, nc))
+		{
+			memcpy(t->cuts, nc, sizeof(int) * (size_t)(t->world + 1));
+			t->info.recuts++;
+		}
+	}
 	t->delivered = d + 1;
 	t->info.frames++;
 	if(out != NULL)
@@ -744,10 +924,20 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		out->seq = d + 1;
 		out->redone = miss ? 1 : 0;
 		out->timed = t->timed[s] ? 1 : 0;
+		out->y0 = t->fcuts[s][t->rank]; out->y1 = t->fcuts[s][t->rank + 1];
+		out->cost = cost[t->rank];
+		out->enqueue_us = t->enqueue_us[s];
 		if(t->timed[s])
 		{
 			(void)hipEventElapsedTime(&out->trace_ms, t->ev_k0[s], t->ev_k1[s]);
-			(void)hipEventElapsedTime(&out->frame_ms, t->ev_k0[s], t->ev_k2[s]);      // trace .. blur: the next frame's trace and the exchange in between
+			if(c->blur_passes)
+			{
+				(void)hipEventElapsedTime(&out->blur_ms, t->ev_k2[s], t->ev_k3[s]);
+				(void)hipEventElapsedTime(&out->frame_ms, t->ev_k0[s], t->ev_k3[s]);      // trace .. blur: waiting for the halo rows in between
+				(void)hipEventElapsedTime(&out->halo_ms, t->ev_g2[s], t->ev_x[s]) ;
+			}
+			if(t->timed_g2[s]) (void)hipEventElapsedTime(&out->gather_ms, t->ev_g0[s], t->ev_g1[s]);
+			if(hipGetLastError() != hipSuccess) { /* (an event without timing data: the figure stays 0) */ }
 		}
 		if(t->host_base != NULL) out->sbuf = (const uint32_t *)(t->host_base + (size_t)s * n * 4);
 		else if(t->rank == 0)

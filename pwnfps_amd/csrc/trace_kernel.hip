@@ -279,6 +279,8 @@ pwn_trace_kernel(pwn_trace_params P)
 		uint4 *dst = (uint4 *)lds_raw;
 		int n16 = (int)(P.blob_bytes >> 4);
 		for(int i = threadIdx.x; i < n16; i += PWN_BLOCK) dst[i] = src[i];
+		// one word behind the tables: the workgroup's share of pwn_trace_params.cost_word (bottom of the kernel)
+		if(threadIdx.x == 0) *(uint32_t *)(lds_raw + ((P.blob_bytes + 15u) & ~15u)) = 0u;
 	}
 	__syncthreads();
 
@@ -299,7 +301,7 @@ pwn_trace_kernel(pwn_trace_params P)
 	Counters cnt = {};
 	// PWN_OPT_WAVE_LOG: when was this wave resident (the GPU's constant 100 MHz clock)
 	unsigned long long t_begin = 0ull;
-	if(P.wave_log != NULL) t_begin = __builtin_amdgcn_s_memrealtime();
+	if(P.wave_log != NULL || P.cost_word != NULL) t_begin = __builtin_amdgcn_s_memrealtime();
 
 	// Work distribution.  A unit is one wave64's 16 x 4 pixels (lane & 15 = column inside one
 	// half of the 32-wide tile of screen.h:6-7 = one DPP row, lane >> 4 = row).  Rays differ in
@@ -375,8 +377,16 @@ pwn_trace_kernel(pwn_trace_params P)
 		misses = 0;
 		const uint32_t unit = ticket * PWN_QUEUES + q;
 		const bool draw = left == 0u;
+		// Asking for the next unit BEFORE tracing this one commits the wave to two units, and near the end of a launch
+		// that is the tail: the last ticket of a queue goes to a wave that still has a whole unit in front of it while
+		// its neighbours find the queues empty and leave.  P.late_rounds > 0 makes a wave draw only when it is done
+		// once fewer tickets than that are left in its queue.  Measured on the strips of an 8-way tiling of a 4K frame
+		// (3 units per wave), on 720p and on 4K frames: always slower (strip 67 -> 76..82 us, 720p 60 -> 71 us, 4K
+		// equal) -- a draw takes ~6 us under load, and the waves of a SIMD, which run in step, all wait for theirs at
+		// the same time.  The launcher passes 0 (always ahead); the parameter stays for experiments.
+		const bool late = ticket + P.late_rounds >= qlen;
 		uint32_t next_raw = ticket + 1u;
-		if(draw && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n);
+		if(draw && !late && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n);
 		// rows from the middle outwards: the horizon band, where rays run longest,
 		// is started first and the cheap top and bottom edges make up the tail
 		// (this arithmetic is the same for the whole wave, but the compiler does it per lane because q starts
@@ -444,6 +454,7 @@ pwn_trace_kernel(pwn_trace_params P)
 			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
+		if(draw && late && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n);
 		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
 		left = draw ? draw_n - 1u : left - 1u;
 	}
@@ -471,6 +482,19 @@ pwn_trace_kernel(pwn_trace_params P)
 		const unsigned simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11));
 		const size_t wid = 1u + (size_t)blockIdx.x * 4u + simd;
 		P.wave_log[2 * wid] = t_begin; P.wave_log[2 * wid + 1] = __builtin_amdgcn_s_memrealtime();
+	}
+	// Row tiling with moving cuts (pwn_tiled.cpp): what this strip COST, as the sum of its waves' lifetimes in ticks of
+	// the constant 100 MHz clock -- a wave lives exactly as long as it finds units, so the sum is the strip's work
+	// in wave-time, whatever the tail of the launch looked like.  The four waves of a workgroup add up in LDS (one
+	// ds_add_rtn: lifetime in the low 28 bits, a count in the high four) and the last one to leave adds the
+	// workgroup's sum to the word: ~1300 no-return atomics per launch, spread over its tail.
+	if(P.cost_word != NULL && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+	{
+		static_assert(PWN_BLOCK == 256, "four waves per workgroup");
+		const uint32_t life = (uint32_t)(__builtin_amdgcn_s_memrealtime() - t_begin) & 0x03ffffffu;
+		PWN_LDS uint32_t *wg = (PWN_LDS uint32_t *)(uintptr_t)((P.blob_bytes + 15u) & ~15u);
+		const uint32_t old = __hip_atomic_fetch_add(wg, life + (1u << 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if((old >> 28) == 3u) (void)__hip_atomic_fetch_add(P.cost_word, (old + life) & 0x0fffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }
 
@@ -517,7 +541,7 @@ extern "C" int pwn_trace_tile_w(void) { return TILE_W; }
 // LDS a workgroup needs beyond the table blob
 extern "C" unsigned pwn_trace_lds_extra(void)
 {
-	return 0u;
+	return 16u;        // the workgroup's cost word (pwn_trace_params.cost_word)
 }
 
 extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w)

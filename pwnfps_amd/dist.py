@@ -16,8 +16,10 @@ so that the protocol -- what goes into which group, which buffers a frame owns, 
 whose blur taps left the halo is repeated, and that every rank decides the same -- is covered
 by world_size 2 / 3 / 8 tests without a GPU (tests/test_dist_gloo.py).
 
-One process per rank; rank r owns rows [r*per, min((r+1)*per, h)), per = ceil(h/world) rounded
-up to 8 (the reference parallelises the same loops with OpenMP over rows, screen.h:63,77).  The
+One process per rank; rank r owns rows [cuts[r], cuts[r+1]) -- to begin with the equal split, per =
+ceil(h/world) rounded up to 8 (the reference parallelises the same loops with OpenMP over rows, screen.h:63,77);
+then the cuts MOVE with what the strips cost (``recut``: every rank's cost word travels with the frame's miss
+word, every rank computes the same new cuts from the same numbers, a frame keeps the cuts it was traced with).  The
 trace pass needs no exchange.  The blur does: its taps reach 0.002*h*(depth-1) rows
 (screen.h:100-102), unbounded in depth.  Per submitted frame f (slot s = f mod 4):
 
@@ -67,6 +69,57 @@ def default_halo(h):
     return int(0.002 * h * 24.0) + 2
 
 
+def equal_cuts(h, world):
+    per = strip_rows(h, world)
+    return [min(r * per, h) for r in range(world)] + [h]
+
+
+def max_strip_rows(h, world):
+    """the tallest strip a rank may be given: one and a half equal strips (pwn_tiled_init)"""
+    per = strip_rows(h, world)
+    return min(h, (per + per // 2 + 7) // 8 * 8)
+
+
+def recut(old, cost, world, h, min_rows, max_rows):
+    """``recut`` of pwn_tiled.cpp, statement for statement: new cuts from what the strips of a delivered frame cost
+    (piecewise-constant cost per row inside a strip; cut k where the running cost reaches k/world of the total, three
+    quarters of the way from the old cut, multiples of 8; every strip within [min_rows, max_rows]).  None = leave them."""
+    total, top = 0.0, 0.0
+    for r in range(world):
+        if int(cost[r]) == 0 or old[r + 1] <= old[r]:
+            return None
+        total += float(cost[r])
+        top = max(top, float(cost[r]))
+    if top * world < total * 1.02:
+        return None
+    cut = [0] * (world + 1)
+    cut[world] = h
+    acc, r = 0.0, 0
+    for k in range(1, world):
+        want = total * float(k) / float(world)
+        while r < world - 1 and acc + float(cost[r]) < want:
+            acc += float(cost[r])
+            r += 1
+        y = float(old[r]) + (want - acc) / float(cost[r]) * float(old[r + 1] - old[r])
+        y = float(old[k]) + 0.75 * (y - float(old[k]))
+        cut[k] = int(y / 8.0 + 0.5) * 8
+    min_rows = max((min_rows + 7) // 8 * 8, 8)
+    if min_rows * world > h or max_rows * world < h:
+        return None
+    for k in range(1, world):
+        cut[k] = max(cut[k], cut[k - 1] + min_rows)
+        cut[k] = min(cut[k], cut[k - 1] + max_rows)
+    for k in range(world - 1, 0, -1):
+        if cut[k] > cut[k + 1] - min_rows:
+            cut[k] = (cut[k + 1] - min_rows) // 8 * 8
+        if cut[k] < cut[k + 1] - max_rows:
+            cut[k] = (cut[k + 1] - max_rows + 7) // 8 * 8
+    for k in range(1, world + 1):
+        if cut[k] - cut[k - 1] < min_rows or cut[k] - cut[k - 1] > max_rows:
+            return None
+    return cut if cut != list(old) else None
+
+
 class HipStripBackend:
     """Strips on this process's GPU through the C ABI (device pointers, torch's
     current stream).  There is no CPU path: constructing it without a usable
@@ -83,6 +136,7 @@ class HipStripBackend:
         return torch.cuda.current_stream().cuda_stream
 
     def trace_rows(self, cam, sec, y0, y1, pre, z):
+        """(returns nothing: the strip forms of the C ABI do not measure cost -- the cuts stay where they are)"""
         self.r.trace_rows_device(cam, sec, y0, y1, pre.data_ptr(), z.data_ptr(), self._stream())
 
     def blur_rows(self, y0, y1, pre, z, out):
@@ -97,7 +151,8 @@ class HipStripBackend:
 class TiledFrames:
     """pwn_tiled_init / _submit / _wait of pwn_tiled.cpp, restated.  Names follow the C code."""
 
-    def __init__(self, w, h, backend, device, rank=None, world=None, blur_passes=1, halo_rows=-1, group=None, host_sink=None):
+    def __init__(self, w, h, backend, device, rank=None, world=None, blur_passes=1, halo_rows=-1, group=None, host_sink=None,
+                 balance_every=None):
         self.w, self.h = int(w), int(h)
         self.group = group
         if world is None:
@@ -112,26 +167,54 @@ class TiledFrames:
             raise ValueError("blur needs a width divisible by 4 (screen.h:88)")
         self.backend = backend
         self.per = strip_rows(self.h, world)
-        self.y0, self.y1 = strip_range(self.h, world, rank)
+        self.cuts = equal_cuts(self.h, world)          # for the next submitted frame
+        self.fcuts = [list(self.cuts) for _ in range(NSLOT)]   # ... as used for the frame in that slot
+        self.max_rows = max_strip_rows(self.h, world)
         H = default_halo(self.h) if halo_rows < 0 else int(halo_rows)
-        shortest = min(strip_range(self.h, world, r)[1] - strip_range(self.h, world, r)[0] for r in range(world))
+        shortest = min(self.cuts[r + 1] - self.cuts[r] for r in range(world))
         if world == 1 or self.blur_passes == 0 or H > shortest or H <= 0:
             H = 0
         self.halo = H                       # rows exchanged with each neighbour; 0 = whole strips to everybody
         self.fhalo = [0] * NSLOT            # ... as used for the frame in that slot
+        # moving cuts: every `balance_every` delivered frames (pwn_tiled_balance; the C default is 8)
+        dflt = 8 if (world > 1 and shortest >= 16 and self.blur_passes == 1) else 0
+        self.balance_every = dflt if balance_every is None else (int(balance_every) if dflt else 0)
+        self.recuts = 0
+        self.last_cost = [0] * world
         kw = dict(device=device)
         mk = lambda dt: [torch.zeros((self.h, self.w), dtype=dt, **kw) for _ in range(NSLOT)]   # noqa: E731
         # int32 views of the uint32 BGRA pixels (the transport does not care)
         self.pre, self.out, self.z = mk(torch.int32), mk(torch.int32), mk(torch.float32)
         self.fin = mk(torch.int32) if rank == 0 else [None] * NSLOT
-        self.missw = [torch.zeros(1, dtype=torch.int32, **kw) for _ in range(NSLOT)]
-        self.missv = [torch.zeros(world, dtype=torch.int32, **kw) for _ in range(NSLOT)]
+        # the two words a rank says about a frame: [0] taps that left its halo, [1] what its strip cost
+        self.missw = [torch.zeros(2, dtype=torch.int32, **kw) for _ in range(NSLOT)]
+        self.missv = [torch.zeros(2 * world, dtype=torch.int32, **kw) for _ in range(NSLOT)]
         self.submitted = self.blurred = self.gathered = self.delivered = 0
         self.info = dict(frames=0, frames_redone=0, groups=0, bytes_sent=0, bytes_received=0, bytes_to_host=0)
         # pwn_tiled_host_sink: uint32 [NSLOT, h, w] in memory shared by the ranks (np.memmap of one file ...)
         self.host = host_sink
         if self.host is not None and tuple(self.host.shape) != (NSLOT, self.h, self.w):
             raise ValueError("a host sink holds %d frames of %dx%d" % (NSLOT, self.w, self.h))
+
+    @property
+    def y0(self):
+        return self.cuts[self.rank]
+
+    @property
+    def y1(self):
+        return self.cuts[self.rank + 1]
+
+    def set_cuts(self, cuts):
+        """pwn_tiled_set_cuts: world + 1 boundaries for the next submitted frames; the same call on every rank"""
+        cuts = [int(v) for v in cuts]
+        lo = self.halo if self.halo > 0 else 1
+        ok = len(cuts) == self.world + 1 and cuts[0] == 0 and cuts[-1] == self.h
+        for r in range(self.world):
+            rows = cuts[r + 1] - cuts[r] if ok else 0
+            ok = ok and lo <= rows <= self.max_rows and rows >= 1 and (r + 1 == self.world or cuts[r + 1] % 8 == 0)
+        if not ok:
+            raise ValueError("cuts: 0 = c[0] < ... < c[world] = h in multiples of 8, every strip %d..%d rows" % (lo, self.max_rows))
+        self.cuts = cuts
 
     # ---- the transport: a group = operations that progress together -----------------------
     def _begin(self):
@@ -151,64 +234,68 @@ class TiledFrames:
                 req.wait()
         self.info["groups"] += 1
 
-    def _rows_of(self, r):
-        return strip_range(self.h, self.world, r)
+    def _rows_of(self, s, r):
+        """strip r of the frame in slot s"""
+        return self.fcuts[s][r], self.fcuts[s][r + 1]
+
+    def _add_words(self, s):
+        """the two words of every rank to every rank"""
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            self._send(self.missw[s], r, TAG_MISS)
+            self._recv(self.missv[s][2 * r:2 * r + 2], r, TAG_MISS)
 
     # ---- pieces of a group (add_gather / add_allgather of pwn_tiled.cpp) ------------------
     def _add_gather(self, g):
         s = g % NSLOT
         mine = self.out[s] if self.blur_passes else self.pre[s]
+        y0, y1 = self._rows_of(s, self.rank)
         if self.host is not None:
-            # no strips: the word of every rank to every rank, behind that rank's copy to the host
-            for r in range(self.world):
-                if r == self.rank:
-                    continue
-                self._send(self.missw[s], r, TAG_MISS)
-                self._recv(self.missv[s][r:r + 1], r, TAG_MISS)
+            # no strips: the words go out behind this rank's copy to the host
+            self._add_words(s)
             return
         if self.rank == 0:
             for r in range(1, self.world):
-                a, b = self._rows_of(r)
+                a, b = self._rows_of(s, r)
                 if b > a:
                     self._recv(self.fin[s][a:b], r, TAG_GATHER)
-        elif self.y1 > self.y0:
-            self._send(mine[self.y0:self.y1], 0, TAG_GATHER)
-        if self.fhalo[s]:
-            for r in range(self.world):
-                if r == self.rank:
-                    continue
-                self._send(self.missw[s], r, TAG_MISS)
-                self._recv(self.missv[s][r:r + 1], r, TAG_MISS)
+        elif y1 > y0:
+            self._send(mine[y0:y1], 0, TAG_GATHER)
+        self._add_words(s)
 
     def _add_allgather(self, s):
+        y0, y1 = self._rows_of(s, self.rank)
         for r in range(self.world):
             if r == self.rank:
                 continue
-            a, b = self._rows_of(r)
-            if self.y1 > self.y0:
-                self._send(self.pre[s][self.y0:self.y1], r, TAG_STRIP)
+            a, b = self._rows_of(s, r)
+            if y1 > y0:
+                self._send(self.pre[s][y0:y1], r, TAG_STRIP)
             if b > a:
                 self._recv(self.pre[s][a:b], r, TAG_STRIP)
 
     def _copy_strip_to_host(self, s):
-        if self.y1 > self.y0:
+        y0, y1 = self._rows_of(s, self.rank)
+        if y1 > y0:
             src = self.out[s] if self.blur_passes else self.pre[s]
-            self.host[s, self.y0:self.y1] = src[self.y0:self.y1].cpu().numpy().view(np.uint32)
+            self.host[s, y0:y1] = src[y0:y1].cpu().numpy().view(np.uint32)
             if hasattr(self.host, "flush"):
                 self.host.flush()
-            self.info["bytes_to_host"] += (self.y1 - self.y0) * self.w * 4
+            self.info["bytes_to_host"] += (y1 - y0) * self.w * 4
 
     def _enqueue_blur(self, k):
         s = k % NSLOT
+        y0, y1 = self._rows_of(s, self.rank)
         if self.blur_passes:
             dst = self.fin[s] if (self.rank == 0 and self.host is None) else self.out[s]
             if self.fhalo[s]:
                 H = self.fhalo[s]
-                a0 = self.y0 - H if self.rank > 0 else 0
-                a1 = self.y1 + H if (self.rank < self.world - 1 and self.y1 < self.h) else self.h
-                self.backend.blur_rows_bounded(self.y0, self.y1, self.pre[s], self.z[s], dst, a0, a1, self.missw[s])
+                a0 = y0 - H if self.rank > 0 else 0
+                a1 = y1 + H if (self.rank < self.world - 1 and y1 < self.h) else self.h
+                self.backend.blur_rows_bounded(y0, y1, self.pre[s], self.z[s], dst, a0, a1, self.missw[s][0:1])
             else:
-                self.backend.blur_rows(self.y0, self.y1, self.pre[s], self.z[s], dst)
+                self.backend.blur_rows(y0, y1, self.pre[s], self.z[s], dst)
         if self.host is not None:
             self._copy_strip_to_host(s)
 
@@ -219,10 +306,16 @@ class TiledFrames:
         f = self.submitted
         s = f % NSLOT
         self.fhalo[s] = self.halo
+        self.fcuts[s] = list(self.cuts)
+        y0, y1 = self.cuts[self.rank], self.cuts[self.rank + 1]
         cam = np.ascontiguousarray(cam, np.float32).reshape(16)
         plane = self.pre[s] if self.blur_passes else (self.fin[s] if (self.rank == 0 and self.host is None) else self.pre[s])
-        self.backend.trace_rows(cam, float(sec), self.y0, self.y1, plane, self.z[s])
         self.missw[s].zero_()
+        cost = self.backend.trace_rows(cam, float(sec), y0, y1, plane, self.z[s])
+        # (in the C code the trace launch adds up its waves' lifetimes and the frame's blur moves the sum into the
+        # frame's second word; a backend that measures nothing leaves it 0 and the cuts where they are)
+        if cost is not None and self.blur_passes:
+            self.missw[s][1] = int(cost) & 0x7fffffff
         # the blur of the frames before this one (normally just f-1)
         while self.blurred < f:
             self._enqueue_blur(self.blurred)
@@ -242,11 +335,11 @@ class TiledFrames:
             if self.halo:
                 H = self.halo
                 if self.rank > 0:
-                    self._send(self.pre[s][self.y0:self.y0 + H], self.rank - 1, TAG_HALO)
-                    self._recv(self.pre[s][self.y0 - H:self.y0], self.rank - 1, TAG_HALO)
-                if self.rank < self.world - 1 and self.y1 < self.h:
-                    self._send(self.pre[s][self.y1 - H:self.y1], self.rank + 1, TAG_HALO)
-                    self._recv(self.pre[s][self.y1:self.y1 + H], self.rank + 1, TAG_HALO)
+                    self._send(self.pre[s][y0:y0 + H], self.rank - 1, TAG_HALO)
+                    self._recv(self.pre[s][y0 - H:y0], self.rank - 1, TAG_HALO)
+                if self.rank < self.world - 1 and y1 < self.h:
+                    self._send(self.pre[s][y1 - H:y1], self.rank + 1, TAG_HALO)
+                    self._recv(self.pre[s][y1:y1 + H], self.rank + 1, TAG_HALO)
             else:
                 self._add_allgather(s)
             self._end()
@@ -272,26 +365,35 @@ class TiledFrames:
                     self._add_gather(g)
                 self._end()
             self.gathered = d + 1
-        miss = False
-        if self.fhalo[s]:
-            words = self.missv[s].clone()
-            words[self.rank] = self.missw[s][0]
-            miss = bool((words != 0).any().item())
+        # the ranks' words of this frame
+        words = self.missv[s].clone()
+        words[2 * self.rank:2 * self.rank + 2] = self.missw[s]
+        words = [int(v) for v in words.cpu().tolist()]
+        miss = bool(self.fhalo[s]) and any(words[2 * r] != 0 for r in range(self.world))
+        cost = [words[2 * r + 1] for r in range(self.world)]
+        self.last_cost = cost
         if miss:
             # every rank sees the same words and comes here together
             self.info["frames_redone"] += 1
             self.halo = 0
             self.fhalo[s] = 0
+            y0, y1 = self._rows_of(s, self.rank)
             self._begin()
             self._add_allgather(s)
             self._end()
             dst = self.fin[s] if (self.rank == 0 and self.host is None) else self.out[s]
-            self.backend.blur_rows(self.y0, self.y1, self.pre[s], self.z[s], dst)
+            self.backend.blur_rows(y0, y1, self.pre[s], self.z[s], dst)
             if self.host is not None:
                 self._copy_strip_to_host(s)            # the strip again, and the words behind it
             self._begin()
             self._add_gather(d)
             self._end()
+        # moving cuts: the same numbers on every rank, so the same new cuts, from the next submitted frame on
+        if self.balance_every > 0 and self.world > 1 and (d + 1) % self.balance_every == 0:
+            nc = recut(self.fcuts[s], cost, self.world, self.h, self.halo if self.halo > 0 else 8, self.max_rows)
+            if nc is not None:
+                self.cuts = nc
+                self.recuts += 1
         self.delivered = d + 1
         self.info["frames"] += 1
         if self.host is not None:

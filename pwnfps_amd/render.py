@@ -68,6 +68,10 @@ class Renderer:
         """HIP events around the kernels of every N-th frame in flight (0: never, 1: all)."""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_FRAME_TIMING, int(every)), "pwn_set_option")
 
+    def set_frame_overlap(self, on):
+        """frames in flight: successive frames alternate between two compute streams (default) or all run on one"""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_FRAME_OVERLAP, 1 if on else 0), "pwn_set_option")
+
     def set_wave_log(self, on):
         """stats()["wave_time"] / (["waves"] * ["kernel_span"]) = mean wave residency of the last frame"""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_WAVE_LOG, 1 if on else 0), "pwn_set_option")
@@ -242,7 +246,8 @@ class Renderer:
         fr = _lib.TiledFrame()
         self._chk(lib.pwn_tiled_wait(self._ctx, _lib.PWN_TILED_HOST if host else 0, C.byref(fr)), "pwn_tiled_wait")
         out = {"seq": fr.seq, "redone": bool(fr.redone), "d_sbuf": fr.d_sbuf, "timed": bool(fr.timed),
-               "trace_ms": fr.trace_ms, "frame_ms": fr.frame_ms}
+               "trace_ms": fr.trace_ms, "frame_ms": fr.frame_ms, "blur_ms": fr.blur_ms, "halo_ms": fr.halo_ms,
+               "gather_ms": fr.gather_ms, "enqueue_us": fr.enqueue_us, "y0": fr.y0, "y1": fr.y1, "cost": fr.cost}
         if fr.sbuf:
             out["sbuf"] = np.ctypeslib.as_array(C.cast(fr.sbuf, C.POINTER(C.c_uint32)), shape=(self.w * self.h,)).reshape(self.h, self.w)
         return out
@@ -261,6 +266,26 @@ class Renderer:
 
     def tiled_shutdown(self):
         lib.pwn_tiled_shutdown(self._ctx)
+
+    def tiled_balance(self, every_frames):
+        """Moving cuts: re-cut the strips every `every_frames` delivered frames from what they cost (0: leave them)."""
+        self._chk(lib.pwn_tiled_balance(self._ctx, int(every_frames)), "pwn_tiled_balance")
+
+    def tiled_set_cuts(self, cuts):
+        """world + 1 row boundaries for the next submitted frames; the same call on every rank."""
+        a = np.ascontiguousarray(cuts, np.int32)
+        self._chk(lib.pwn_tiled_set_cuts(self._ctx, a.ctypes.data, len(a)), "pwn_tiled_set_cuts")
+
+    def tiled_get_cuts(self):
+        """(cuts of the next frame [world + 1], every rank's cost word of the last delivered frame [world])"""
+        cuts = np.zeros(_lib.PWN_TILED_MAX_WORLD + 1, np.int32)
+        cost = np.zeros(_lib.PWN_TILED_MAX_WORLD, np.uint32)
+        n = self._chk(lib.pwn_tiled_get_cuts(self._ctx, cuts.ctypes.data, cost.ctypes.data), "pwn_tiled_get_cuts")
+        return cuts[:n].copy(), cost[:n - 1].copy()
+
+    def tiled_set_reserve(self, workgroups):
+        """workgroups the persistent trace grid leaves free for RCCL's kernels (this rank, between frames)"""
+        self._chk(lib.pwn_tiled_set_reserve(self._ctx, int(workgroups)), "pwn_tiled_set_reserve")
 
     # -- sink (screen.h:126-149) ----------------------------------------------
     def screen_upscale(self, sbuf, scale, pitch_bytes=None, pixels=None):

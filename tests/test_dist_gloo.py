@@ -42,6 +42,9 @@ class OracleStripBackend:
         self.o.L.pwno_trace_rows(self.o.lv, self.w, self.h, y0, y1, np.ascontiguousarray(cam, np.float32).ctypes.data,
                                  float(sec), 1, pre.data_ptr(), z.data_ptr(), None)
         assert hp >= self.h
+        # what the rows "cost" (the C code measures its trace launch): a horizon band three times as dear as the rest
+        y = np.arange(y0, y1, dtype=np.float64)
+        return int(np.sum(100.0 + 300.0 * np.exp(-((y - 0.5 * self.h) / (0.12 * self.h)) ** 2)))
 
     def blur_rows(self, y0, y1, pre, z, out):
         self.o.L.pwno_blur_rows(self.w, self.h, y0, y1, 1, pre.data_ptr(), z.data_ptr(), out.data_ptr())
@@ -62,7 +65,7 @@ class OracleStripBackend:
         self.o.L.pwno_blur_rows(self.w, self.h, y0, y1, 1, pre.data_ptr(), z.data_ptr(), out.data_ptr())
 
 
-def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=None):
+def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=None, balance=None, cuts_at=None):
     import sys
     sys.path.insert(0, HERE)
     sys.path.insert(0, ROOT)
@@ -82,10 +85,13 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=Non
         if sink_path is not None:
             # pwn_tiled_host_sink: one file mapped by every rank plays the shared host memory
             sink = np.memmap(sink_path, dtype=np.uint32, mode="r+", shape=(4, h, w))
-        fr = TiledFrames(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur, halo_rows=halo, host_sink=sink)
+        fr = TiledFrames(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur, halo_rows=halo, host_sink=sink,
+                         balance_every=balance)
         assert (fr.y0, fr.y1) == strip_range(h, world, rank)
         halo0 = fr.halo
         got = []
+        cuts_seen = []
+        cuts_at = cuts_at or {}
 
         def deliver(k):
             frame, redone = fr.wait()
@@ -97,6 +103,9 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=Non
         for k in range(frames):
             cam, sec, sph = tiled_rank.scene(k, base, spawn)
             be.o.set_spheres(sph)
+            if k in cuts_at:
+                fr.set_cuts(cuts_at[k])
+            cuts_seen.append(list(fr.cuts))
             fr.submit(cam, sec)
             if k >= 2:
                 deliver(k - 2)
@@ -111,16 +120,18 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=Non
         deliver(frames)
         with pytest.raises(RuntimeError, match="nothing in flight"):
             fr.wait()
-        q.put((rank, got, halo0, fr.halo, dict(fr.info)))
+        info = dict(fr.info)
+        info.update(recuts=fr.recuts, cuts_seen=cuts_seen, last_cost=list(fr.last_cost))
+        q.put((rank, got, halo0, fr.halo, info))
     finally:
         dist.destroy_process_group()
 
 
-def _run(world, w, h, level, frames, blur, halo, sink_path=None):
+def _run(world, w, h, level, frames, blur, halo, sink_path=None, balance=None, cuts_at=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, level, frames, blur, halo, q, sink_path)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, level, frames, blur, halo, q, sink_path, balance, cuts_at)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -215,10 +226,95 @@ def test_host_sink_delivers_whole_frames_to_every_rank(world, blur, halo, tmp_pa
         assert [x[0] for x in g] == want, r
         assert [x[1] for x in g] == redone
         assert info["bytes_to_host"] > 0
-        # between ranks: halo rows (or whole pre-blur strips after a miss) and one word per pair -- never finished strips
+        # between ranks: halo rows (or whole pre-blur strips after a miss) and two words per pair -- never finished strips
         if halo == -1 and blur:
-            assert info["bytes_sent"] <= (frames + 1) * (2 * 13 * w * 4 + 4 * (world - 1))
+            assert info["bytes_sent"] <= (frames + 1) * (2 * 13 * w * 4 + 8 * (world - 1))
         if blur == 0:
-            assert info["bytes_sent"] == (frames + 1) * 4 * (world - 1)
+            assert info["bytes_sent"] == (frames + 1) * 8 * (world - 1)
     assert (sum(redone) > 0) == (halo == 1)
 
+
+
+# ---- moving cuts (pwn_tiled_balance / pwn_tiled_set_cuts) -------------------------------------------------------
+
+@pytest.mark.parametrize("world,halo,sink", [(8, -1, False), (3, -1, False), (3, 1, False), (4, 0, False), (3, -1, True)])
+def test_moving_cuts_keep_every_frame_exact(world, halo, sink, tmp_path):
+    """The strips are re-cut every second delivered frame from the ranks' cost words and once by hand; every rank
+    computes the same cuts, a frame in flight keeps the cuts it was traced with (exchange, blur, gather, host-sink
+    copies, the repeat after a missed halo), and every delivered frame is the oracle's."""
+    from pwnfps_amd.dist import equal_cuts
+    w, h, frames = 320, 240, 11
+    path = None
+    if sink:
+        path = str(tmp_path / "frames.bin")
+        np.zeros((4, h, w), np.uint32).tofile(path)
+    eq = equal_cuts(h, world)
+    by_hand = {5: [0] + [c + 8 for c in eq[1:-2]] + [eq[-2], h]}            # (the last strip of the equal split is the short one)
+    want = _want(w, h, "pwnfps_level", frames + 1, 1)
+    res = _run(world, w, h, "pwnfps_level", frames, 1, halo, path, balance=2, cuts_at=by_hand)
+    assert [g[0] for g in res[0][0]] == want
+    seen0 = res[0][3]["cuts_seen"]
+    for r in range(world):
+        info = res[r][3]
+        assert info["cuts_seen"] == seen0 and info["recuts"] == res[0][3]["recuts"] and info["last_cost"] == res[0][3]["last_cost"]
+        if sink:
+            assert [g[0] for g in res[r][0]] == want
+    assert seen0[0] == eq and seen0[5] == by_hand[5] and res[0][3]["recuts"] >= 2
+    # the cuts went where the cost is: the strips over the dear middle band got shorter than the equal split's
+    rows = lambda c: [c[i + 1] - c[i] for i in range(world)]        # noqa: E731
+    assert rows(seen0[4])[world // 2] < rows(eq)[world // 2] or world <= 3
+    for c in seen0:
+        assert c[0] == 0 and c[-1] == h and all(v % 8 == 0 for v in c[1:-1]) and all(b > a for a, b in zip(c, c[1:]))
+
+
+def test_the_recut_rule_is_the_librarys():
+    """pwnfps_amd.dist.recut restates pwn_tiled.cpp's rule; the library exports it (pwn_tiled_recut, no device needed)."""
+    import ctypes as C
+    from pwnfps_amd import _lib
+    from pwnfps_amd.dist import equal_cuts, max_strip_rows, recut
+    rng = np.random.default_rng(7)
+    moved = 0
+    for trial in range(400):
+        world = int(rng.integers(2, 9))
+        h = int(rng.choice([240, 360, 720, 1080, 2160, 4320]))
+        cuts = equal_cuts(h, world)
+        mx = max_strip_rows(h, world)
+        mn = int(rng.choice([8, int(0.002 * h * 24.0) + 2]))
+        for step in range(4):
+            cost = (rng.integers(1, 1000, world) * rng.choice([1, 1, 1, 50], world)).astype(np.uint32)
+            if trial % 17 == 0:
+                cost[int(rng.integers(0, world))] = 0
+            a = np.array(cuts, np.int32)
+            out = np.zeros(world + 1, np.int32)
+            rc = _lib.lib.pwn_tiled_recut(a.ctypes.data, cost.ctypes.data, world, h, mn, mx, out.ctypes.data)
+            mine = recut(cuts, [int(v) for v in cost], world, h, mn, mx)
+            assert rc in (0, 1) and (rc == 1) == (mine is not None), (trial, cuts, cost)
+            if mine is not None:
+                assert mine == out.tolist(), (trial, cuts, cost.tolist(), mine, out.tolist())
+                rows = np.diff(mine)
+                assert rows.min() >= (mn + 7) // 8 * 8 and rows.max() <= mx and mine[0] == 0 and mine[-1] == h
+                cuts = mine
+                moved += 1
+            else:
+                assert out.tolist() == list(cuts)
+    assert moved > 300
+
+
+def test_recut_converges_on_a_fixed_cost_profile():
+    """rows of fixed cost (a horizon band twice as dear as floor and ceiling -- level.txt's busiest strip of eight costs 1.3x
+    the mean): a few re-cuts bring the strips within 3 % of each other.  (A strip may grow to 1.5 equal strips; a
+    profile so peaked that the cheap strips want more than that stops there.)"""
+    from pwnfps_amd.dist import equal_cuts, max_strip_rows, recut
+    h, world = 2160, 8
+    y = np.arange(h, dtype=np.float64)
+    per_row = 100.0 + 100.0 * np.exp(-((y - 0.5 * h) / (0.12 * h)) ** 2)
+    cuts = equal_cuts(h, world)
+    cost_of = lambda c: [int(per_row[c[r]:c[r + 1]].sum()) for r in range(world)]      # noqa: E731
+    first = cost_of(cuts)
+    for _ in range(8):
+        nc = recut(cuts, cost_of(cuts), world, h, 105, max_strip_rows(h, world))
+        if nc is None:
+            break
+        cuts = nc
+    last = cost_of(cuts)
+    assert max(first) / np.mean(first) > 1.3 and max(last) / np.mean(last) < 1.03, (cuts, last)

@@ -21,7 +21,8 @@ RANK = os.path.join(ROOT, "tools", "tiled_rank.py")
 _runs = [0]
 
 
-def run_ranks(world, w, h, level, frames, halo, tmp_path, transport="shm", blur=None, hostsink=False, seen=None):
+def run_ranks(world, w, h, level, frames, halo, tmp_path, transport="shm", blur=None, hostsink=False, seen=None, balance=None, cuts_at=None,
+              rows=None, extra_env=None):
     _runs[0] += 1
     idfile = str(tmp_path / ("id_%d" % _runs[0]))          # a fresh file per run: the ranks wait for it to appear
     env = dict(os.environ)
@@ -29,6 +30,11 @@ def run_ranks(world, w, h, level, frames, halo, tmp_path, transport="shm", blur=
         env["TILED_BLUR"] = str(blur)
     if hostsink:
         env["TILED_HOSTSINK"] = "1"
+    if balance is not None:
+        env["TILED_BALANCE"] = str(balance)
+    if cuts_at:
+        env["TILED_CUTS_AT"] = ";".join("%d:%s" % (k, ",".join(str(v) for v in c)) for k, c in cuts_at.items())
+    env.update(extra_env or {})
     procs = [subprocess.Popen([sys.executable, RANK, str(r), str(world), idfile, transport, str(w), str(h), level, str(frames), str(halo)],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
     outs = []
@@ -45,6 +51,9 @@ def run_ranks(world, w, h, level, frames, halo, tmp_path, transport="shm", blur=
     if seen is not None:                                  # host sink: what the other ranks saw in the shared frame
         seen.extend([h for _, h in re.findall(r"seen (\d+) fnv64 ([0-9a-f]{16})", o)] for o in outs[1:])
     infos = [json.loads(re.search(r"info (\{.*\})", o).group(1)) for o in outs]
+    if rows is not None:                                  # per rank: [(frame, y0, y1, cost)], and the cuts at the end
+        rows.extend([tuple(int(v) for v in m) for m in re.findall(r"rows (\d+) (\d+) (\d+) (\d+)", o)] for o in outs)
+        rows.append([json.loads(re.search(r"cuts (\[.*\])", o).group(1)) for o in outs])
     return hashes, infos
 
 
@@ -243,3 +252,59 @@ def test_host_sink_argument_checks_and_one_rank(oracle_lib, cases):
     r.tiled_shutdown()
     r.close()
 
+
+
+def _check_rows(rows, world, h, frames):
+    """every frame's strips tile the frame, in rank order, the same on every rank's account"""
+    per_rank, final_cuts = rows[:world], rows[world]
+    assert all(c == final_cuts[0] for c in final_cuts)
+    cuts_of = []
+    for k in range(frames):
+        edges = [0]
+        for r in range(world):
+            fk = [x for x in per_rank[r] if x[0] == k]
+            assert len(fk) == 1 and fk[0][1] == edges[-1] and fk[0][2] > fk[0][1]
+            edges.append(fk[0][2])
+        assert edges[-1] == h and all(e % 8 == 0 for e in edges[1:-1])
+        cuts_of.append(edges)
+    return cuts_of
+
+
+@pytest.mark.parametrize("world,halo,hostsink", [(3, -1, False), (2, -1, False), (3, 1, False), (3, -1, True), (4, 0, False)])
+def test_tiled_frames_with_moving_cuts(world, halo, hostsink, tmp_path, oracle_lib):
+    """Moving cuts (pwn_tiled_balance / pwn_tiled_set_cuts): the strips are re-cut every second delivered frame from
+    what the trace launches measured, and twice by hand to cuts far from equal; every frame is the oracle's frame
+    whatever cuts it was traced with -- halo exchange, blur, gather offsets, the repeat after a missed halo (halo 1)
+    and the host-sink copies all follow the frame's own cuts."""
+    w, h, frames = 640, 360, 14
+    want = oracle_hashes(w, h, "pwnfps_level", frames, oracle_lib)
+    eq = [min(r * (-(-(-(-h // world)) // 8) * 8), h) for r in range(world)] + [h]
+    by_hand = {3: 24, 9: -16}
+    cuts_at = {k: [0] + [c + d for c in eq[1:-1]] + [h] for k, d in by_hand.items()}
+    rows, seen = [], []
+    hashes, infos = run_ranks(world, w, h, "pwnfps_level", frames, halo, tmp_path, hostsink=hostsink, seen=seen, balance=2, cuts_at=cuts_at, rows=rows)
+    assert [x[1] for x in hashes] == want
+    if hostsink:
+        assert all(sn == want for sn in seen)
+    cuts_of = _check_rows(rows, world, h, frames)
+    assert cuts_of[0] == eq and cuts_of[3] == cuts_at[3] and cuts_of[9] == cuts_at[9]
+    # the launches measured something, and it moved the cuts away from what was set by hand
+    assert all(x[3] > 0 for x in rows[0])
+    assert len({tuple(c) for c in cuts_of}) >= 4
+    assert infos[0]["recuts"] >= 2 and len({i["recuts"] for i in infos}) == 1
+    assert all(i["balance_every"] == 2 and i["max_rows"] >= -(-h // world) for i in infos)
+
+
+def test_moving_cuts_even_out_the_strips_of_a_4k_frame(tmp_path, oracle_lib, cases):
+    """3 ranks at the BASELINE frame size, the same frame sixteen times, a re-cut every second frame: the frames stay the
+    compiled reference's golden frame and the strips' costs come closer together than with the equal split."""
+    want = [c for c in cases if c["name"] == "level_spawn_3840x2160"][0]["post"]
+    rows = []
+    frames = 16
+    hashes, infos = run_ranks(3, 3840, 2160, "pwnfps_level", frames, -1, tmp_path, balance=2, rows=rows, extra_env={"TILED_SAME_SCENE": "1"})
+    assert [x[1] for x in hashes] == [want] * frames
+    cuts_of = _check_rows(rows, 3, 2160, frames)
+    cost = lambda k: [[x for x in rows[r] if x[0] == k][0][3] for r in range(3)]       # noqa: E731
+    spread = lambda c: max(c) / (sum(c) / len(c))                                     # noqa: E731
+    first, last = cost(0), cost(frames - 1)
+    assert cuts_of[-1] != cuts_of[0] and spread(last) < spread(first) and spread(last) < 1.04, (first, last, cuts_of[-1])

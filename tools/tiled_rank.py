@@ -8,7 +8,9 @@ Rank 0 creates the group id and writes it to IDFILE (.tmp + rename); the others 
 file.  Every frame has its own camera, sec_current and sphere set (tools/tiled_rank.scene), so a
 frame that is delivered late or from the wrong buffers shows.  Rank 0 prints one line per frame:
     frame K fnv64 HASH redone R
-and every rank a line `info {...}` (pwn_tiled_info).  TILED_HOSTSINK=1: frames are delivered into POSIX shared
+and every rank a line `info {...}` (pwn_tiled_info) and per frame `rows K Y0 Y1 COST` (the rows it traced of that frame and
+what they cost).  TILED_BALANCE=k: pwn_tiled_balance(k) (moving cuts); TILED_CUTS_AT="K:c0,c1,..;K2:.." calls
+pwn_tiled_set_cuts in front of frame K.  TILED_HOSTSINK=1: frames are delivered into POSIX shared
 memory by every rank (pwn_tiled_host_sink); the other ranks then print `seen K fnv64 HASH` too."""
 import json
 import os
@@ -79,23 +81,34 @@ def main():
         os.close(fd)
         r.tiled_host_sink(mm)
 
+    if os.environ.get("TILED_BALANCE") is not None:
+        r.tiled_balance(int(os.environ["TILED_BALANCE"]))
+    cuts_at = {}
+    for part in filter(None, os.environ.get("TILED_CUTS_AT", "").split(";")):
+        k, c = part.split(":")
+        cuts_at[int(k)] = [int(v) for v in c.split(",")]
+
     def deliver(k):
         fr = r.tiled_wait(host=True)
         assert fr["seq"] == k + 1
+        print("rows %d %d %d %d" % (k, fr["y0"], fr["y1"], fr["cost"]), flush=True)
         if rank == 0:
             print("frame %d fnv64 %s redone %d" % (k, oracle.fnv64(fr["sbuf"]), int(fr["redone"])), flush=True)
         elif hostsink:
             # with a host sink every rank holds the whole frame when its wait returns
             print("seen %d fnv64 %s" % (k, oracle.fnv64(fr["sbuf"])), flush=True)
     for k in range(frames):
-        cam, sec, sph = scene(k, base, spawn)
+        cam, sec, sph = scene(0 if os.environ.get("TILED_SAME_SCENE") else k, base, spawn)
         r.set_objects(sph)
+        if k in cuts_at:
+            r.tiled_set_cuts(cuts_at[k])
         r.tiled_submit(cam, sec)
         if k >= 2:
             deliver(k - 2)
     for k in range(max(0, frames - 2), frames):
         deliver(k)
     print("info " + json.dumps(r.tiled_info()), flush=True)
+    print("cuts " + json.dumps([int(v) for v in r.tiled_get_cuts()[0]]), flush=True)
     r.tiled_shutdown()
     r.close()
     if mm is not None:                       # (the mapping itself goes with the process: views of it are still alive)
