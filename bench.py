@@ -24,6 +24,13 @@ the spread over blocks and over single launches is reported next to it.
 
 Prints ONE JSON line on rank 0.  After the timed region the last frame is
 hashed and compared with the golden hash of the compiled reference.
+
+N > 1: the line carries what it takes to read a first multi-GPU run from the driver's output alone --
+`tiling.per_rank` (every rank's trace / blur kernel times, the durations of the two grouped exchanges on the
+comm stream, host enqueue time per frame, rows and cost of its strip), the moving cuts, and `tiling.sweep`: short
+legs in the same run with the trace grid's room for RCCL at 0 / 16 / 64 workgroups, equal strips, one compute
+stream, and whole strips instead of the bounded halo.  `transport` says at top level what carried the data; over
+the shared-memory fallback the metric string says that the figure is NOT RCCL over xGMI.
 """
 import argparse
 import json
@@ -91,6 +98,21 @@ def pmc_issue_rate(kernel, w, h, launch_ms):
         return out
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
+
+
+def issue_frac(w, h, level, launch_ms):
+    """VALU issue time of one launch by the committed issue model (tools/issue_model.py -> profiles/r3_issue_model.json) over the
+    measured launch time.  None when the model was not made for this frame."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r3_issue_model.json")) as f:
+            m = json.load(f)
+        for c in m["cases"]:
+            if (c["w"], c["h"], c["level"]) == (w, h, level) and launch_ms > 0:
+                return {"valu_issue_ms_model": c["valu_issue_ms"], "frac": round(c["valu_issue_ms"] / launch_ms, 4),
+                        "model": "profiles/r3_issue_model.txt"}
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(w, h, cam, spheres, level_file, target_s=10.0):
@@ -282,7 +304,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--level", default="pwnfps_level")
     ap.add_argument("--blur", type=int, default=1)
-    ap.add_argument("--min-time", type=float, default=1.0, help="repeat the K-step block until this many seconds were timed")
+    ap.add_argument("--min-time", type=float, default=3.0, help="repeat the K-step block until this many seconds were timed (each of the "
+                    "resident and the d2h leg: the GPU is busy for >= 6 s of a default run)")
+    ap.add_argument("--sweep-time", type=float, default=0.3, help="N > 1: seconds timed per leg of tiling.sweep (0 = no sweep)")
     ap.add_argument("--slots", type=int, default=3, help="frames in flight of the d2h_inclusive leg")
     ap.add_argument("--resident-slots", type=int, default=3, help="N = 1: frames in flight of the resident loop (1 = strictly one after the other)")
     ap.add_argument("--scheduler", choices=["units", "refill"], default=None, help="trace kernel scheduler (default: the library's)")
@@ -338,7 +362,7 @@ def main():
     r.set_blur_passes(args.blur)
     if args.scheduler:
         r.set_scheduler(args.scheduler)
-    r.set_frame_timing(max(1, args.time_every))
+    r.set_frame_timing(max(1, args.time_every))       # (N = 1 with two compute streams: off in the headline leg, see the roofline leg)
     _, _, spawn = r.get_level()
     cam = pwnfps_amd.spawn_camera(spawn)            # main.c:61-64
     sec = 0.0
@@ -355,7 +379,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    # The CPU baseline runs FIRST (rank 0, N = 1): ~15 s of host work, then the GPU legs in one piece (>= 6 s busy).
+    cpu_line = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu_line = cpu_baseline(w, h, cam, spheres, level_file)
+
     nres = max(1, min(args.resident_slots, 4))
+    # frames alternate between two compute streams (the library's default, PWN_OPT_FRAME_OVERLAP; PWN_FRAME_OVERLAP=0 in the
+    # environment switches it off): the next frame's trace grid fills what the current one's tail leaves idle
+    overlap_on = os.environ.get("PWN_FRAME_OVERLAP", "1") not in ("0", "") and nres >= 2
     tinfo = None
     if world == 1:
         r.frames_config(nres, sbuf=False)
@@ -376,14 +408,14 @@ def main():
                 transport = "shm"
                 transport_note = transport_note or "librccl could not be loaded on another rank"
                 print("bench.py rank %d: %s -- falling back to the shared-memory transport" % (rank, transport_note), file=sys.stderr)
-        def bring_up(tp):
-            """Communicator plus four frames through every leg of the exchange (halo group, gather group, miss
+        def bring_up(tp, halo=None):
+            """Communicator plus four frames through every leg of the exchange (halo group, gather group, the ranks'
             words); every rank learns whether ALL ranks got through."""
             u = [pwnfps_amd.Renderer.tiled_unique_id(tp) if rank == 0 else None]
             dist.broadcast_object_list(u, src=0)
             err = None
             try:
-                r.tiled_init(rank, world, u[0], tp, args.halo)
+                r.tiled_init(rank, world, u[0], tp, args.halo if halo is None else halo)
                 for i in range(4):
                     r.set_objects(spheres)
                     r.tiled_submit(cam, sec)
@@ -413,6 +445,20 @@ def main():
 
     launch_ms = []
     last = {"f": None}
+    diag = {"trace_ms": [], "blur_ms": [], "halo_ms": [], "gather_ms": [], "frame_ms": [], "enqueue_us": [], "rows": 0, "cost": 0, "redone": 0}
+
+    def diag_reset():
+        for k in diag:
+            diag[k] = [] if isinstance(diag[k], list) else 0
+        launch_ms.clear()
+
+    def per_rank():
+        """every rank's means of what it measured since diag_reset(), gathered over the control plane"""
+        mine = {k: (round(float(np.mean(v)), 4) if v else None) for k, v in diag.items() if isinstance(v, list)}
+        mine.update(rows=diag["rows"], cost=diag["cost"], frames_redone=diag["redone"], timed_frames=len(diag["trace_ms"]))
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        return {k: [e[k] for e in every] for k in mine}
     early = args.prepare == "early"
 
     # Every step re-bins and re-uploads the spheres first, like the reference's frame loop does
@@ -422,6 +468,15 @@ def main():
         def note(f):
             if f["timed"]:
                 launch_ms.append(f["trace_ms"])
+                if world > 1:
+                    for k in ("trace_ms", "blur_ms", "halo_ms", "gather_ms", "frame_ms"):
+                        if f[k] > 0:
+                            diag[k].append(f[k])
+            if world > 1:
+                diag["enqueue_us"].append(f["enqueue_us"])
+                diag["rows"] = f["y1"] - f["y0"]
+                diag["cost"] = f["cost"]
+                diag["redone"] += int(f["redone"])
             last["f"] = f
         if world == 1:
             # N = 1: the slot ring of the frames API, frames stay on the device
@@ -462,19 +517,43 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
-    run(args.warmup)
-    launch_ms.clear()
-    block_s = []
-    while True:
-        block_s.append(block())
-        # all ranks see the same (max-reduced) times, so they stop together
-        if sum(block_s) >= args.min_time or len(block_s) >= 500:
-            break
-    dt = float(np.median(block_s))
+    def leg(warmup, min_time, max_blocks=500):
+        """warm-up, then K-step blocks until min_time seconds were timed: (median block seconds, all blocks)"""
+        run(warmup)
+        diag_reset()
+        blocks = []
+        while True:
+            blocks.append(block())
+            # all ranks see the same (max-reduced) times, so they stop together
+            if sum(blocks) >= min_time or len(blocks) >= max_blocks:
+                break
+        return float(np.median(blocks)), blocks
+
+    if world == 1 and overlap_on:
+        # events between the kernels of frames that share the chip would time neither kernel by itself and cost a few
+        # microseconds of pipeline each: the headline leg records none, the roofline leg below times solo launches
+        r.set_frame_timing(0)
+    dt, block_s = leg(args.warmup, args.min_time)
+    roofline_leg = None
+    if world == 1 and overlap_on:
+        # ---- the roofline's launch duration: the same loop on ONE compute stream, every time_every-th frame between HIP
+        # events on the launch stream -- a launch by itself, as `roofline` is defined
+        r.set_frame_overlap(False)
+        r.set_frame_timing(max(1, args.time_every))
+        dt1, bl1 = leg(max(2, args.warmup // 2), min(args.min_time, 1.0))
+        roofline_leg = {"what": "the resident loop on one compute stream (PWN_OPT_FRAME_OVERLAP 0), where a launch runs by itself",
+                        "ms_per_step": round(dt1 / args.steps * 1e3, 4), "value": round(w * h * args.steps / dt1 / 1e6, 3), "blocks": len(bl1)}
+        r.set_frame_overlap(True)
     trace_ms = max_over_ranks(float(np.mean(launch_ms)) if launch_ms else 0.0)
+    launch_ms_headline = list(launch_ms)
+    ranks = None
+    sweep = None
+    cuts_now = None
     if world > 1:
         tinfo = r.tiled_info()
         redone = max_over_ranks(float(tinfo["frames_redone"]))
+        ranks = per_rank()
+        cuts_now = [int(v) for v in r.tiled_get_cuts()[0]]
 
     # ---- outside the timed region: parity of the last frame, work counters ----
     parity = None
@@ -493,6 +572,40 @@ def main():
                 parity = bool(frame_hash == (want[0]["post"] if args.blur else want[0]["pre"]))
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("parity check skipped: %s\n" % e)
+
+    # ---- N > 1: the same run, other settings, a fraction of a second each: what a first multi-GPU run should look at
+    if world > 1 and args.sweep_time > 0:
+        sweep = {}
+
+        def point(name, what):
+            d2, bl = leg(max(2, args.warmup // 2), args.sweep_time, 60)
+            pr = per_rank()
+            sweep[name] = {"what": what, "value": round(w * h * args.steps / d2 / 1e6, 3), "ms_per_step": round(d2 / args.steps * 1e3, 4),
+                           "blocks": len(bl), "trace_ms": pr["trace_ms"], "blur_ms": pr["blur_ms"], "halo_ms": pr["halo_ms"],
+                           "gather_ms": pr["gather_ms"], "enqueue_us": pr["enqueue_us"], "rows": pr["rows"]}
+        reserve0 = tinfo["grid_reserve"]
+        for rsv in (0, 16, 64):
+            r.tiled_set_reserve(rsv)
+            point("reserve_%d" % rsv, "PWN_TILED_RESERVE = %d workgroups of the persistent trace grid left free for the transport's kernels" % rsv)
+        r.tiled_set_reserve(reserve0)
+        bal = tinfo["balance_every"]
+        r.tiled_balance(0)
+        r.tiled_set_cuts([min(k * tinfo["rows_per_rank"], h) for k in range(world)] + [h])
+        point("equal_strips", "pwn_tiled_balance(0) with the equal split (the reference's static schedule, screen.h:63-64)")
+        r.tiled_balance(bal)
+        barrier()
+        r.tiled_shutdown()
+        r.set_frame_overlap(False)
+        ok1, _ = bring_up(transport)
+        if ok1:
+            point("one_stream", "PWN_OPT_FRAME_OVERLAP 0: every frame's kernels on ONE compute stream")
+        barrier()
+        r.tiled_shutdown()
+        r.set_frame_overlap(True)
+        ok2, _ = bring_up(transport, halo=0)
+        if ok2:
+            point("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows")
+        # (the host-sink leg below sets the tiling up once more)
 
     counters = None
     pcie = None
@@ -534,15 +647,24 @@ def main():
 
     if rank == 0:
         pix = w * h
+        not_rccl = world > 1 and transport != "rccl"
         if world == 1:
-            strip_pix, par = pix, "rows/1, %d frames in flight" % nres
+            strip_pix, par = pix, "rows/1, %d frames in flight on %s" % (nres, "two compute streams" if overlap_on else "one compute stream")
         else:
-            strip_pix = (tinfo["y1"] - tinfo["y0"]) * w
-            par = "rows/%d, two grouped %s send/recv launches per frame (%s; the gather of the strips of the frame two back), 3 frames in flight" % (
-                world, transport.upper(), ("%d halo rows per neighbour" % tinfo["halo_rows"]) if tinfo["halo_rows"] else "whole pre-blur strips to every rank")
+            # the roofline's launch: the rank whose trace launches took longest, with the rows it traced
+            tm = [v if v is not None else 0.0 for v in ranks["trace_ms"]]
+            slow = int(np.argmax(tm))
+            strip_pix = ranks["rows"][slow] * w
+            trace_ms = tm[slow]
+            par = "rows/%d with moving cuts, two grouped %s send/recv launches per frame (%s; the gather of the strips of the frame two back), 3 frames in flight on %s" % (
+                world, transport.upper(), ("%d halo rows per neighbour" % tinfo["halo_rows"]) if tinfo["halo_rows"] else "whole pre-blur strips to every rank",
+                "two compute streams" if tinfo["two_streams"] else "one compute stream")
         achieved = TRACE_BYTES_PER_PIXEL * strip_pix / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
         line = {
-            "metric": "Mpixels/s at 3840x2160 (level.txt scene, trace + blur), mean steps/ray alongside",
+            "metric": ("Mpixels/s at %dx%d (level.txt scene, trace + blur), frames resident on the device; mean steps/ray alongside"
+                       % (w, h)) + ("; d2h_inclusive = the rate with every frame delivered to the host (SURVEY 8d)" if not args.no_d2h else "")
+                      + (" -- MEASURED OVER THE HOST-STAGED SHARED-MEMORY TEST TRANSPORT, NOT RCCL OVER xGMI" if not_rccl else ""),
+            "transport": (None if world == 1 else ("rccl" if transport == "rccl" else "shm: host-staged test transport, NOT RCCL over xGMI")),
             "value": round(pix * args.steps / dt / 1e6, 3),
             "unit": "Mpixels/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -550,9 +672,12 @@ def main():
             "timing": {"blocks_of_k_steps": len(block_s), "value_is": "median block",
                        "block_ms_p10_p50_p90": [round(float(np.percentile(block_s, q)) * 1e3, 4) for q in (10, 50, 90)],
                        "first_block_ms": round(block_s[0] * 1e3, 4),
-                       "trace_launch_ms_p10_p50_p90": [round(float(np.percentile(launch_ms, q)), 4) for q in (10, 50, 90)] if launch_ms else None,
-                       "launches_timed": len(launch_ms),
-                       "launches_timed_are": "every %d-th frame of the timed region (HIP events on the launch stream)" % max(1, args.time_every)},
+                       "trace_launch_ms_p10_p50_p90": [round(float(np.percentile(launch_ms_headline, q)), 4) for q in (10, 50, 90)] if launch_ms_headline else None,
+                       "launches_timed": len(launch_ms_headline),
+                       "launches_timed_are": ("every %d-th frame of the roofline leg (HIP events on the launch stream): the same loop on one compute "
+                                              "stream, where a launch runs by itself" if roofline_leg else
+                                              "every %d-th frame of the timed region (HIP events on the launch stream)") % max(1, args.time_every),
+                       "roofline_leg": roofline_leg},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -573,7 +698,10 @@ def main():
                          "instruction_issue": pmc_issue_rate("pwn_trace_kernel", w, h, trace_ms) if world == 1 and trace_ms > 0 else None,
                          "bytes_per_pixel": TRACE_BYTES_PER_PIXEL, "pixels_per_launch": strip_pix,
                          "avg_launch_ms": round(trace_ms, 4),
-                         "note": "VALU/divergence-bound DDA: tables live in LDS, compulsory HBM traffic is the 8 B/pixel written"},
+                         # what really bounds the kernel: the VALU issue time of its instruction stream (profiles/r3_issue_model.json:
+                         # per-block instruction mix x measured execution counts x measured issue cost per opcode class) over the launch
+                         "issue_frac": issue_frac(w, h, args.level, trace_ms) if world == 1 else None,
+                         "note": "VALU-issue-bound DDA (issue_frac): tables live in LDS, compulsory HBM traffic is the 8 B/pixel written"},
             # the second kernel of a frame, the one that really is a memory gather: 12 algorithmic
             # bytes per pixel (read colour 4 + depth 4, write 4), single-GPU figure from HIP events
             "blur_roofline": ({"bound": "hbm", "kernel": "pwn_blur_tiled_kernel", "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -587,18 +715,27 @@ def main():
             "frame_fnv64": frame_hash,
         }
         if world > 1:
-            line["tiling"] = {k: tinfo[k] for k in ("rows_per_rank", "halo_rows", "groups", "frames", "frames_redone", "bytes_sent", "bytes_received")}
+            line["tiling"] = {k: tinfo[k] for k in ("rows_per_rank", "halo_rows", "groups", "frames", "frames_redone", "bytes_sent", "bytes_received",
+                                                    "max_rows", "balance_every", "grid_reserve", "two_streams", "recuts")}
             line["tiling"]["transport"] = transport
             if transport_note:
                 line["tiling"]["transport_note"] = transport_note
+            line["tiling"]["cuts"] = cuts_now
+            # every rank's own account of the headline leg: kernel times of the timed frames (HIP events; with two compute
+            # streams a trace shares the chip with the neighbour frames' kernels), the two grouped exchanges on the comm
+            # stream (halo = this frame's border rows, gather = the finished strips of the frame two back + the ranks'
+            # words), host time inside pwn_tiled_submit per frame, the rows of its strip and what they cost
+            line["tiling"]["per_rank"] = ranks
+            if sweep is not None:
+                line["tiling"]["sweep"] = sweep
         if counters:
             line["work"] = counters
         if kernel_ms:
             line["kernel_ms"] = kernel_ms
         if pcie:
             line["d2h_inclusive"] = pcie
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(w, h, cam, spheres, level_file)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
 
     if world > 1:

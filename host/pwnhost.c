@@ -177,7 +177,8 @@ int main(int argc, char **argv)
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
 	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL, window = 0, frames_given = 0, hostsink = 0;
 	int rank_given = 0, device_given = 0;
-	const char *idfile = NULL;
+	const char *idfile = NULL, *nonce = "";
+	const time_t started = time(NULL);
 	float turn = 0.0f, fixed_dt = -1.0f;
 	for(int i = 1; i < argc; i++)
 	{
@@ -205,6 +206,7 @@ int main(int argc, char **argv)
 			case 'W': world = atoi(argv[++i]); break;
 			case 'R': rank = atoi(argv[++i]); rank_given = 1; break;
 			case 'I': idfile = argv[++i]; break;
+			case 'N': nonce = argv[++i]; break;
 			case 'H': halo = atoi(argv[++i]); break;
 			case 'M': hostsink = atoi(argv[++i]); break;
 			case 'T': transport = strcmp(argv[++i], "shm") == 0 ? PWN_TRANSPORT_SHM : PWN_TRANSPORT_RCCL; break;
@@ -215,7 +217,7 @@ int main(int argc, char **argv)
 	{
 		fprintf(stderr, "usage: pwnhost level.txt [-s spheres.txt | -g game_objects.txt] [-w W] [-h H] [-x SCALE] "
 			"[-n FRAMES] [-t SEC_PER_FRAME] [-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE] [-v 1] [-q SLOTS]\n"
-			"       [-W WORLD -R RANK -I IDFILE [-T rccl|shm] [-H HALO_ROWS]]\n");
+			"       [-W WORLD -R RANK -I IDFILE [-N LAUNCH_NONCE] [-T rccl|shm] [-H HALO_ROWS]]\n");
 		return 2;
 	}
 	/* -W WORLD without -R: this process starts the other ranks itself (fork, before anything touches a GPU): rank r
@@ -322,27 +324,42 @@ int main(int argc, char **argv)
 	{
 		/* the frame loop of main.c:93-140 with every frame row-tiled over `world` processes; two frames in
 		   flight (three), the present step two frames behind; every rank runs the same loop (and the same script) */
+		/* The group id travels through IDFILE, and an id belongs to ONE launch: a file left behind by an earlier run of
+		   the same command would hand ranks 1.. the previous run's id, and rank 0 would wait in ncclCommInitRank for
+		   peers that never come.  So the file starts with a line "pwnid <nonce>": the launcher gives every rank of a
+		   launch the same -N NONCE (anything unique: its pid, a timestamp) and the other ranks take only a file that
+		   carries it; without -N they take only a file written after they started themselves, less a minute for
+		   launchers that start the ranks one by one.  Rank 0 removes IDFILE before it writes the new one and again
+		   when it is done. */
 		unsigned char id[PWN_TILED_ID_BYTES];
+		char head[128];
+		snprintf(head, sizeof(head), "pwnid %.100s\n", nonce);
+		const size_t hlen = strlen(head);
 		if(rank == 0)
 		{
+			unlink(idfile);
 			CHK(pwn_tiled_unique_id(id, transport));
 			char tmp[1024];
 			snprintf(tmp, sizeof(tmp), "%s.tmp", idfile);
 			FILE *fp = fopen(tmp, "wb");
-			if(fp == NULL || fwrite(id, 1, sizeof(id), fp) != sizeof(id)) { fprintf(stderr, "cannot write %s\n", tmp); pwn_destroy(ctx); return 1; }
+			if(fp == NULL || fwrite(head, 1, hlen, fp) != hlen || fwrite(id, 1, sizeof(id), fp) != sizeof(id)) { fprintf(stderr, "cannot write %s\n", tmp); pwn_destroy(ctx); return 1; }
 			fclose(fp);
 			rename(tmp, idfile);
 		}
 		else
 		{
-			FILE *fp = NULL;
-			for(int tries = 0; tries < 12000 && (fp = fopen(idfile, "rb")) == NULL; tries++)
+			int got = 0;
+			for(int tries = 0; tries < 12000 && !got; tries++)
 			{
-				struct timespec ts = { 0, 10 * 1000 * 1000 };
-				nanosleep(&ts, NULL);
+				struct stat sb;
+				FILE *fp = fopen(idfile, "rb");
+				char have[128];
+				if(fp != NULL && fstat(fileno(fp), &sb) == 0 && (nonce[0] != 0 || sb.st_mtime >= started - 60) &&
+				   fread(have, 1, hlen, fp) == hlen && memcmp(have, head, hlen) == 0 && fread(id, 1, sizeof(id), fp) == sizeof(id)) got = 1;
+				if(fp != NULL) fclose(fp);
+				if(!got) { struct timespec ts = { 0, 10 * 1000 * 1000 }; nanosleep(&ts, NULL); }
 			}
-			if(fp == NULL || fread(id, 1, sizeof(id), fp) != sizeof(id)) { fprintf(stderr, "rank %d: no group id in %s\n", rank, idfile); pwn_destroy(ctx); return 1; }
-			fclose(fp);
+			if(!got) { fprintf(stderr, "rank %d: no group id of this launch in %s (a stale file of an earlier run? see -N)\n", rank, idfile); pwn_destroy(ctx); return 1; }
 		}
 		CHK(pwn_tiled_init(ctx, rank, world, id, transport, halo));
 		void *host_frames = NULL;
@@ -410,9 +427,9 @@ int main(int argc, char **argv)
 		double t2 = now_s();
 		pwn_tiled_info inf;
 		CHK(pwn_tiled_get_info(ctx, &inf));
-		printf("rank %d of %d: rows [%d,%d), halo %d rows, %llu frames (%llu repeated with whole strips), %llu grouped exchanges, sent %.1f MB, received %.1f MB\n",
-			inf.rank, inf.world, inf.y0, inf.y1, inf.halo_rows, (unsigned long long)inf.frames, (unsigned long long)inf.frames_redone,
-			(unsigned long long)inf.groups, (double)inf.bytes_sent / 1e6, (double)inf.bytes_received / 1e6);
+		printf("rank %d of %d: rows [%d,%d) now (the cuts moved %llu times; %d rows to begin with), halo %d rows, %llu frames (%llu repeated with whole strips), %llu grouped exchanges, sent %.1f MB, received %.1f MB\n",
+			inf.rank, inf.world, inf.y0, inf.y1, (unsigned long long)inf.recuts, inf.rows_per_rank, inf.halo_rows, (unsigned long long)inf.frames,
+			(unsigned long long)inf.frames_redone, (unsigned long long)inf.groups, (double)inf.bytes_sent / 1e6, (double)inf.bytes_received / 1e6);
 		if(rank == 0)
 		{
 			CHK(pwn_screen_upscale(ctx, tf.sbuf, rscale, surface.pitch, surface.pixels));      /* main.c:108 */
@@ -440,7 +457,7 @@ int main(int argc, char **argv)
 			int st = 0;
 			if(waitpid(kids[i], &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
 		}
-		if(nkids > 0 && idfile == idbuf) unlink(idfile);
+		if(rank == 0) unlink(idfile);                /* (every rank has read it: pwn_tiled_init is a collective) */
 		return bad;
 	}
 	if(slots > 0)

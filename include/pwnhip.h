@@ -69,6 +69,14 @@ typedef struct pwn_stats
 	   constant 100 MHz clock: sum of the waves' lifetimes, first start to last end, number of waves.
 	   wave_time / (waves * kernel_span) = share of the kernel's duration the average wave was resident */
 	uint64_t wave_time, kernel_span, waves;
+	/* counted frames: how often a wave64 entered each region of the kernel outside the walk's paths above (the issue
+	   model, tools/issue_model.py; the order is trace_common.h's RG_* enum): 0 ray segment set-up, 1 its slow path, 2 exhausted
+	   rays, 3 wall shading, 4 sphere shading, 5 floor normal, 6 sphere mirror, 7 jitter + push, 8 / 9 composite of the last
+	   bounce and its fog, 10 / 11 of the first, 12 help-another-queue, 13 units, 14 sphere tests (list loop trips), 15
+	   nearer-sphere updates, 16 walk iterations with a lane in a non-room cell, 17 units in the right half of a 32-pixel tile,
+	   18 / 19 height-change block: out of a 2-high cell, and its wall test, 20 portal letters that are walls, 21 portal
+	   crossings, 22 / 23 those that turn by a quarter / by a half, 24 waves of the launch */
+	uint64_t regions[32];
 } pwn_stats;
 
 /* options for pwn_set_option */

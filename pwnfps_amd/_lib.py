@@ -34,7 +34,7 @@ class Stats(C.Structure):
                 ("sphere_tests", C.c_uint64), ("exhausted", C.c_uint64), ("wave_steps", C.c_uint64),
                 ("trace_ms", C.c_float), ("blur_ms", C.c_float), ("total_ms", C.c_float), ("reserved_", C.c_float),
                 ("wave_paths", C.c_uint64 * 8), ("phase_passes", C.c_uint64), ("phase_lanes", C.c_uint64),
-                ("wave_time", C.c_uint64), ("kernel_span", C.c_uint64), ("waves", C.c_uint64)]
+                ("wave_time", C.c_uint64), ("kernel_span", C.c_uint64), ("waves", C.c_uint64), ("regions", C.c_uint64 * 32)]
 
 
 class Frame(C.Structure):

@@ -67,6 +67,7 @@ template<class TP> __device__ __forceinline__ float tab_rcp(TP tab, float x)
 		r = sign | (rcp_entry(tab, a) - (a & 0x7f800000u));
 	else
 	{
+//@SLOW
 		uint32_t e = a >> 23, m = a & 0x7fffffu;
 		if(e == 0u) r = sign | 0x7f800000u;      // zero / denormal (DAZ) -> inf
 		else if(e == 255u) r = m ? (b | 0x00400000u) : sign;
@@ -76,6 +77,7 @@ template<class TP> __device__ __forceinline__ float tab_rcp(TP tab, float x)
 			uint32_t t = rcp_entry(tab, a);
 			int re = (int)(t >> 23) - (int)e;
 			r = re <= 0 ? sign : (sign | (t - (e << 23)));
+//@FAST
 		}
 	}
 	return __uint_as_float(r);
@@ -97,6 +99,7 @@ template<class TP> __device__ __forceinline__ float tab_rsqrt(TP tab, float x)
 	const bool special = !(b - 0x00800000u < 0x7f000000u);
 	if(__builtin_expect(__ballot(special) != 0ull, 0))
 	{
+//@SLOW
 		uint32_t sign = b & 0x80000000u, e = (b >> 23) & 0xffu, m = b & 0x7fffffu;
 		uint32_t q;
 		if(e == 255u && m) q = b | 0x00400000u;
@@ -104,6 +107,7 @@ template<class TP> __device__ __forceinline__ float tab_rsqrt(TP tab, float x)
 		else if(sign) q = 0xffc00000u;
 		else q = 0u;                               // +inf
 		r = special ? q : r;
+//@FAST
 	}
 	return __uint_as_float(r);
 }
@@ -156,10 +160,12 @@ __device__ __forceinline__ uint32_t col_pack4(float x, float y, float z, float w
 	const bool over = fmaxf(fmaxf(sx, sy), fmaxf(sz, sw)) >= 2147483648.0f;
 	if(__builtin_expect(__ballot(over) != 0ull, 0))
 	{
+//@SLOW
 		if(sx >= 2147483648.0f) pk &= ~0x000000ffu;
 		if(sy >= 2147483648.0f) pk &= ~0x0000ff00u;
 		if(sz >= 2147483648.0f) pk &= ~0x00ff0000u;
 		if(sw >= 2147483648.0f) pk &= ~0xff000000u;
+//@FAST
 	}
 	return pk;
 }
@@ -241,6 +247,7 @@ __device__ __forceinline__ uint32_t sincosf_sign_s(int n) { return (uint32_t)((n
 __device__ __forceinline__ uint32_t sincosf_sign_p(int n) { return (uint32_t)((n >> 1) & 1) << 31; }
 
 // which = 0: sinf, 1: cosf -- every input
+//@SLOW
 __device__ PWN_LIBM_ATTR float glibc_sincosf_general(float y, int which)
 {
 	double x = (double)y;
@@ -281,6 +288,7 @@ __device__ PWN_LIBM_ATTR float glibc_sincosf_general(float y, int which)
 		return sincos_poly(x * s, x * x, ((n + sign) & 2) ? -1.0 : 1.0, n ^ which);
 	}
 	return __builtin_nanf("");
+//@FAST
 }
 
 // which = 0: sinf, 1: cosf
@@ -366,10 +374,12 @@ template<class TP> __device__ PWN_LIBM_ATTR float glibc_expf_t(float x, TP lds_t
 	{
 		if(big)
 		{
+//@SLOW
 			if(__float_as_uint(x) == 0xff800000u) res = 0.0f;
 			else if(at >= 0x7f8u) res = x + x;
 			else if(x > 0x1.62e42ep6f) res = __builtin_inff();
 			else if(x < -0x1.9fe368p6f) res = 0.0f;
+//@FAST
 		}
 	}
 	return res;

@@ -82,7 +82,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 8; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
 	c->stream = NULL; c->copy_stream = NULL; c->stream2 = NULL; c->d_pre2 = NULL;
-	c->frame_overlap = 1; c->last_frame_done = NULL; c->serialize_next = false; c->last_frame_stream = NULL;
+	c->frame_overlap = 1; c->last_frame_done = NULL; c->last_frame_stream = NULL;
 	if(const char *e = getenv("PWN_FRAME_OVERLAP")) c->frame_overlap = atoi(e) != 0;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));
@@ -110,7 +110,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		if(hipMalloc((void **)&c->d_pre, n * 4) != hipSuccess ||
 		   hipMalloc((void **)&c->d_out, n * 4) != hipSuccess ||
 		   hipMalloc((void **)&c->d_z, n * 4) != hipSuccess ||
-		   hipMalloc((void **)&c->d_counters, 24 * sizeof(unsigned long long)) != hipSuccess ||
+		   hipMalloc((void **)&c->d_counters, PWN_NCOUNTERS * sizeof(unsigned long long)) != hipSuccess ||
 		   hipMalloc((void **)&c->d_tickets, PWN_TICKET_SETS * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
 		   hipMemset(c->d_tickets, 0, PWN_TICKET_SETS * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)) != hipSuccess ||
 		   hipMalloc((void **)&c->d_skip, sizeof(uint2) * (size_t)(width / 4 + 1)) != hipSuccess) { rc = PWN_ENOMEM; break; }
@@ -123,8 +123,20 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		   hipMemset(c->d_out, 0, n * 4) != hipSuccess) { rc = PWN_EHIP; break; }
 		if(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
 		   hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-		   hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess ||
-		   hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+		   hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+		// The second compute stream has to sit on another HARDWARE queue than the first, or the two only take turns.
+		// The runtime hands its hardware queues (four per priority level by default, GPU_MAX_HW_QUEUES) to streams as
+		// they are first used, and with PyTorch's streams, the copy and the upload stream in the same process the two
+		// compute streams of a context landed on the same one: frames "on two streams" measured exactly like frames
+		// on one (0.0823 / 0.0823 ms at 3840 x 272; 0.0823 / 0.0655 with GPU_MAX_HW_QUEUES=8).  Queues are pooled per
+		// priority, so a stream of another priority level is certain to have a queue of its own.
+		{
+			int least = 0, greatest = 0;
+			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+			int prio = greatest < 0 ? greatest : -1;          // (numerically lower = more urgent; 0 is the default level)
+			if(const char *e = getenv("PWN_DBG_STREAM2_PRIORITY")) if(*e) prio = atoi(e);
+			if(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio) != hipSuccess) { rc = PWN_EHIP; break; }
+		}
 		for(int i = 0; i < 4; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { rc = PWN_EHIP; break; }
 		for(int i = 0; i < PWN_NBLOB && rc == PWN_OK; i++)
 			if(hipEventCreateWithFlags(&c->ev_tables[i], hipEventDisableTiming) != hipSuccess ||
@@ -143,6 +155,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 			for(int k = 0; k < 32; k++) { A = (A * 25739u) & 0x7FFFFFFFu; C = (C * 25739u + 4u) & 0x7FFFFFFFu; }
 		}
 		if(hipMemcpy(c->d_skip, skip.data(), skip.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess) { rc = PWN_EHIP; break; }
+		// (the memsets above ran on the null stream; the context's streams are non-blocking and do not wait for it)
+		if(hipDeviceSynchronize() != hipSuccess) { rc = PWN_EHIP; break; }
 	} while(0);
 
 	if(rc != PWN_OK) { pwn_destroy(c); return rc; }
@@ -577,7 +591,7 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	P.has_w = !(cam[3] == 0.0f && cam[7] == 0.0f && cam[11] == 0.0f && cam[15] == 1.0f);
 	// test hook (tests/test_gpu_fuzz.py): send every camera through the general variant
 	if(c->dbg_force_hasw) P.has_w = 1;
-	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), stream));
+	if(c->counters_on) HIPCHK(c, hipMemsetAsync(c->d_counters, 0, PWN_NCOUNTERS * sizeof(unsigned long long), stream));
 	// persistent grid: as many workgroups as are resident at once, each striding over tiles
 	const bool refill = c->scheduler == PWN_SCHED_REFILL;
 	const size_t lds_bytes = ((P.blob_bytes + 15u) & ~15u) + (refill ? pwn_trace_refill_lds_extra(P.has_w != 0) : pwn_trace_lds_extra());
@@ -714,7 +728,6 @@ extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float s
 	// behind the frames in flight, whichever compute stream their kernels are on
 	if(c->last_frame_done != NULL && c->last_frame_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->last_frame_done, 0));
 	c->last_frame_done = NULL;       // (this call ends with the stream empty)
-	c->serialize_next = false;
 	HIPCHK(c, hipEventRecord(c->ev[0], s));
 	// trace into d_pre; with blur on, d_pre plays tsbuf and d_out plays sbuf
 	// (the memcpy of screen.h:75 becomes a pointer swap per pass)
@@ -768,7 +781,7 @@ static void frames_release(pwn_ctx *c)
 		if(c->stream2) (void)hipStreamSynchronize(c->stream2);
 		for(int i = 0; i < PWN_NBLOB; i++) c->tables_in_use[i] = false;
 	}
-	c->last_frame_done = NULL; c->serialize_next = false;       // (a slot's event, destroyed below)
+	c->last_frame_done = NULL;       // (a slot's event, destroyed below)
 	for(int i = 0; i < PWN_MAX_SLOTS; i++) slot_release(c->slot[i]);
 	c->nslots = 0;
 }
@@ -808,6 +821,14 @@ extern "C" int pwn_frames_config(pwn_ctx *c, int nslots, int flags, int scale, i
 		for(int k = 0; k < 4 && rc == PWN_OK; k++) if(hipEventCreate(&sl.ev_k[k]) != hipSuccess) rc = PWN_EHIP;
 		if(rc == PWN_OK && hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming) != hipSuccess) rc = PWN_EHIP;
 	}
+	// the pre-blur plane of the frames on the second compute stream (PWN_OPT_FRAME_OVERLAP)
+	if(rc == PWN_OK && nslots >= 2 && c->d_pre2 == NULL)
+	{
+		if(hipMalloc((void **)&c->d_pre2, n * 4) != hipSuccess) rc = PWN_ENOMEM;
+		else if(hipMemset(c->d_pre2, 0, n * 4) != hipSuccess) rc = PWN_EHIP;
+	}
+	// (the memsets above run on the null stream, which the non-blocking streams of the frames do not wait for)
+	if(rc == PWN_OK && hipDeviceSynchronize() != hipSuccess) rc = PWN_EHIP;
 	if(rc != PWN_OK) { frames_release(c); return rc; }
 	c->nslots = nslots; c->frame_flags = flags; c->frame_scale = scale; c->frame_pitch = pitch_bytes;
 	return PWN_OK;
@@ -832,24 +853,21 @@ extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int 
 	// 0.4429 ms per 4K frame.)  Every event between two kernels costs a few microseconds of pipeline, so only the
 	// ones somebody reads are recorded.
 	const bool counted = c->counters_on || c->wave_log_on;           // one set of counters: no second grid beside a counted one
-	const bool overlap = c->frame_overlap && c->nslots >= 2 && !counted && c->blur_passes <= 1;
+	const bool overlap = c->frame_overlap && c->nslots >= 2 && !counted && c->blur_passes <= 1 && (c->d_pre2 != NULL || c->blur_passes == 0);
 	const int par = overlap ? (int)(c->frame_seq & 1u) : 0;
 	hipStream_t s = par ? c->stream2 : c->stream;
-	if(par && c->d_pre2 == NULL && c->blur_passes > 0)
-	{
-		HIPCHK(c, hipMalloc((void **)&c->d_pre2, n * 4));
-		HIPCHK(c, hipMemset(c->d_pre2, 0, n * 4));
-	}
 	uint32_t *pre = par ? c->d_pre2 : c->d_pre;
-	// timing events: on every frame_timing-th frame (each event between two kernels is a few
-	// microseconds of pipeline: 0.428 against 0.417 ms per 4K frame with all frames timed).  A timed frame runs
-	// ALONE: it starts when the frame before it is done and the frame after it starts when it is done, so that its
-	// durations are those of the kernels and not of two grids sharing the chip (pwn_frame.trace_ms is what the
-	// bench line's roofline is defined on).
+	// timing events: on every frame_timing-th frame (each event between two kernels is a few microseconds of
+	// pipeline: 0.428 against 0.417 ms per 4K frame with all frames timed).  With two compute streams the
+	// durations are those of kernels that share the chip with the neighbour frames' kernels: a host that wants
+	// the duration of a launch by itself times frames with PWN_OPT_FRAME_OVERLAP 0 (bench.py's roofline leg).
+	// (Making a timed frame run alone -- its stream waits for the frame before it, the next frame's for it -- was
+	// tried: with the per-frame table upload in the picture the two waits between the streams cost 50 us per
+	// frame at 4K, 0.4335 against 0.3629 ms.)
 	const bool timing = c->frame_timing > 0 && (c->frame_seq % (uint64_t)c->frame_timing) == 0;
-	if(c->last_frame_done != NULL && c->last_frame_stream != s && (!overlap || timing || c->serialize_next))
-		HIPCHK(c, hipStreamWaitEvent(s, c->last_frame_done, 0));
-	c->serialize_next = timing && overlap;
+	// a frame on the other stream than the one before it is ordered behind that one only where the streams are
+	// not meant to run side by side
+	if(c->last_frame_done != NULL && c->last_frame_stream != s && !overlap) HIPCHK(c, hipStreamWaitEvent(s, c->last_frame_done, 0));
 	if(timing) HIPCHK(c, hipEventRecord(sl.ev_k[0], s));
 	// the last pass writes into the slot's own plane, which is what the copy stream reads while
 	// the next frame's kernels reuse the context's d_pre / d_out
@@ -944,8 +962,9 @@ extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 	(void)hipSetDevice(c->device);
 	if(c->counters_on)
 	{
-		unsigned long long v[24];
+		unsigned long long v[PWN_NCOUNTERS];
 		HIPCHK(c, hipMemcpy(v, c->d_counters, sizeof(v), hipMemcpyDeviceToHost));
+		for(int i = 0; i < 32; i++) c->stats.regions[i] = v[16 + i];
 		c->stats.rays = v[0]; c->stats.steps = v[1]; c->stats.portals = v[2];
 		c->stats.sphere_tests = v[3]; c->stats.exhausted = v[4]; c->stats.wave_steps = v[5];
 		for(int i = 0; i < 8; i++) c->stats.wave_paths[i] = v[6 + i];

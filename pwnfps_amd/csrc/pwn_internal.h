@@ -44,6 +44,7 @@ extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out
                           // of frame f+1's tables had to wait for the end of frame f-1 and so ran right where trace f starts;
                           // with three or four it runs at once, somewhere beside the trace grid: 0.3823 -> 0.3790 ms per 4K frame
 #endif
+#define PWN_NCOUNTERS 48     // device counters of the counting kernel variants: 16 (pwn_stats) + 24 regions + spare
 #define PWN_TICKET_SETS 4u  // launch n counts in set n mod 4 and clears set (n + 2) mod 4 (pwn_i_launch_trace)
 #define PWN_NSTAGE 4      // pinned staging buffers for those uploads
 
@@ -119,7 +120,6 @@ struct pwn_ctx
 	uint32_t *d_pre2;                // the pre-blur plane of the frames on stream2 (allocated with the first of them)
 	int frame_overlap;               // PWN_OPT_FRAME_OVERLAP
 	hipEvent_t last_frame_done; hipStream_t last_frame_stream;   // "kernels done" of the frame submitted last, and its stream
-	bool serialize_next;             // the next frame starts behind last_frame_done (the last one was a timed frame, which runs alone)
 	hipStream_t copy_stream;         // frames in flight: D2H of finished frames
 	hipEvent_t ev[4];
 	pwn_stats stats;

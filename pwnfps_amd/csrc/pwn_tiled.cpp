@@ -237,6 +237,10 @@ struct pwn_tiled
 	int fhalo[NSLOT];                   // ... as used for the frame in that slot (the mode changes after a miss)
 	int balance_every;                  // re-cut every this many delivered frames from the ranks' cost words; 0 = never
 	uint32_t last_cost[MAXW];           // the cost words of the last delivered frame (pwn_tiled_get_cuts)
+	// what the re-cut works from: per rank the SMALLEST cost among the delivered frames that were traced with acc_cuts
+	// (a launch that shared its GPU with something else for a moment -- another process, a clock dip -- reports a
+	// cost too high, never one too low), reset when a frame with other cuts is delivered
+	int acc_cuts[MAXW + 1]; uint32_t acc_cost[MAXW]; int acc_frames;
 	pwn_transport *tp;
 	hipStream_t comm;
 	// Compute: the kernels of frame f (trace f, later blur f) on cs[f & 1] -- two streams, so that the trace grid of
@@ -409,7 +413,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	(void)hipSetDevice(c->device);
 	// (frames of the frames-in-flight API may have used the second compute stream)
 	if(c->stream2 && hipStreamSynchronize(c->stream2) != hipSuccess) return PWN_EHIP;
-	c->last_frame_done = NULL; c->serialize_next = false;
+	c->last_frame_done = NULL;
 	pwn_tiled *t = new(std::nothrow) pwn_tiled();
 	if(t == NULL) return PWN_ENOMEM;
 	memset(t, 0, sizeof(*t));
@@ -464,7 +468,13 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 		}
 		else { rc = PWN_EINVAL; break; }
 
-		if(hipStreamCreateWithFlags(&t->comm, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+		// the exchange on a hardware queue of its own (queues are pooled per priority level: pwn_init on stream2) -- on a
+		// queue shared with a compute stream the transport's kernels would wait behind that stream's trace launches
+		{
+			int least = 0, greatest = 0;
+			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+			if(hipStreamCreateWithPriority(&t->comm, hipStreamNonBlocking, greatest < 0 ? greatest : -1) != hipSuccess) { rc = PWN_EHIP; break; }
+		}
 		if(hipMalloc((void **)&t->cost_acc, 128) != hipSuccess) { rc = PWN_ENOMEM; break; }
 		if(hipMemset(t->cost_acc, 0, 128) != hipSuccess) { rc = PWN_EHIP; break; }
 		for(int s = 0; s < NSLOT && rc == PWN_OK; s++)
@@ -510,6 +520,8 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 			}
 		}
 	} while(0);
+	// (the memsets above ran on the null stream, which the non-blocking streams of the frames do not wait for)
+	if(rc == PWN_OK && hipDeviceSynchronize() != hipSuccess) rc = PWN_EHIP;
 	if(rc != PWN_OK) { char keep[256]; memcpy(keep, c->err, sizeof(keep)); pwn_tiled_destroy(c); memcpy(c->err, keep, sizeof(keep)); return rc; }
 	// Room for RCCL's kernels beside the persistent trace grid (pwn_api.cpp): 16 workgroups of ~1280, i.e. one less
 	// on 16 CUs, 1.25 % of the grid.  Not measurable without several GPUs; PWN_TILED_RESERVE=n overrides it
@@ -907,10 +919,21 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	// ---- moving cuts: every balance_every delivered frames, new cuts from what this frame's strips cost.  Every
 	// rank has the same words and the same cuts of this frame, so every rank computes the same new cuts, and they
 	// take effect with the same frame: the next one submitted.
+	if(t->acc_frames == 0 || memcmp(t->acc_cuts, t->fcuts[s], sizeof(int) * (size_t)(t->world + 1)) != 0)
+	{
+		memcpy(t->acc_cuts, t->fcuts[s], sizeof(int) * (size_t)(t->world + 1));
+		memcpy(t->acc_cost, cost, sizeof(uint32_t) * (size_t)t->world);
+		t->acc_frames = 1;
+	}
+	else
+	{
+		for(int r = 0; r < t->world; r++) if(cost[r] < t->acc_cost[r]) t->acc_cost[r] = cost[r];
+		t->acc_frames++;
+	}
 	if(t->balance_every > 0 && t->world > 1 && ((d + 1) % (unsigned long long)t->balance_every) == 0)
 	{
 		int nc[MAXW + 1];
-		if(recut(t->fcuts[s], cost, t->world, c->h, t->halo > 0 ? t->halo : 8, t->max_rows, nc))
+		if(recut(t->acc_cuts, t->acc_cost, t->world, c->h, t->halo > 0 ? t->halo : 8, t->max_rows, nc))
 		{
 			memcpy(t->cuts, nc, sizeof(int) * (size_t)(t->world + 1));
 			t->info.recuts++;

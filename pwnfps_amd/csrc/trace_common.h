@@ -88,6 +88,22 @@ __device__ __forceinline__ uint32_t cxz_add(uint32_t c, uint32_t step)
 {
 	return __builtin_bit_cast(uint32_t, (pwn_s2)(__builtin_bit_cast(pwn_s2, c) + __builtin_bit_cast(pwn_s2, step)));
 }
+// Which face the ray came through (ldir of trace.h:156-184) is not selected per step: the walk keeps the STEP it
+// took last -- the packed (gx, 0) or (0, gz) it added to the cell, which it has in a register anyway -- and the
+// face is decoded from that where somebody needs it: after the walk, in a portal, at a solid cell.  0 stands for
+// FYN, the value a segment starts with (trace.h:247); LSTEP_FYP for the one face a ramp can add (trace.h:474).
+#define LSTEP_FYP 0x7fff7fffu
+__device__ __forceinline__ int lstep_dir(uint32_t s)
+{
+	const int xz = (s & 0xffffu) ? (int)(s & 2u) : 1 + (int)((s >> 16) & 2u);        // +-1 in the low half: FXP / FXN, in the high half: FZP / FZN
+	return s == 0u ? FYN : (s == LSTEP_FYP ? FYP : xz);
+}
+__device__ __forceinline__ uint32_t lstep_of(int dir)
+{
+	const uint32_t v = (dir & 2) ? 0xffffu : 1u;
+	const uint32_t xz = (dir & 1) ? v << 16 : v;
+	return dir == FYN ? 0u : (dir == FYP ? LSTEP_FYP : xz);
+}
 __device__ __forceinline__ uint32_t cellword_pk(const Lds &L, uint32_t cxz)
 {
 	const pwn_us2 lim = { 64, 64 }, pitch = { 4, (unsigned short)(PWN_GRID_PITCH * 4u) };
@@ -144,6 +160,13 @@ enum { EV_NONE = 0, EV_WALL, EV_SPHERE, EV_EXHAUSTED };
 // the face and the colour follow from the ray's y sign after the walk
 enum { BASE_CEIL = 0, BASE_FLOOR, BASE_WALL, BASE_MAGENTA, BASE_ROOM_Y };
 
-struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps, wp[8], apasses, apass_lanes; };
+// Regions of the kernel for the issue model (tools/issue_model.py): `//@R name` comments in the sources mark their
+// extent, RG(k) counts -- in the counting variants -- how often a wave64 enters one with at least one lane
+// (pwn_stats.regions).  The walk's own paths are the older wave_paths counters (WAVE_PATH) and wave_steps.
+enum { RG_SEG = 0, RG_SETUP_SLOW, RG_EXHAUSTED, RG_WALL, RG_SPHERE, RG_FLOOR, RG_SPHREFL, RG_JITTER, RG_COMP1, RG_COMP1_FOG,
+	RG_COMP2, RG_COMP2_FOG, RG_HELP, RG_UNIT, RG_SPHTEST, RG_SPHUPD, RG_ELSE,
+	RG_UNIT_HALF, RG_HC_R2, RG_HC_OUT, RG_PORTAL_WALL, RG_PORTAL_GO, RG_PORTAL_ODD, RG_PORTAL_ROT2, RG_N };
+struct Counters { uint32_t rays, steps, portals, tests, exhausted, wsteps, wp[8], apasses, apass_lanes, rg[RG_N]; };
 // one count per wave64 that enters a code path with at least one lane (pwn_stats.wave_paths)
 #define WAVE_PATH(k) do { if(COUNT && (__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt.wp[k]++; } while(0)
+#define RG(k) do { if(COUNT && (__ffsll((long long)__ballot(1)) - 1) == (int)(threadIdx.x & 63)) cnt.rg[k]++; } while(0)

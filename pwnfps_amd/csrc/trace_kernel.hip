@@ -67,6 +67,8 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #pragma unroll 1
 	for(;;)
 	{
+		//@R p_setup
+		RG(RG_SEG);
 		seg = __builtin_amdgcn_readfirstlane(seg);
 		// ------------------------------------------------ trace.h:186-248
 		float cdist = 0.0f, fog = 0.0f;
@@ -107,12 +109,15 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			}
 			else
 			{
+				//@R p_setup_slow
+				RG(RG_SETUP_SLOW);
 				if(fabsf(ray.x) < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
 				if(fabsf(ray.y) < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
 				if(fabsf(ray.z) < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
 				iax = tab_rcp(L.rcp, fabsf(ray.x)); iay_ = tab_rcp(L.rcp, fabsf(ray.y)); iaz = tab_rcp(L.rcp, fabsf(ray.z));
 			}
 		}
+		//@R p_setup
 		const float iay = iay_;
 		float wx = pos.x - (float)cx, wy = pos.y, wz = pos.z - (float)cz;
 		if(ray.x >= 0.0f) wx = 1.0f - wx;
@@ -125,37 +130,79 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		const int ldy = gyp ? FYP : FYN;
 		uint32_t iay_up_bits = gyp ? __float_as_uint(iay) : 0u;         // +iay when looking up, else +0
 		asm volatile("" : "+v"(iay_up_bits));        // keep it a register, not a select on gyp per step
-		int ldx = (gx < 0 ? FXN : FXP), ldz = (gz < 0 ? FZN : FZP);
 		// cell coordinates and steps in the packed form the walk uses (trace_common.h)
 		uint32_t cxz = cxz_pack_start(cx, cz), sx = (uint32_t)gx & 0xffffu, sz = (uint32_t)gz << 16;
 
 		uint32_t cw = cellword_pk(L, cxz);
-		int ldir = FYN;
+		uint32_t lstep = 0u;                     // the step taken last; 0 = none yet = FYN (trace.h:247)
 		int ev = EV_NONE, base = BASE_ROOM_Y;
 
 		// ------------------------------------------------ trace.h:250-675 (trace_walk.inc)
+		//@R p_walk_ctl
+		// How the walk loop ends (PWN_WALK_EXIT, an experiment switch; profiles/r3_walk_exit.txt has the timings):
+		//   0  ev per step -- two selects in the room body (sphere hit / floor-ceiling / neither), the step limit
+		//      (trace.h:250) folded into it with three more VALU instructions, one compare of ev for the exit
+		//   1  the same, but the step limit is a scalar count with its own branch, and "exhausted" is written once,
+		//      after the loop
+		//   2  the room body records nothing: a lane mask `done` (hit || ymin) ends the loop and WHICH of the two it was
+		//      is read off cdist against aux_dist afterwards; the rare cells set ev themselves
 		int maxsteps = 1000;
+#ifndef PWN_WALK_EXIT
+#define PWN_WALK_EXIT 0
+#endif
+#if PWN_WALK_EXIT == 2
+		bool done;
+#define WALK_ROOM_ENDS(hit, ymin) done = (hit) || (ymin)
+#define WALK_ENDED() done = true
+#define WALK_ELSE_ENDS() done = ev != 0
 #pragma unroll 1
 		do
 		{
 #include "trace_walk.inc"
-			// trace.h:250,677: out of steps.  (Leaving the loop on the scalar counter instead and marking the
-			// lanes afterwards trades these 3 VALU for 4 SALU: measured equal, 0.3748 / 0.3731 ms at 4K.)
+			maxsteps = __builtin_amdgcn_readfirstlane(maxsteps) - 1;
+		} while(!done && maxsteps != 0);
+		// trace.h:250,677: out of steps; else what the room body left open (trace.h:313-330: the sphere first)
+		if(!done) ev = EV_EXHAUSTED;
+		else if(ev == 0) ev = cdist > aux_dist ? EV_SPHERE : EV_WALL;
+#else
+#define WALK_ROOM_ENDS(hit, ymin) ev = (hit) ? EV_SPHERE : ((ymin) ? EV_WALL : 0)
+#define WALK_ENDED() do { } while(0)
+#define WALK_ELSE_ENDS() do { } while(0)
+#pragma unroll 1
+		do
+		{
+#include "trace_walk.inc"
+#if PWN_WALK_EXIT == 1
+			maxsteps = __builtin_amdgcn_readfirstlane(maxsteps) - 1;
+		} while(ev == 0 && maxsteps != 0);
+		if(ev == 0) ev = EV_EXHAUSTED;              // trace.h:250,677: out of steps
+#else
+			// trace.h:250,677: out of steps
 			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
 		} while(ev == 0);
+#endif
+#endif
+#undef WALK_ROOM_ENDS
+#undef WALK_ENDED
+#undef WALK_ELSE_ENDS
 		// what the ray ended on is read back from the register: without this the compiler keeps
 		// "ev == EV_EXHAUSTED" as a lane mask that it updates in every iteration of the walk
 		// (5 of ~85 instructions per step)
 		asm volatile("" : "+v"(ev));
 
+		//@R p_post
 		if(ev == EV_EXHAUSTED)
 		{
+			//@R p_exhausted
+			RG(RG_EXHAUSTED);
 			// trace.h:677-678: out of steps -- the walked ray is the colour
 			if(COUNT) cnt.exhausted++;
 			vx = ray.x; vy = ray.y; vz = ray.z; vw = HAS_W ? ray.w : 0.0f;
 			depth = seg;
 			break;
 		}
+		//@R p_post
+		int ldir = lstep_dir(lstep);
 		if(ev == EV_WALL && base == BASE_ROOM_Y) { ldir = ldy; base = (gyp ? BASE_CEIL : BASE_FLOOR); }
 		// zbuf = the PRIMARY ray's hit distance (trace.h:102-105); a primary ray that ran out of steps
 		// leaves the old depth in place (trace.h:677)
@@ -164,6 +211,8 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		float colx, coly, colz, refl;
 		if(ev == EV_WALL)
 		{
+			//@R p_wall
+			RG(RG_WALL);
 			// trace.h:108-154, and the axis-aligned mirrors of trace.h:50-75.  Colour by wall class and what
 			// the face does to the ray are two constant tables in LDS (tables.h PWN_T_FACES): three 16-byte
 			// reads instead of two switch trees (which the compiler builds out of lane masks and branches)
@@ -188,6 +237,8 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		}
 		else
 		{
+			//@R p_sphere
+			RG(RG_SPHERE);
 			// trace.h:283-291 for the committed sphere
 			const PWN_LDS pwn_f4 *sp = (const PWN_LDS pwn_f4 *)((const PWN_LDS unsigned char *)L.sph + aux_idx);      // (a byte offset)
 			const pwn_f4 s0 = sp[0], s1 = sp[1];
@@ -202,12 +253,15 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			pos = aux_pos;
 		}
 
+		//@R p_post
 		// trace.h:3-7
 		if(seg >= REFLECT_MAX || refl == 0.0f) { vx = colx; vy = coly; vz = colz; vw = 0.0f; depth = seg; break; }
 
 		// trace.h:9-75
 		if(ldir == FYN)
 		{
+			//@R p_floor
+			RG(RG_FLOOR);
 			const float pi = (float)3.14159265358979323846;
 			float ang = (pi * 2.0f) * (
 				(glibc_sincosf((pi * 0.5f) * pos.x, 0) + glibc_sincosf((pi * 0.5f) * pos.z, 1))
@@ -220,11 +274,15 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		}
 		else if(ldir < 0)
 		{
+			//@R p_sphrefl
+			RG(RG_SPHREFL);
 			pos = vsub<HAS_W>(pos, vscale<HAS_W>(0.001f, ray));
 			float rmul = -2.0f * ((ray.x * aux_norm.x + ray.y * aux_norm.y) + ray.z * aux_norm.z);
 			ray = vnormalise<HAS_W>(L.rsq, vadd<HAS_W>(vscale<HAS_W>(rmul, aux_norm), ray));
 		}
 
+		//@R p_jitter
+		RG(RG_JITTER);
 		// trace.h:77-84: five draws, two discarded
 		ray.x += lcg_fs(seed) * REFLECT_BLUR_F;
 		ray.y += lcg_fs(seed) * REFLECT_BLUR_F;
@@ -239,24 +297,34 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		iray = ray;
 	}
 
+	//@R p_comp
 	// trace.h:91-101, innermost first
 	// the top of the stack is the last surface the ray bounced off, the entry below it the one before
 	if(depth >= 1)
 	{
+		//@R p_comp1
+		RG(RG_COMP1);
 		const float r0 = st_refl0, q0 = 1.0f - st_refl0;
 		vx = r0 * vx + q0 * sc0x; vy = r0 * vy + q0 * sc0y; vz = r0 * vz + q0 * sc0z; vw = r0 * vw;
 		if(st_fog0 != 0.0f)
 		{
+			//@R p_comp1_fog
+			RG(RG_COMP1_FOG);
 			float f = glibc_expf(-0.6f * st_fog0, L.exp2), g = 1.0f - f;
 			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 		}
 	}
+	//@R p_comp
 	if(depth >= 2)
 	{
+		//@R p_comp2
+		RG(RG_COMP2);
 		const float r1 = st_refl1, q1 = 1.0f - st_refl1;
 		vx = r1 * vx + q1 * sc1x; vy = r1 * vy + q1 * sc1y; vz = r1 * vz + q1 * sc1z; vw = r1 * vw;
 		if(st_fog1 != 0.0f)
 		{
+			//@R p_comp2_fog
+			RG(RG_COMP2_FOG);
 			float f = glibc_expf(-0.6f * st_fog1, L.exp2), g = 1.0f - f;
 			vx = f * vx + g; vy = f * vy + g; vz = f * vz + g; vw = f * vw + g;
 		}
@@ -264,6 +332,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #undef icx
 #undef icy
 #undef icz
+	//@R p_comp
 	out_x = vx; out_y = vy; out_z = vz; out_w = vw + w_acc;
 }
 
@@ -271,6 +340,7 @@ template<bool COUNT, bool HAS_W>
 __global__ void __launch_bounds__(PWN_BLOCK, PWN_MIN_WAVES)
 pwn_trace_kernel(pwn_trace_params P)
 {
+	//@R k_prologue
 	extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
 	// HBM -> LDS, 16 B per lane per trip
@@ -339,10 +409,13 @@ pwn_trace_kernel(pwn_trace_params P)
 	uint32_t left = 0u;
 	for(;;)
 	{
+		//@R k_unit
 		// units of queue q: q, q + Q, ...  below `units`
 		const uint32_t qlen = (units + PWN_QUEUES - 1u - q) / PWN_QUEUES;
 		if(ticket >= qlen)
 		{
+			//@R k_help
+			RG(RG_HELP);
 			if(++misses > 2 * (int)PWN_QUEUES) break;
 			left = 0u;
 			// this queue is empty: find one that is not (plain loads; a stale value can only
@@ -374,6 +447,8 @@ pwn_trace_kernel(pwn_trace_params P)
 			ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
 			continue;
 		}
+		//@R k_unit
+		RG(RG_UNIT);
 		misses = 0;
 		const uint32_t unit = ticket * PWN_QUEUES + q;
 		const bool draw = left == 0u;
@@ -423,9 +498,12 @@ pwn_trace_kernel(pwn_trace_params P)
 		V rayl = vadd<HAS_W>(vadd<HAS_W>(vscale<HAS_W>((float)cx0, rdx), rayb), vscale<HAS_W>((float)y, rdy));
 		if(half)
 		{
+			//@R k_unit_half
+			RG(RG_UNIT_HALF);
 #pragma unroll
 			for(int k = 0; k < 16; k++) rayl = vadd<HAS_W>(rayl, rdx);
 		}
+		//@R k_unit
 		rayl = vadd<HAS_W>(rayl, rdx);
 		{
 			const bool first = (l16 == 0);
@@ -459,17 +537,21 @@ pwn_trace_kernel(pwn_trace_params P)
 		left = draw ? draw_n - 1u : left - 1u;
 	}
 
+	//@R k_epilogue
 	if(COUNT)
 	{
 		// wave reduce, one atomic per wave and counter
-		unsigned long long v[16] = { cnt.rays, cnt.steps, cnt.portals, cnt.tests, cnt.exhausted, cnt.wsteps,
+		unsigned long long v[16 + RG_N] = { cnt.rays, cnt.steps, cnt.portals, cnt.tests, cnt.exhausted, cnt.wsteps,
 			cnt.wp[0], cnt.wp[1], cnt.wp[2], cnt.wp[3], cnt.wp[4], cnt.wp[5], cnt.wp[6], cnt.wp[7], cnt.apasses, cnt.apass_lanes };
-		for(int i = 0; i < 16; i++)
+		for(int i = 0; i < RG_N; i++) v[16 + i] = cnt.rg[i];
+		for(int i = 0; i < 16 + RG_N; i++)
 		{
 			unsigned long long s = v[i];
 			for(int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
 			if(lane == 0 && s) atomicAdd(&P.counters[i], s);
 		}
+		// (waves of this launch: the prologue and the epilogue of the issue model)
+		if(lane == 0) atomicAdd(&P.counters[16 + RG_N], 1ull);
 	}
 	// PWN_OPT_WAVE_LOG: every wave's lifetime (pwn_stats.wave_time ..., tools/wave_log.py)
 	// (Which wave of the workgroup this is comes from the hardware: the four waves of a 256-thread workgroup

@@ -181,6 +181,8 @@ class TiledFrames:
         self.balance_every = dflt if balance_every is None else (int(balance_every) if dflt else 0)
         self.recuts = 0
         self.last_cost = [0] * world
+        # what the re-cut works from: per rank the smallest cost among the delivered frames traced with acc_cuts
+        self.acc_cuts, self.acc_cost = None, None
         kw = dict(device=device)
         mk = lambda dt: [torch.zeros((self.h, self.w), dtype=dt, **kw) for _ in range(NSLOT)]   # noqa: E731
         # int32 views of the uint32 BGRA pixels (the transport does not care)
@@ -389,8 +391,12 @@ class TiledFrames:
             self._add_gather(d)
             self._end()
         # moving cuts: the same numbers on every rank, so the same new cuts, from the next submitted frame on
+        if self.acc_cuts != self.fcuts[s]:
+            self.acc_cuts, self.acc_cost = list(self.fcuts[s]), list(cost)
+        else:
+            self.acc_cost = [min(a, b) for a, b in zip(self.acc_cost, cost)]
         if self.balance_every > 0 and self.world > 1 and (d + 1) % self.balance_every == 0:
-            nc = recut(self.fcuts[s], cost, self.world, self.h, self.halo if self.halo > 0 else 8, self.max_rows)
+            nc = recut(self.acc_cuts, self.acc_cost, self.world, self.h, self.halo if self.halo > 0 else 8, self.max_rows)
             if nc is not None:
                 self.cuts = nc
                 self.recuts += 1

@@ -312,6 +312,7 @@ class Renderer:
         self._chk(lib.pwn_get_stats(self._ctx, C.byref(st)), "pwn_get_stats")
         out = {n: getattr(st, n) for n, _ in _lib.Stats._fields_ if n != "reserved_"}
         out["wave_paths"] = list(st.wave_paths)
+        out["regions"] = list(st.regions)
         return out
 
     def probe(self, op, words):

@@ -304,7 +304,10 @@ def test_moving_cuts_even_out_the_strips_of_a_4k_frame(tmp_path, oracle_lib, cas
     hashes, infos = run_ranks(3, 3840, 2160, "pwnfps_level", frames, -1, tmp_path, balance=2, rows=rows, extra_env={"TILED_SAME_SCENE": "1"})
     assert [x[1] for x in hashes] == [want] * frames
     cuts_of = _check_rows(rows, 3, 2160, frames)
-    cost = lambda k: [[x for x in rows[r] if x[0] == k][0][3] for r in range(3)]       # noqa: E731
-    spread = lambda c: max(c) / (sum(c) / len(c))                                     # noqa: E731
-    first, last = cost(0), cost(frames - 1)
-    assert cuts_of[-1] != cuts_of[0] and spread(last) < spread(first) and spread(last) < 1.04, (first, last, cuts_of[-1])
+    # (three processes take turns on ONE GPU here: now and then a launch is held up and reports a cost too high, never
+    # one too low -- the library's re-cut works from the smallest cost per rank for the same reason)
+    least = lambda ks: [min([x for x in rows[r] if x[0] == k][0][3] for k in ks) for r in range(3)]      # noqa: E731
+    spread = lambda c: max(c) / (sum(c) / len(c))                                                     # noqa: E731
+    first, last = least(range(0, 4)), least(range(frames - 6, frames))        # frames 0..3 were traced with the equal split
+    assert cuts_of[3] == cuts_of[0] and cuts_of[-1] != cuts_of[0], cuts_of[-1]
+    assert spread(last) < 1.03 and spread(last) <= spread(first) + 0.005, (first, last, cuts_of[-1])
