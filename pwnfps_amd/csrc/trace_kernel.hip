@@ -139,32 +139,13 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 
 		// ------------------------------------------------ trace.h:250-675 (trace_walk.inc)
 		//@R p_walk_ctl
-		// How the walk loop ends (PWN_WALK_EXIT, an experiment switch; profiles/r3_walk_exit.txt has the timings):
-		//   0  ev per step -- two selects in the room body (sphere hit / floor-ceiling / neither), the step limit
-		//      (trace.h:250) folded into it with three more VALU instructions, one compare of ev for the exit
-		//   1  the same, but the step limit is a scalar count with its own branch, and "exhausted" is written once,
-		//      after the loop
-		//   2  the room body records nothing: a lane mask `done` (hit || ymin) ends the loop and WHICH of the two it was
-		//      is read off cdist against aux_dist afterwards; the rare cells set ev themselves
+		// How the walk loop ends: ev per step -- two selects in the room body (sphere hit / floor-ceiling / neither), the
+		// step limit (trace.h:250) folded into it with three more VALU instructions, one compare of ev for the exit.
+		// Two other forms were built and measured in round 3 (profiles/r3_walk_exit.txt; the code is in commit 2b36426):
+		// the step limit as a scalar count with a branch of its own (-3 VALU, +2 scalar per step: +3.9 % time at 4K), and a
+		// lane mask `done` = hit || ymin with WHICH of the two read off cdist against aux_dist after the walk (-4 VALU,
+		// +10 scalar mask instructions per step as compiled: +5.3 %).  Scalar instructions are not free here.
 		int maxsteps = 1000;
-#ifndef PWN_WALK_EXIT
-#define PWN_WALK_EXIT 0
-#endif
-#if PWN_WALK_EXIT == 2
-		bool done;
-#define WALK_ROOM_ENDS(hit, ymin) done = (hit) || (ymin)
-#define WALK_ENDED() done = true
-#define WALK_ELSE_ENDS() done = ev != 0
-#pragma unroll 1
-		do
-		{
-#include "trace_walk.inc"
-			maxsteps = __builtin_amdgcn_readfirstlane(maxsteps) - 1;
-		} while(!done && maxsteps != 0);
-		// trace.h:250,677: out of steps; else what the room body left open (trace.h:313-330: the sphere first)
-		if(!done) ev = EV_EXHAUSTED;
-		else if(ev == 0) ev = cdist > aux_dist ? EV_SPHERE : EV_WALL;
-#else
 #define WALK_ROOM_ENDS(hit, ymin) ev = (hit) ? EV_SPHERE : ((ymin) ? EV_WALL : 0)
 #define WALK_ENDED() do { } while(0)
 #define WALK_ELSE_ENDS() do { } while(0)
@@ -172,16 +153,9 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		do
 		{
 #include "trace_walk.inc"
-#if PWN_WALK_EXIT == 1
-			maxsteps = __builtin_amdgcn_readfirstlane(maxsteps) - 1;
-		} while(ev == 0 && maxsteps != 0);
-		if(ev == 0) ev = EV_EXHAUSTED;              // trace.h:250,677: out of steps
-#else
 			// trace.h:250,677: out of steps
 			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
 		} while(ev == 0);
-#endif
-#endif
 #undef WALK_ROOM_ENDS
 #undef WALK_ENDED
 #undef WALK_ELSE_ENDS
@@ -532,6 +506,8 @@ pwn_trace_kernel(pwn_trace_params P)
 			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
+		// (a late draw; in front of the colour store instead -- so that the wave waits for the ticket alone and not for
+		// the store's way to memory, vmcnt counts both -- it measured the same: profiles/r3_strips/late_draws.txt)
 		if(draw && late && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n);
 		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
 		left = draw ? draw_n - 1u : left - 1u;

@@ -72,28 +72,50 @@ def pipelined(y0, y1, two, frames=200):
     return best
 
 
-rows = []
-for rank, (y0, y1) in enumerate(ranges):
-    if n > 16 and rank not in (0, n // 2, n - 1):
-        continue
-    s = streams[0]
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    tt, tb = [], []
-    for it in range(30):
-        ev[0].record(s)
-        r.trace_rows_device(cam, 0.0, y0, y1, pre[0].data_ptr(), z[0].data_ptr(), s.cuda_stream)
-        ev[1].record(s)
-        r.blur_rows_device_bounded(y0, y1, pre[0].data_ptr(), z[0].data_ptr(), out[0].data_ptr(), max(y0 - H, 0), min(y1 + H, h), miss.data_ptr(), s.cuda_stream)
-        ev[2].record(s)
-        torch.cuda.synchronize()
-        tt.append(ev[0].elapsed_time(ev[1]))
-        tb.append(ev[1].elapsed_time(ev[2]))
-    p1, p2 = pipelined(y0, y1, False), pipelined(y0, y1, True)
-    rows.append((min(tt[5:]), min(tb[5:]), p1, p2))
-    print("N=%d rank %d rows [%d,%d): isolated trace %.4f + blur %.4f = %.4f ms | pipelined %.4f ms/frame | 2 streams %.4f ms/frame" % (
-        len(ranges), rank, y0, y1, rows[-1][0], rows[-1][1], rows[-1][0] + rows[-1][1], p1, p2), flush=True)
-a = np.array(rows)
-iso = a[:, 0] + a[:, 1]
-print("N=%d %dx%d %s: slowest strip isolated %.4f ms (max/mean %.3f) | pipelined %.4f (%.3f) | 2 streams %.4f (%.3f) | sum over strips of the 2-stream figure %.4f ms" % (
-    len(ranges), w, h, level, iso.max(), iso.max() / iso.mean(), a[:, 2].max(), a[:, 2].max() / a[:, 2].mean(),
-    a[:, 3].max(), a[:, 3].max() / a[:, 3].mean(), a[:, 3].sum()))
+def measure(ranges, quiet=False):
+    rows = []
+    for rank, (y0, y1) in enumerate(ranges):
+        if n > 16 and rank not in (0, n // 2, n - 1):
+            continue
+        s = streams[0]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tt, tb = [], []
+        for it in range(30):
+            ev[0].record(s)
+            r.trace_rows_device(cam, 0.0, y0, y1, pre[0].data_ptr(), z[0].data_ptr(), s.cuda_stream)
+            ev[1].record(s)
+            r.blur_rows_device_bounded(y0, y1, pre[0].data_ptr(), z[0].data_ptr(), out[0].data_ptr(), max(y0 - H, 0), min(y1 + H, h), miss.data_ptr(), s.cuda_stream)
+            ev[2].record(s)
+            torch.cuda.synchronize()
+            tt.append(ev[0].elapsed_time(ev[1]))
+            tb.append(ev[1].elapsed_time(ev[2]))
+        p1, p2 = pipelined(y0, y1, False), pipelined(y0, y1, True)
+        rows.append((min(tt[5:]), min(tb[5:]), p1, p2))
+        if not quiet:
+            print("N=%d rank %d rows [%d,%d): isolated trace %.4f + blur %.4f = %.4f ms | pipelined %.4f ms/frame | 2 streams %.4f ms/frame" % (
+                len(ranges), rank, y0, y1, rows[-1][0], rows[-1][1], rows[-1][0] + rows[-1][1], p1, p2), flush=True)
+    a = np.array(rows)
+    iso = a[:, 0] + a[:, 1]
+    print("N=%d %dx%d %s cuts %s: slowest strip isolated %.4f ms (max/mean %.3f) | pipelined %.4f (%.3f) | 2 streams %.4f (%.3f) | sum over strips of the 2-stream figure %.4f ms" % (
+        len(ranges), w, h, level, [y0 for y0, _ in ranges[1:]], iso.max(), iso.max() / iso.mean(), a[:, 2].max(), a[:, 2].max() / a[:, 2].mean(),
+        a[:, 3].max(), a[:, 3].max() / a[:, 3].mean(), a[:, 3].sum()), flush=True)
+    return a
+
+
+a = measure(ranges)
+# STRIP_BALANCE=k: k rounds of the library's own re-cut rule (pwn_tiled_recut) with each strip's 2-stream time as its cost --
+# what the moving cuts of pwn_tiled_balance converge to (there the cost is the sum of the trace waves' lifetimes)
+rounds = int(os.environ.get("STRIP_BALANCE", "0"))
+if rounds and len(ranges) > 1 and len(ranges) <= 16:
+    from pwnfps_amd import _lib
+    from pwnfps_amd.dist import max_strip_rows
+    cuts_now = [y0 for y0, _ in ranges] + [h]
+    for k in range(rounds):
+        cost = np.array([max(1, int(v * 1e6)) for v in a[:, 3]], np.uint32)
+        cin, cout = np.array(cuts_now, np.int32), np.zeros(len(cuts_now), np.int32)
+        moved = _lib.lib.pwn_tiled_recut(cin.ctypes.data, cost.ctypes.data, len(ranges), h, H, max_strip_rows(h, len(ranges)), cout.ctypes.data)
+        if moved != 1:
+            print("re-cut %d: the cuts stay (within 2 %% of each other, or a constraint)" % (k + 1))
+            break
+        cuts_now = [int(v) for v in cout]
+        a = measure([(cuts_now[i], cuts_now[i + 1]) for i in range(len(ranges))], quiet=(k + 1 < rounds))
