@@ -317,6 +317,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prepare", choices=("early", "late"), default="early",
                     help="set_objects of a frame before (early) or after (late) the host waits for a free slot")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="N = 1: PWN_OPT_FRAME_OVERLAP 0 for the whole run -- every launch by itself, for rocprofv3 --kernel-trace runs whose "
+                         "average kernel durations are to be compared with roofline.avg_launch_ms")
     ap.add_argument("--no-d2h", action="store_true",
                     help="skip the d2h_inclusive leg: for rocprofv3 --kernel-trace runs, where the profiler serialises the copies of "
                          "that leg with the kernels and their durations (2.7x) would be averaged into the resident loop's")
@@ -387,7 +390,9 @@ def main():
     nres = max(1, min(args.resident_slots, 4))
     # frames alternate between two compute streams (the library's default, PWN_OPT_FRAME_OVERLAP; PWN_FRAME_OVERLAP=0 in the
     # environment switches it off): the next frame's trace grid fills what the current one's tail leaves idle
-    overlap_on = os.environ.get("PWN_FRAME_OVERLAP", "1") not in ("0", "") and nres >= 2
+    overlap_on = os.environ.get("PWN_FRAME_OVERLAP", "1") not in ("0", "") and nres >= 2 and not args.one_stream
+    if args.one_stream:
+        r.set_frame_overlap(False)
     tinfo = None
     if world == 1:
         r.frames_config(nres, sbuf=False)

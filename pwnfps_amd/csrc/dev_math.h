@@ -133,6 +133,22 @@ __device__ __forceinline__ float lcg_fs(uint32_t &s)
 	return __builtin_fmaf(u, 2.0f, -1.0f);
 }
 
+// The same generator on the DOUBLED state t = 2 s (util.h:1-16 of the reference): the "& 0x7FFFFFFF" of every step is then the
+// wrap of 32-bit arithmetic (2 ((25739 s + 4) mod 2^31) = (25739 t + 8) mod 2^32), the quotient s / 3759 is the same
+// multiply-high (t M >> 44 = s M >> 43, M = ceil(2^43 / 3759), exact for every s < 2^31: checked for all 2^31 states on the
+// CPU), the remainder comes out doubled from one 24-bit multiply-add (the quotient has 20 bits), and (float)(2 r) * (inv / 2)
+// rounds exactly as (float)r * inv.  Two instructions per draw fewer than lcg_fs, one fewer than lcg_next; same bits.
+// A state is doubled once (t = s << 1: bit 31 of s never mattered, the first step masks it away) and stays doubled.
+__device__ __forceinline__ void lcg2_next(uint32_t &t) { t = t * 25739u + 8u; }
+__device__ __forceinline__ float lcg2_fs(uint32_t &t)
+{
+	t = t * 25739u + 8u;
+	const uint32_t q = __umulhi(t, 0x8b79b351u) >> 12;
+	const uint32_t r2 = (uint32_t)(__mul24((int)q, -7518) + (int)t);
+	const float u = (float)r2 * (0.5f * (1.0f / 3759.0f));
+	return __builtin_fmaf(u, 2.0f, -1.0f);
+}
+
 // ---- colour pack: cvtps2dq (RNE) + packs_epi32 + packus_epi16 --------------
 __device__ __forceinline__ uint32_t ftoint_lane(float f)
 {

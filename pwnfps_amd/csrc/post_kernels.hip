@@ -64,19 +64,7 @@ __device__ __forceinline__ int blur_coord1(float f, int hi)
 	return r;
 }
 
-// lcg_fs (dev_math.h; util.h:33-45 of the reference) on the DOUBLED state t = 2 s: the "& 0x7FFFFFFF" of every
-// step is then the wrap of 32-bit arithmetic (2 ((25739 s + 4) mod 2^31) = (25739 t + 8) mod 2^32), the quotient
-// s / 3759 is the same multiply-high (t M >> 44 = s M >> 43, M = ceil(2^43 / 3759), exact for every s < 2^31), the
-// remainder comes out doubled from one 24-bit multiply-add (the quotient has 20 bits), and (float)(2 r) * (inv / 2)
-// rounds exactly as (float)r * inv.  Two instructions per draw fewer; same bits.
-__device__ __forceinline__ float blur_lcg_fs(uint32_t &t)
-{
-	t = t * 25739u + 8u;
-	const uint32_t q = __umulhi(t, 0x8b79b351u) >> 12;
-	const uint32_t r2 = (uint32_t)(__mul24((int)q, -7518) + (int)t);
-	const float u = (float)r2 * (0.5f * (1.0f / 3759.0f));
-	return __builtin_fmaf(u, 2.0f, -1.0f);
-}
+// (the row LCG runs on the doubled state: lcg2_fs, dev_math.h)
 
 __global__ void __launch_bounds__(256)
 pwn_blur_kernel(pwn_blur_params P)
@@ -198,7 +186,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	const int lx1 = lx0 + 1, ly1 = ly0 + 1;
 	const uint32_t w1 = (uint32_t)P.w + 1u;
 	const uintptr_t pre1 = (uintptr_t)P.pre - (uintptr_t)w1 * 4u;
-	uint32_t t2 = seed << 1;                               // the LCG state doubled (see blur_lcg_fs)
+	uint32_t t2 = seed << 1;                               // the LCG state doubled (lcg2_fs, dev_math.h)
 	uint32_t tap[4][4];
 	bool missed = false;
 #pragma unroll
@@ -208,8 +196,8 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 		for(int j = 0; j < 4; j++)
 		{
 			// screen.h:101-106
-			const float fx = fcx[j] + (blur_lcg_fs(t2) * fstr) * z[j];
-			const float fy = fcy + (blur_lcg_fs(t2) * fstr) * z[j];
+			const float fx = fcx[j] + (lcg2_fs(t2) * fstr) * z[j];
+			const float fy = fcy + (lcg2_fs(t2) * fstr) * z[j];
 			const int x1 = blur_coord1(fx, P.w), y1 = blur_coord1(fy, P.h);
 			if(CHECK) missed |= (unsigned)(y1 - (P.avail_y0 + 1)) >= (unsigned)(P.avail_y1 - P.avail_y0);
 			// from the staged rectangle (every lane reads LDS, at a clamped index); a tap outside it is
@@ -353,7 +341,7 @@ __global__ void pwn_probe_kernel(int op, const uint32_t *in, uint32_t *out, int 
 		case 6: out[i] = __float_as_uint(__uint_as_float(in[2 * i]) / __uint_as_float(in[2 * i + 1])); break;
 		case 7: out[i] = col_pack(v4_set(__uint_as_float(in[4 * i]), __uint_as_float(in[4 * i + 1]),
 			__uint_as_float(in[4 * i + 2]), __uint_as_float(in[4 * i + 3]))); break;
-		case 8: { uint32_t s = in[i]; out[i] = __float_as_uint(lcg_fs(s)); break; }
+		case 8: { uint32_t t = in[i] << 1; out[i] = __float_as_uint(lcg2_fs(t)); break; }        // (the form the kernels use: doubled state)
 		case 9: out[i] = __float_as_uint(glibc_sincosf_both(__uint_as_float(in[i])).x); break;
 		case 10: out[i] = __float_as_uint(glibc_sincosf_both(__uint_as_float(in[i])).y); break;
 		default: out[i] = 0; break;

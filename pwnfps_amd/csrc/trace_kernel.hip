@@ -258,11 +258,11 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		//@R p_jitter
 		RG(RG_JITTER);
 		// trace.h:77-84: five draws, two discarded
-		ray.x += lcg_fs(seed) * REFLECT_BLUR_F;
-		ray.y += lcg_fs(seed) * REFLECT_BLUR_F;
-		lcg_next(seed);
-		ray.z += lcg_fs(seed) * REFLECT_BLUR_F;
-		lcg_next(seed);
+		ray.x += lcg2_fs(seed) * REFLECT_BLUR_F;
+		ray.y += lcg2_fs(seed) * REFLECT_BLUR_F;
+		lcg2_next(seed);
+		ray.z += lcg2_fs(seed) * REFLECT_BLUR_F;
+		lcg2_next(seed);
 
 		st_refl1 = st_refl0; st_fog1 = st_fog0; sc1x = sc0x; sc1y = sc0y; sc1z = sc0z;
 		st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz;
@@ -500,6 +500,7 @@ pwn_trace_kernel(pwn_trace_params P)
 			uint32_t seed = (uint32_t)x + (uint32_t)y * (uint32_t)y * ((uint32_t)P.w + 1u);
 			seed *= seed * seed;
 			seed *= seed * seed;
+			seed <<= 1;                               // the generator runs on the doubled state (lcg2_fs, dev_math.h)
 
 			float ox, oy, oz, ow;
 			const size_t o = (size_t)y * (size_t)P.w + (size_t)x;

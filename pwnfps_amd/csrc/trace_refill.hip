@@ -207,11 +207,11 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 					}
 
 					// trace.h:77-84: five draws, two discarded
-					ray.x += lcg_fs(seed) * REFLECT_BLUR_F;
-					ray.y += lcg_fs(seed) * REFLECT_BLUR_F;
-					lcg_next(seed);
-					ray.z += lcg_fs(seed) * REFLECT_BLUR_F;
-					lcg_next(seed);
+					ray.x += lcg2_fs(seed) * REFLECT_BLUR_F;
+					ray.y += lcg2_fs(seed) * REFLECT_BLUR_F;
+					lcg2_next(seed);
+					ray.z += lcg2_fs(seed) * REFLECT_BLUR_F;
+					lcg2_next(seed);
 
 					// the composite stack as a shift register; its top entry's colour is the next segment's icol
 					st_refl1 = st_refl0; st_fog1 = st_fog0; sc1x = sc0x; sc1y = sc0y; sc1z = sc0z;
@@ -370,6 +370,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 						seed = (uint32_t)x + (uint32_t)y * (uint32_t)y * ((uint32_t)P.w + 1u);
 						seed *= seed * seed;
 						seed *= seed * seed;
+						seed <<= 1;                   // the generator runs on the doubled state (lcg2_fs, dev_math.h)
 						depth = 0; sc0x = sc0y = sc0z = 1.0f; w_acc = 0.0f;
 						ev = EV_SETUP;
 					}
