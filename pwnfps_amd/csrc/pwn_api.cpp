@@ -64,10 +64,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	// workgroups per CU of the persistent grid
 	c->dbg_force_hasw = getenv("PWN_DBG_FORCE_HASW") != NULL;
 	c->dbg_blocks_per_cu = 0;
-	c->dbg_late_rounds = -1;
 	c->dbg_blur_th = 0;
 	if(const char *e = getenv("PWN_DBG_BLUR_TH")) c->dbg_blur_th = atoi(e);
-	if(const char *e = getenv("PWN_DBG_LATE_ROUNDS")) c->dbg_late_rounds = atoi(e);
 	if(const char *e = getenv("PWN_DBG_BLOCKS_PER_CU")) { int v = atoi(e); if(v > 0) c->dbg_blocks_per_cu = v; }
 	c->blob_cur = 0; c->blob_dirty = true; c->off_sph = 0; c->stage_next = 0; c->up_stream = NULL;
 	for(int i = 0; i < PWN_NBLOB; i++)
@@ -628,13 +626,6 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 		if(!refill && grid > (P.tiles_total + wg_waves - 1) / wg_waves) grid = (P.tiles_total + wg_waves - 1) / wg_waves;
 		if(grid > P.tiles_total) grid = P.tiles_total;
 	}
-	// a wave asks for its next unit ahead of the current one while more tickets than this are left in its queue
-	// (trace_kernel.hip): 0 = always ahead.  Measured (profiles/r3_strips/late_draws.txt): drawing late -- no
-	// commitment to a second unit near the end of the launch -- loses everywhere, because a draw is not ~2 us behind
-	// other waves' work but ~6 us that the SIMD's waves, which run in step, all wait out together.
-	P.late_rounds = 0u;
-	if(c->dbg_late_rounds >= 0) P.late_rounds = (uint32_t)c->dbg_late_rounds;
-	if(c->dbg_late_rounds == -2) P.late_rounds = (uint32_t)((grid * 4 + (int)PWN_QUEUES - 1) / (int)PWN_QUEUES);
 	// PWN_OPT_WAVE_LOG: every wave of this launch writes its start and end time; entry 0 is unused, entry
 	// 1 + 4 * workgroup + SIMD is a wave's (the buffer follows the grid of the launch)
 	if(c->wave_log_on)

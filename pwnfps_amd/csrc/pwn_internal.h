@@ -108,7 +108,6 @@ struct pwn_ctx
 	unsigned long long *d_wave_log; int wave_log_on; size_t wave_log_cap;   // PWN_OPT_WAVE_LOG; entries (16 B) allocated
 	bool dbg_force_hasw; int dbg_blocks_per_cu;      // PWN_DBG_* hooks, read at pwn_init
 	int dbg_blur_th;                 // PWN_DBG_BLUR_TH: tile height of every blur launch (8 / 16 / 32), 0 = the launcher's choice
-	int dbg_late_rounds;             // PWN_DBG_LATE_ROUNDS: pwn_trace_params.late_rounds for every launch (experiments), -1 = the launcher's choice
 	int grid_reserve;                // workgroups the persistent trace grid leaves free (row tiling over RCCL), else 0
 	uint32_t *trace_cost_word;       // likewise: pwn_trace_params.cost_word for the next launch
 	uint32_t *trace_clear_word;      // set by a caller of pwn_i_launch_trace for its next launch: see pwn_trace_params.clear_word

@@ -144,8 +144,6 @@ struct pwn_trace_params
 	// work queues of the wave scheduler (trace_kernel.hip): PWN_QUEUES counters, one per 128 B,
 	// for this launch; the set of the next launch, which this one clears
 	uint32_t *tickets, *tickets_next;
-	uint32_t late_rounds;                     // a wave asks for its next unit ahead of the current one only while more than this many
-	                                          // tickets are left in its queue (trace_kernel.hip); ~ resident waves / PWN_QUEUES
 	uint32_t *cost_word;                      // NULL, or a word this launch adds the sum of its waves' lifetimes to (100 MHz ticks): what
 	                                          // the rows cost, for the row tiling's moving cuts (pwn_tiled.cpp)
 	uint32_t *clear_word;                     // NULL, or a word this launch sets to 0 (the row tiling's miss word of the frame:

@@ -88,22 +88,6 @@ __device__ __forceinline__ uint32_t cxz_add(uint32_t c, uint32_t step)
 {
 	return __builtin_bit_cast(uint32_t, (pwn_s2)(__builtin_bit_cast(pwn_s2, c) + __builtin_bit_cast(pwn_s2, step)));
 }
-// Which face the ray came through (ldir of trace.h:156-184) is not selected per step: the walk keeps the STEP it
-// took last -- the packed (gx, 0) or (0, gz) it added to the cell, which it has in a register anyway -- and the
-// face is decoded from that where somebody needs it: after the walk, in a portal, at a solid cell.  0 stands for
-// FYN, the value a segment starts with (trace.h:247); LSTEP_FYP for the one face a ramp can add (trace.h:474).
-#define LSTEP_FYP 0x7fff7fffu
-__device__ __forceinline__ int lstep_dir(uint32_t s)
-{
-	const int xz = (s & 0xffffu) ? (int)(s & 2u) : 1 + (int)((s >> 16) & 2u);        // +-1 in the low half: FXP / FXN, in the high half: FZP / FZN
-	return s == 0u ? FYN : (s == LSTEP_FYP ? FYP : xz);
-}
-__device__ __forceinline__ uint32_t lstep_of(int dir)
-{
-	const uint32_t v = (dir & 2) ? 0xffffu : 1u;
-	const uint32_t xz = (dir & 1) ? v << 16 : v;
-	return dir == FYN ? 0u : (dir == FYP ? LSTEP_FYP : xz);
-}
 __device__ __forceinline__ uint32_t cellword_pk(const Lds &L, uint32_t cxz)
 {
 	const pwn_us2 lim = { 64, 64 }, pitch = { 4, (unsigned short)(PWN_GRID_PITCH * 4u) };

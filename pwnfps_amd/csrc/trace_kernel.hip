@@ -128,13 +128,14 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		// (trace.h:345-349,381-385); iay_dn is the amount added when stepping DOWN into it
 		const float iay_dn = gyp ? iay : -iay;
 		const int ldy = gyp ? FYP : FYN;
+		int ldx = (gx < 0 ? FXN : FXP), ldz = (gz < 0 ? FZN : FZP);
 		uint32_t iay_up_bits = gyp ? __float_as_uint(iay) : 0u;         // +iay when looking up, else +0
 		asm volatile("" : "+v"(iay_up_bits));        // keep it a register, not a select on gyp per step
 		// cell coordinates and steps in the packed form the walk uses (trace_common.h)
 		uint32_t cxz = cxz_pack_start(cx, cz), sx = (uint32_t)gx & 0xffffu, sz = (uint32_t)gz << 16;
 
 		uint32_t cw = cellword_pk(L, cxz);
-		uint32_t lstep = 0u;                     // the step taken last; 0 = none yet = FYN (trace.h:247)
+		int ldir = FYN;
 		int ev = EV_NONE, base = BASE_ROOM_Y;
 
 		// ------------------------------------------------ trace.h:250-675 (trace_walk.inc)
@@ -146,9 +147,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		// lane mask `done` = hit || ymin with WHICH of the two read off cdist against aux_dist after the walk (-4 VALU,
 		// +10 scalar mask instructions per step as compiled: +5.3 %).  Scalar instructions are not free here.
 		int maxsteps = 1000;
-#define WALK_ROOM_ENDS(hit, ymin) ev = (hit) ? EV_SPHERE : ((ymin) ? EV_WALL : 0)
-#define WALK_ENDED() do { } while(0)
-#define WALK_ELSE_ENDS() do { } while(0)
 #pragma unroll 1
 		do
 		{
@@ -156,9 +154,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			// trace.h:250,677: out of steps
 			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
 		} while(ev == 0);
-#undef WALK_ROOM_ENDS
-#undef WALK_ENDED
-#undef WALK_ELSE_ENDS
 		// what the ray ended on is read back from the register: without this the compiler keeps
 		// "ev == EV_EXHAUSTED" as a lane mask that it updates in every iteration of the walk
 		// (5 of ~85 instructions per step)
@@ -176,7 +171,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			break;
 		}
 		//@R p_post
-		int ldir = lstep_dir(lstep);
 		if(ev == EV_WALL && base == BASE_ROOM_Y) { ldir = ldy; base = (gyp ? BASE_CEIL : BASE_FLOOR); }
 		// zbuf = the PRIMARY ray's hit distance (trace.h:102-105); a primary ray that ran out of steps
 		// leaves the old depth in place (trace.h:677)
@@ -426,16 +420,15 @@ pwn_trace_kernel(pwn_trace_params P)
 		misses = 0;
 		const uint32_t unit = ticket * PWN_QUEUES + q;
 		const bool draw = left == 0u;
-		// Asking for the next unit BEFORE tracing this one commits the wave to two units, and near the end of a launch
-		// that is the tail: the last ticket of a queue goes to a wave that still has a whole unit in front of it while
-		// its neighbours find the queues empty and leave.  P.late_rounds > 0 makes a wave draw only when it is done
-		// once fewer tickets than that are left in its queue.  Measured on the strips of an 8-way tiling of a 4K frame
-		// (3 units per wave), on 720p and on 4K frames: always slower (strip 67 -> 76..82 us, 720p 60 -> 71 us, 4K
-		// equal) -- a draw takes ~6 us under load, and the waves of a SIMD, which run in step, all wait for theirs at
-		// the same time.  The launcher passes 0 (always ahead); the parameter stays for experiments.
-		const bool late = ticket + P.late_rounds >= qlen;
+		// The next unit is asked for BEFORE this one is traced, which commits the wave to two units -- near the end of a
+		// launch that is the tail: the last ticket of a queue goes to a wave that still has a whole unit in front of it
+		// while its neighbours find the queues empty and leave.  Drawing only when a unit is done, throughout or for the
+		// last tickets of a queue, was built and measured in round 3 (profiles/r3_strips/late_draws.txt, commit 5a68fef):
+		// slower everywhere (a strip of an 8-way tiling 64 -> 65..77 us, 720p 58 -> 62..75 us, 4K equal), also with the
+		// draw issued in front of the unit's colour store: a draw costs a wave ~6 us in this kernel, and the waves of a
+		// SIMD, which run in step, wait for theirs together.
 		uint32_t next_raw = ticket + 1u;
-		if(draw && !late && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n);
+		if(draw && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n);
 		// rows from the middle outwards: the horizon band, where rays run longest,
 		// is started first and the cheap top and bottom edges make up the tail
 		// (this arithmetic is the same for the whole wave, but the compiler does it per lane because q starts
@@ -507,9 +500,6 @@ pwn_trace_kernel(pwn_trace_params P)
 			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
-		// (a late draw; in front of the colour store instead -- so that the wave waits for the ticket alone and not for
-		// the store's way to memory, vmcnt counts both -- it measured the same: profiles/r3_strips/late_draws.txt)
-		if(draw && late && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n);
 		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
 		left = draw ? draw_n - 1u : left - 1u;
 	}

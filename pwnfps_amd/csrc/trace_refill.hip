@@ -105,8 +105,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 	float cdist = 0.0f, fog = 0.0f, aux_dist = __builtin_inff(), aux_diff = 0.0f;
 	uint32_t aux_idx = 0u;
 	uint32_t cxz = 0u, sx = 1u, sz = 1u << 16;         // cell x | z << 16 and the steps (gx, 0), (0, gz): trace_common.h
-	int ldy = FYP, ldir = FYN, base = BASE_ROOM_Y, maxsteps = 0;
-	uint32_t lstep = 0u;                          // the step taken last, which stands for ldir inside the walk (trace_common.h)
+	int ldx = FXP, ldz = FZP, ldy = FYP, ldir = FYN, base = BASE_ROOM_Y, maxsteps = 0;
 	float wx = 0.0f, wy = 0.0f, wz = 0.0f, iax = 0.0f, iay = 0.0f, iaz = 0.0f, iay_dn = 0.0f;
 	uint32_t iay_up_bits = 0u, cw = 0u;
 
@@ -130,7 +129,6 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 			}
 			else
 			{
-				ldir = lstep_dir(lstep);
 				if(ev == EV_WALL && base == BASE_ROOM_Y) { ldir = ldy; base = (ldy == FYP ? BASE_CEIL : BASE_FLOOR); }
 				// zbuf = the PRIMARY ray's hit distance (trace.h:102-105)
 				if(depth == 0) P.zbuf[o] = (ev == EV_SPHERE ? aux_dist : cdist);
@@ -425,7 +423,8 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 			iay_up_bits = gyp ? __float_as_uint(iay) : 0u;         // +iay when looking up, else +0
 			cxz = cxz_pack_start(cx, cz); sx = (uint32_t)gx & 0xffffu; sz = (uint32_t)gz << 16;
 			cw = cellword_pk(L, cxz);
-			lstep = 0u; base = BASE_ROOM_Y;
+			ldx = (gx < 0 ? FXN : FXP); ldz = (gz < 0 ? FZN : FZP);
+			ldir = FYN; base = BASE_ROOM_Y;
 			maxsteps = 1000;
 			ev = EV_NONE;
 		}
@@ -455,14 +454,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 #pragma unroll 1
 			do
 			{
-// (this kernel looks at ev after every step: the room body writes it)
-#define WALK_ROOM_ENDS(hit, ymin) ev = (hit) ? EV_SPHERE : ((ymin) ? EV_WALL : 0)
-#define WALK_ENDED() do { } while(0)
-#define WALK_ELSE_ENDS() do { } while(0)
 #include "trace_walk.inc"
-#undef WALK_ROOM_ENDS
-#undef WALK_ENDED
-#undef WALK_ELSE_ENDS
 				// wave-uniform: a young ray still walks, and the ended ones have not waited too long
 				const unsigned long long w = __ballot(ev == EV_NONE);
 				waited += (int)__builtin_popcountll(walking0 & ~w);

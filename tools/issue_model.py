@@ -240,6 +240,15 @@ def main():
         print("\n(no %s: run tools/region_counts.py on the GPU for the dynamic part)" % args.counts)
         return
     scenes = json.load(open(args.counts))["scenes"]
+    # the instruction counters of the 4K level.txt launch: the committed PMC summary of the same build
+    try:
+        rows = [ln.rstrip("\n").rsplit(",", 3) for ln in open(os.path.join(ROOT, "profiles", "pmc_latest.csv"))]
+        v = {r[1]: float(r[3]) for r in rows if len(r) == 4 and "pwn_trace_kernel" in r[0] and "<true" not in r[0] and ", true>" not in r[0]}
+        for sc in scenes:
+            if (sc["level"], sc["w"], sc["h"]) == ("pwnfps_level", 3840, 2160):
+                sc["pmc"] = {k: v[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS")}
+    except (OSError, KeyError, ValueError):
+        pass
 
     def totals(cnt):
         t = collections.Counter()
@@ -262,9 +271,11 @@ def main():
 
     P("")
     P("# Reading: `VALU issue` is what the kernel's VALU instructions alone cost the 1024 SIMDs -- entries x instructions x issue cost, nothing")
-    P("# overlapped, nothing else counted.  `busy` is the launch's SIMD time: launch x mean wave residency (wave stamps).  Where VALU issue")
-    P("# at the saturated rates comes to ~100 % of busy, the kernel is VALU-issue-bound and its scalar third rides along in the shadow of")
-    P("# other waves' VALU instructions (additive at the ~1.0 ns they cost beside VALU work in the microbenchmark they would add a third).")
+    P("# overlapped, nothing else counted: the floor of the launch.  `span` is the launch from its first wave's start to its last wave's end")
+    P("# (wave stamps, PWN_OPT_WAVE_LOG), `busy` the mean wave's lifetime.  Where VALU issue at the saturated rates comes to ~100 % of the")
+    P("# span, the launch is AT its VALU-issue floor and its scalar third rides along in the shadow of other waves' VALU instructions")
+    P("# (additive at the ~1.0 ns they cost beside VALU work in the microbenchmark they would add a third).  Launches whose span is well")
+    P("# above the floor are bound by their tail (few units per wave, or single waves walking mirror halls to the step limit): section 6.")
     out_cases = []
     for sc in scenes:
         t, by_region = totals(sc["counts"])
@@ -272,29 +283,27 @@ def main():
         valu_ms = t["valu_ns"] / simds * 1e-6
         sat_ms = t["sat_ns"] / simds * 1e-6
         res = sc.get("residency", 1.0)
-        busy = sc["trace_ms"] * res
-        pred = sat_ms / res
+        span = sc.get("span_ms", sc["trace_ms"])
+        busy = span * res
         P("")
-        P("## %s %dx%d: trace launch %.4f ms between HIP events (uncounted frames), mean wave residency %.3f -> busy %.4f ms" % (
-            sc["level"], sc["w"], sc["h"], sc["trace_ms"], res, busy))
+        P("## %s %dx%d: launch span %.4f ms (wave stamps; %.4f ms between HIP events around a blocking frame), mean wave residency %.3f -> busy %.4f ms" % (
+            sc["level"], sc["w"], sc["h"], span, sc["trace_ms"], res, busy))
         P("   wave-instructions by the model: VALU %.4g (half-rate %.4g), SALU %.4g, branch %.4g, LDS %.4g" % (t["valu"], t["half"], t["salu"], t["branch"], t["lds"]))
         if sc.get("pmc"):
             pm = sc["pmc"]
             P("   PMC of the same launch:         VALU %.4g, SALU %.4g, branch %.4g, LDS %.4g   (model / PMC: %.3f %.3f %.3f %.3f)" % (
                 pm["SQ_INSTS_VALU"], pm["SQ_INSTS_SALU"], pm["SQ_INSTS_BRANCH"], pm["SQ_INSTS_LDS"], t["valu"] / pm["SQ_INSTS_VALU"],
                 t["salu"] / pm["SQ_INSTS_SALU"], t["branch"] / pm["SQ_INSTS_BRANCH"], t["lds"] / pm["SQ_INSTS_LDS"]))
-        P("   VALU issue: %.4f ms at the 5-wave single-opcode rates, %.4f ms at the saturated rates = %.3f of busy, %.3f of the launch;" % (
-            valu_ms, sat_ms, sat_ms / busy, sat_ms / sc["trace_ms"]))
-        P("   predicted launch = VALU issue (saturated) / residency = %.4f ms (%+.1f %% against measured); scalar + branch instructions: %.4g (x 1.0 ns = %.4f ms if they were additive)" % (
-            pred, (pred / sc["trace_ms"] - 1) * 100, t["scalar_n"], t["scalar_n"] / simds * 1e-6))
+        P("   VALU issue: %.4f ms at the saturated rates (%.4f at the 5-wave single-opcode rates) = %.3f of the span (predicted launch %+.1f %% against it), %.3f of busy;" % (
+            sat_ms, valu_ms, sat_ms / span, (sat_ms / span - 1) * 100, sat_ms / busy))
+        P("   scalar + branch instructions: %.4g (x 1.0 ns = %.4f ms if they were additive)" % (t["scalar_n"], t["scalar_n"] / simds * 1e-6))
         P("   %-14s %10s %12s %10s %10s %7s" % ("region", "entries", "VALU instr", "half-rate", "VALU ms", "share"))
         for reg in sorted(by_region, key=lambda r: -by_region[r][3]):
             n, nv, nsc, vns, nh = by_region[reg]
             if n:
                 P("   %-14s %10d %12d %10d %10.4f %6.1f%%" % (reg, n, nv, nh, vns / simds * 1e-6, 100 * vns / max(t["valu_ns"], 1)))
         out_cases.append({"level": sc["level"], "w": sc["w"], "h": sc["h"], "valu_issue_ms": round(sat_ms, 4), "valu_issue_ms_5_wave_rates": round(valu_ms, 4),
-                          "predicted_launch_ms": round(pred, 4), "measured_launch_ms": sc["trace_ms"], "residency": res,
-                          "valu": int(t["valu"]), "valu_half_rate": int(t["half"]), "scalar_and_branch": int(t["scalar_n"])})
+                          "span_ms": span, "residency": res, "valu": int(t["valu"]), "valu_half_rate": int(t["half"]), "scalar_and_branch": int(t["scalar_n"])})
     txt = "\n".join(lines) + "\n"
     print(txt)
     with open(args.out + ".txt", "w") as f:
