@@ -307,6 +307,9 @@ def main():
     ap.add_argument("--min-time", type=float, default=3.0, help="repeat the K-step block until this many seconds were timed (each of the "
                     "resident and the d2h leg: the GPU is busy for >= 6 s of a default run)")
     ap.add_argument("--sweep-time", type=float, default=0.3, help="N > 1: seconds timed per leg of tiling.sweep (0 = no sweep)")
+    ap.add_argument("--post-timeout", type=float, default=240.0,
+                    help="N > 1: seconds the legs AFTER the headline (sweep, host-sink leg) may take in all; then every rank stops and "
+                         "rank 0 prints the line with what it has -- a hang in an extra leg must not cost the headline number")
     ap.add_argument("--slots", type=int, default=3, help="frames in flight of the d2h_inclusive leg")
     ap.add_argument("--resident-slots", type=int, default=3, help="N = 1: frames in flight of the resident loop (1 = strictly one after the other)")
     ap.add_argument("--scheduler", choices=["units", "refill"], default=None, help="trace kernel scheduler (default: the library's)")
@@ -578,79 +581,13 @@ def main():
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("parity check skipped: %s\n" % e)
 
-    # ---- N > 1: the same run, other settings, a fraction of a second each: what a first multi-GPU run should look at
-    if world > 1 and args.sweep_time > 0:
-        sweep = {}
-
-        def point(name, what):
-            d2, bl = leg(max(2, args.warmup // 2), args.sweep_time, 60)
-            pr = per_rank()
-            sweep[name] = {"what": what, "value": round(w * h * args.steps / d2 / 1e6, 3), "ms_per_step": round(d2 / args.steps * 1e3, 4),
-                           "blocks": len(bl), "trace_ms": pr["trace_ms"], "blur_ms": pr["blur_ms"], "halo_ms": pr["halo_ms"],
-                           "gather_ms": pr["gather_ms"], "enqueue_us": pr["enqueue_us"], "rows": pr["rows"]}
-        reserve0 = tinfo["grid_reserve"]
-        for rsv in (0, 16, 64):
-            r.tiled_set_reserve(rsv)
-            point("reserve_%d" % rsv, "PWN_TILED_RESERVE = %d workgroups of the persistent trace grid left free for the transport's kernels" % rsv)
-        r.tiled_set_reserve(reserve0)
-        bal = tinfo["balance_every"]
-        r.tiled_balance(0)
-        r.tiled_set_cuts([min(k * tinfo["rows_per_rank"], h) for k in range(world)] + [h])
-        point("equal_strips", "pwn_tiled_balance(0) with the equal split (the reference's static schedule, screen.h:63-64)")
-        r.tiled_balance(bal)
-        barrier()
-        r.tiled_shutdown()
-        r.set_frame_overlap(False)
-        ok1, _ = bring_up(transport)
-        if ok1:
-            point("one_stream", "PWN_OPT_FRAME_OVERLAP 0: every frame's kernels on ONE compute stream")
-        barrier()
-        r.tiled_shutdown()
-        r.set_frame_overlap(True)
-        ok2, _ = bring_up(transport, halo=0)
-        if ok2:
-            point("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows")
-        # (the host-sink leg below sets the tiling up once more)
-
     counters = None
     pcie = None
     kernel_ms = None
-    if world == 1:
-        r.set_counters(True)
-        sb = np.empty((h, w), np.uint32)
-        r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
-        st = r.stats()
-        r.set_counters(False)
-        counters = {"rays_per_pixel": round(st["rays"] / (w * h), 4),
-                    "steps_per_ray": round(st["steps"] / max(st["rays"], 1), 4),
-                    "portal_crossings_per_ray": round(st["portals"] / max(st["rays"], 1), 4),
-                    "sphere_tests_per_ray": round(st["sphere_tests"] / max(st["rays"], 1), 4),
-                    # lanes doing a cell step / lanes of the wave64s running the walk loop
-                    "walk_active_lane_fraction": round(st["steps"] / max(64 * st["wave_steps"], 1), 4)}
-        # share of the kernel's duration the average wave64 is resident: start / end stamps of every
-        # wave (constant 100 MHz clock) in an UNcounted frame of the timed build
-        r.set_wave_log(True)
-        r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
-        sw = r.stats()
-        r.set_wave_log(False)
-        counters["mean_wave_residency"] = round(sw["wave_time"] / max(sw["waves"] * sw["kernel_span"], 1), 4)
-        counters["trace_kernel_span_ms"] = round(sw["kernel_span"] / 1e5, 4)
-        counters["waves"] = sw["waves"]
-        blocking_best = 1e9
-        for _ in range(5):
-            t1 = time.perf_counter()
-            r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
-            blocking_best = min(blocking_best, time.perf_counter() - t1)
-        st = r.stats()                     # kernel times of an uncounted frame
-        kernel_ms = {"trace": round(st["trace_ms"], 4), "blur": round(st["blur_ms"], 4)}
-    if world == 1 and not args.no_d2h:
-        pcie = d2h_leg_one_gpu(r, args, w, h, cam, sec, spheres, blocking_best,
-                               (lambda buf: oracle.fnv64(buf) == frame_hash) if (oracle is not None and frame_hash is not None) else None)
-    if world > 1 and not args.no_d2h:
-        pcie = host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks,
-                             (lambda buf: oracle.fnv64(buf) == frame_hash) if (rank == 0 and oracle is not None and frame_hash is not None) else None)
+    post = {"note": None}
 
-    if rank == 0:
+    def build_line():
+        nonlocal trace_ms
         pix = w * h
         not_rccl = world > 1 and transport != "rccl"
         if world == 1:
@@ -733,6 +670,8 @@ def main():
             line["tiling"]["per_rank"] = ranks
             if sweep is not None:
                 line["tiling"]["sweep"] = sweep
+            if post["note"]:
+                line["tiling"]["post_note"] = post["note"]
         if counters:
             line["work"] = counters
         if kernel_ms:
@@ -741,7 +680,99 @@ def main():
             line["d2h_inclusive"] = pcie
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
-        print(json.dumps(line), flush=True)
+        return line
+
+    # ---- N > 1: what follows the headline (sweep, host-sink leg) runs under a deadline on every rank: a leg that hangs -- a transport
+    # that does not come up a second time, a peer that died -- must not cost the headline number.  When it passes, rank 0 prints the
+    # line with what it has and every rank leaves (the process's exit takes its GPU queues down).
+    watchdog = None
+    if world > 1 and args.post_timeout > 0:
+        import threading
+
+        def bail():
+            post["note"] = "the legs after the headline did not finish within %.0f s (--post-timeout): sweep / d2h_inclusive hold what was measured until then" % args.post_timeout
+            try:
+                if rank == 0:
+                    print(json.dumps(build_line()), flush=True)
+            finally:
+                os._exit(0)
+        watchdog = threading.Timer(args.post_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
+    # ---- N > 1: the same run, other settings, a fraction of a second each: what a first multi-GPU run should look at
+    if world > 1 and args.sweep_time > 0:
+        sweep = {}
+
+        def point(name, what):
+            d2, bl = leg(max(2, args.warmup // 2), args.sweep_time, 60)
+            pr = per_rank()
+            sweep[name] = {"what": what, "value": round(w * h * args.steps / d2 / 1e6, 3), "ms_per_step": round(d2 / args.steps * 1e3, 4),
+                           "blocks": len(bl), "trace_ms": pr["trace_ms"], "blur_ms": pr["blur_ms"], "halo_ms": pr["halo_ms"],
+                           "gather_ms": pr["gather_ms"], "enqueue_us": pr["enqueue_us"], "rows": pr["rows"]}
+        reserve0 = tinfo["grid_reserve"]
+        for rsv in (0, 16, 64):
+            r.tiled_set_reserve(rsv)
+            point("reserve_%d" % rsv, "PWN_TILED_RESERVE = %d workgroups of the persistent trace grid left free for the transport's kernels" % rsv)
+        r.tiled_set_reserve(reserve0)
+        bal = tinfo["balance_every"]
+        r.tiled_balance(0)
+        r.tiled_set_cuts([min(k * tinfo["rows_per_rank"], h) for k in range(world)] + [h])
+        point("equal_strips", "pwn_tiled_balance(0) with the equal split (the reference's static schedule, screen.h:63-64)")
+        r.tiled_balance(bal)
+        barrier()
+        r.tiled_shutdown()
+        r.set_frame_overlap(False)
+        ok1, _ = bring_up(transport)
+        if ok1:
+            point("one_stream", "PWN_OPT_FRAME_OVERLAP 0: every frame's kernels on ONE compute stream")
+        barrier()
+        r.tiled_shutdown()
+        r.set_frame_overlap(True)
+        ok2, _ = bring_up(transport, halo=0)
+        if ok2:
+            point("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows")
+        # (the host-sink leg below sets the tiling up once more)
+
+    if world == 1:
+        r.set_counters(True)
+        sb = np.empty((h, w), np.uint32)
+        r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
+        st = r.stats()
+        r.set_counters(False)
+        counters = {"rays_per_pixel": round(st["rays"] / (w * h), 4),
+                    "steps_per_ray": round(st["steps"] / max(st["rays"], 1), 4),
+                    "portal_crossings_per_ray": round(st["portals"] / max(st["rays"], 1), 4),
+                    "sphere_tests_per_ray": round(st["sphere_tests"] / max(st["rays"], 1), 4),
+                    # lanes doing a cell step / lanes of the wave64s running the walk loop
+                    "walk_active_lane_fraction": round(st["steps"] / max(64 * st["wave_steps"], 1), 4)}
+        # share of the kernel's duration the average wave64 is resident: start / end stamps of every
+        # wave (constant 100 MHz clock) in an UNcounted frame of the timed build
+        r.set_wave_log(True)
+        r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
+        sw = r.stats()
+        r.set_wave_log(False)
+        counters["mean_wave_residency"] = round(sw["wave_time"] / max(sw["waves"] * sw["kernel_span"], 1), 4)
+        counters["trace_kernel_span_ms"] = round(sw["kernel_span"] / 1e5, 4)
+        counters["waves"] = sw["waves"]
+        blocking_best = 1e9
+        for _ in range(5):
+            t1 = time.perf_counter()
+            r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
+            blocking_best = min(blocking_best, time.perf_counter() - t1)
+        st = r.stats()                     # kernel times of an uncounted frame
+        kernel_ms = {"trace": round(st["trace_ms"], 4), "blur": round(st["blur_ms"], 4)}
+    if world == 1 and not args.no_d2h:
+        pcie = d2h_leg_one_gpu(r, args, w, h, cam, sec, spheres, blocking_best,
+                               (lambda buf: oracle.fnv64(buf) == frame_hash) if (oracle is not None and frame_hash is not None) else None)
+    if world > 1 and not args.no_d2h:
+        pcie = host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks,
+                             (lambda buf: oracle.fnv64(buf) == frame_hash) if (rank == 0 and oracle is not None and frame_hash is not None) else None)
+
+    if watchdog is not None:
+        watchdog.cancel()
+    if rank == 0:
+        print(json.dumps(build_line()), flush=True)
 
     if world > 1:
         barrier()

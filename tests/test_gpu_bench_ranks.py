@@ -67,6 +67,24 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     assert 0 < hs["bytes_over_pcie_per_frame_and_rank"] <= t["max_rows"] * size[0] * 4
 
 
+def test_bench_line_survives_a_leg_that_does_not_finish():
+    """The legs after the headline (sweep, host-sink leg) run under a deadline: when it passes -- here a sweep made far too long
+    for it -- every rank leaves and rank 0 prints the line with the headline figures and a note, exit code 0."""
+    env = dict(os.environ)
+    env.update(PWN_BENCH_ONE_DEVICE="1", PWN_BENCH_TRANSPORT="shm", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--min-time", "0.1", "--sweep-time", "30",
+           "--post-timeout", "0.2", "--time-every", "2", "--width", "1280", "--height", "720"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["frame_fnv64"] == "078fb94a5cd068f5"
+    assert "did not finish" in d["tiling"]["post_note"] and len(d["tiling"]["per_rank"]["trace_ms"]) == 2
+
+
 def test_bench_falls_back_when_rccl_does_not_come_up():
     """RCCL asked for with two ranks on ONE device -- a communicator that cannot be made here: every rank gets an
     error back (or librccl is missing altogether), the ranks agree on the shared-memory transport, and the line says
