@@ -8,12 +8,16 @@
  * the reference tree).  INTEGRATION.md shows the host-side change.
  *
  * Like the reference's render path (globals, one main thread: main.c:26-34) a
- * context is not re-entrant: one thread at a time per context, and the strip
- * forms of one context must be ordered with respect to each other (and to the
- * blocking frame call) by their streams: two trace launches of one context
- * never run at the same time -- they share the level tables and the work-queue
- * counters of the kernel.  Different contexts (one per GPU, one process per
- * GPU) are independent.
+ * context is not re-entrant: one thread at a time per context.  Trace launches
+ * of a context take turns on four sets of work-queue counters: launch n counts in
+ * set n mod 4 and clears the set of launch n + 2.  So a caller of the strip forms
+ * either keeps all its launches on ONE stream, or alternates strictly between
+ * TWO (launch n on stream n mod 2, what the frames in flight and the row tiling
+ * do themselves): launch n + 2 is then ordered behind launch n, and launch n + 1
+ * may run beside it.  Any other pattern needs the caller's own ordering (events)
+ * between launches two apart.  The blocking frame call is ordered behind the
+ * frames in flight.  Different contexts (one per GPU, one process per GPU) are
+ * independent.
  */
 #ifndef PWNHIP_H
 #define PWNHIP_H
@@ -95,8 +99,14 @@ typedef struct pwn_stats
 #define PWN_OPT_FRAME_OVERLAP 7 /* frames in flight: 1 (default) = the kernels of successive frames alternate between two compute
                                   streams, so that the next frame's trace grid fills the CUs the current one's tail leaves idle
                                   and its blur runs beside it; 0 = all frames on one stream, strictly one after the other.
-                                  PWN_EBUSY while frames are in flight.  Frames still complete in submission order as far as
-                                  pwn_wait_frame is concerned (every slot has its own event). */
+                                  PWN_EBUSY while frames are in flight.  A slot's frame is complete when its pwn_wait_frame
+                                  returns (every slot has its own event); frames two apart complete in order, neighbours may
+                                  finish either way round.  Frames f and f + 1 share nothing they write: pre-blur planes by parity,
+                                  colour / depth / surface planes by slot, counter sets by launch, and the tables a frame reads are
+                                  the copy that was current at its submit (four copies; an upload never touches one in use).
+                                  A frame counted (PWN_OPT_COUNTERS) or wave-logged runs on one stream: one set of counters.
+                                  The second stream is created at another priority level than the first so that it gets a
+                                  hardware queue of its own.  The row tiling reads the option at pwn_tiled_init. */
 #define PWN_OPT_FRAME_TIMING 5 /* frames in flight: record HIP events around the trace and blur kernels of every N-th
                                   frame (pwn_frame.timed, .trace_ms ...); 1 = every frame (default), 0 = never.  An event
                                   between two kernels costs a few microseconds of pipeline */
