@@ -187,6 +187,10 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	const uint32_t w1 = (uint32_t)P.w + 1u;
 	const uintptr_t pre1 = (uintptr_t)P.pre - (uintptr_t)w1 * 4u;
 	uint32_t t2 = seed << 1;                               // the LCG state doubled (lcg2_fs, dev_math.h)
+	// (the frame's width and height once in vector registers: blur_coord1's v_med3_i32 takes its bound from one, and handed a
+	// scalar the compiler copied it into a fresh register in front of every one of the 32 clamps)
+	int vw = P.w, vh = P.h;
+	asm volatile("" : "+v"(vw), "+v"(vh));
 	uint32_t tap[4][4];
 	bool missed = false;
 #pragma unroll
@@ -198,7 +202,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 			// screen.h:101-106
 			const float fx = fcx[j] + (lcg2_fs(t2) * fstr) * z[j];
 			const float fy = fcy + (lcg2_fs(t2) * fstr) * z[j];
-			const int x1 = blur_coord1(fx, P.w), y1 = blur_coord1(fy, P.h);
+			const int x1 = blur_coord1(fx, vw), y1 = blur_coord1(fy, vh);
 			if(CHECK) missed |= (unsigned)(y1 - (P.avail_y0 + 1)) >= (unsigned)(P.avail_y1 - P.avail_y0);
 			// from the staged rectangle (every lane reads LDS, at a clamped index); a tap outside it is
 			// fetched from the frame afterwards

@@ -9,7 +9,7 @@
     dynamic   how often a wave64 runs each region with at least one lane: the counting variant's counters
               (pwn_stats.wave_steps, wave_paths, regions), taken on the GPU by tools/region_counts.py
               -> profiles/r3_region_counts.json
-    costs     ns of SIMD issue per wave-instruction, tools/ubench/valu_rate.hip (profiles/r2_valu_rate.txt): full-rate
+    costs     ns of SIMD issue per wave-instruction, tools/ubench/valu_rate.hip (profiles/r3_valu_rate.txt): full-rate
               1 / 0.91, half-rate 1 / 0.545, quarter-rate 1 / 0.29 at 5 waves per SIMD with one opcode; 1 / 1.00, 1 / 0.57,
               1 / 0.293 saturated.  Scalar and branch instructions are counted, not priced: they issue beside the VALU
               instructions of other waves (the table shows what they would add if they did not)
@@ -37,7 +37,7 @@ FULL = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_f
         "v_sub_co_u32", "v_subb_co_u32", "v_xnor_b32", "v_accvgpr_write_b32", "v_accvgpr_read_b32"}
 QUARTER = {"v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_rcp_f64", "v_sqrt_f64", "v_rsq_f64", "v_div_scale_f32", "v_div_fmas_f32", "v_div_fixup_f32",
            "v_rcp_iflag_f32", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32"}
-# ns of SIMD issue per wave-instruction (profiles/r2_valu_rate.txt): at 5 waves per SIMD -- what this kernel runs with -- the
+# ns of SIMD issue per wave-instruction (profiles/r3_valu_rate.txt): at 5 waves per SIMD -- what this kernel runs with -- the
 # microbenchmark's streams of ONE opcode reach 0.91 / 0.545 / 0.29 instructions per ns (full / half / quarter rate); at 8 waves
 # 1.00 / 0.57 / 0.293, the pipes' saturated rates, which a MIXED stream of five waves also reaches (mix_vs: 0.96 at 5 waves)
 COST = {"full": 1.0 / 0.91, "half": 1.0 / 0.545, "quarter": 1.0 / 0.29}
@@ -222,7 +222,7 @@ def main():
     lines = []
     P = lines.append
     P("# issue model of pwn_trace_kernel<false,false> (tools/issue_model.py); static part: %d instructions in %d regions" % (len(ins), len(per)))
-    P("# costs per wave-instruction and SIMD at 5 waves / SIMD (profiles/r2_valu_rate.txt): full-rate VALU %.2f ns, half-rate %.2f ns, quarter-rate %.2f ns"
+    P("# costs per wave-instruction and SIMD at 5 waves / SIMD (profiles/r3_valu_rate.txt): full-rate VALU %.2f ns, half-rate %.2f ns, quarter-rate %.2f ns"
       % (COST["full"], COST["half"], COST["quarter"]))
     P("")
     P("%-14s %6s | %5s %5s %5s | %5s %5s %4s %4s %5s" % ("region", "blocks", "full", "half", "quart", "salu", "br", "lds", "vmem", "other"))

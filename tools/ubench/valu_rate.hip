@@ -112,6 +112,32 @@ KERNEL_PK(k_mad_u64, "v_mad_u64_u32 v[32:33], s[4:5], v64, v66, v[64:65]\nv_mad_
 	"v_mad_u64_u32 v[40:41], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[42:43], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[44:45], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[46:47], s[4:5], v64, v66, v[64:65]\n" \
 	"v_mad_u64_u32 v[48:49], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[50:51], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[52:53], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[54:55], s[4:5], v64, v66, v[64:65]\n" \
 	"v_mad_u64_u32 v[56:57], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[58:59], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[60:61], s[4:5], v64, v66, v[64:65]\nv_mad_u64_u32 v[62:63], s[4:5], v64, v66, v[64:65]\n")
+// round 3: the opcodes the issue model (tools/issue_model.py) classes without a measurement of their own
+KERNEL(k_or_b32,    ASM16("v_or_b32 ", ", %16, %17"))
+KERNEL(k_sub_u32,   ASM16("v_sub_u32 ", ", %16, %17"))
+KERNEL(k_min_u32,   ASM16("v_min_u32 ", ", %16, %17"))
+KERNEL(k_cvt_i32,   ASM16("v_cvt_i32_f32 ", ", %16"))
+KERNEL(k_mul_u24,   ASM16("v_mul_u32_u24 ", ", %16, %17"))
+KERNEL(k_mad_i24,   ASM16("v_mad_i32_i24 ", ", %16, %17, %16"))
+KERNEL(k_and_or,    ASM16("v_and_or_b32 ", ", %16, %17, %16"))
+KERNEL(k_lshl_or,   ASM16("v_lshl_or_b32 ", ", %16, 3, %17"))
+KERNEL(k_perm,      ASM16("v_perm_b32 ", ", %16, %17, %16"))
+KERNEL(k_cvt_pk_u8, ASM16("v_cvt_pk_u8_f32 ", ", %16, 1, %17"))
+KERNEL(k_lerp_u8,   ASM16("v_lerp_u8 ", ", %16, %17, %16"))
+#define F64_16(op, args) \
+	op " v[32:33], " args "\n" op " v[34:35], " args "\n" op " v[36:37], " args "\n" op " v[38:39], " args "\n" \
+	op " v[40:41], " args "\n" op " v[42:43], " args "\n" op " v[44:45], " args "\n" op " v[46:47], " args "\n" \
+	op " v[48:49], " args "\n" op " v[50:51], " args "\n" op " v[52:53], " args "\n" op " v[54:55], " args "\n" \
+	op " v[56:57], " args "\n" op " v[58:59], " args "\n" op " v[60:61], " args "\n" op " v[62:63], " args "\n"
+KERNEL_PK(k_f64_mul, F64_16("v_mul_f64", "v[64:65], v[66:67]"))
+KERNEL_PK(k_f64_add, F64_16("v_add_f64", "v[64:65], v[66:67]"))
+KERNEL_PK(k_cvt_f64_f32, F64_16("v_cvt_f64_f32", "v64"))
+KERNEL_PK(k_lshr_b64, F64_16("v_lshrrev_b64", "3, v[64:65]"))
+#define F32FROM64_16(op) \
+	op " v32, v[64:65]\n" op " v33, v[64:65]\n" op " v34, v[64:65]\n" op " v35, v[64:65]\n" op " v36, v[64:65]\n" op " v37, v[64:65]\n" op " v38, v[64:65]\n" op " v39, v[64:65]\n" \
+	op " v40, v[64:65]\n" op " v41, v[64:65]\n" op " v42, v[64:65]\n" op " v43, v[64:65]\n" op " v44, v[64:65]\n" op " v45, v[64:65]\n" op " v46, v[64:65]\n" op " v47, v[64:65]\n"
+KERNEL_PK(k_cvt_f32_f64, F32FROM64_16("v_cvt_f32_f64"))
+KERNEL_PK(k_cvt_i32_f64, F32FROM64_16("v_cvt_i32_f64"))
 KERNEL(k_max_f32,   ASM16("v_max_f32 ", ", %16, %17"))
 KERNEL(k_cvt,       ASM16("v_cvt_f32_i32 ", ", %16"))
 KERNEL(k_mul_lo,    ASM16("v_mul_lo_u32 ", ", %16, %17"))
@@ -184,6 +210,8 @@ int main(int argc, char **argv)
 	R(mad_u64); R(pk_add_f32); R(pk_mul_f32); R(pk_fma_f32); R(min3_f32); R(med3_i32); R(xor_b32); R(sub_f32); R(lshl_add); R(pk_add_u16); R(dot2_u16); R(bitop3); R(add_dpp); R(cmp_u32); R(f64_fma);
 	R(cmp); R(cmp_e64); R(max_f32); R(cvt); R(mul_lo); R(mul_hi); R(mad_u32); R(add3); R(rcp); R(sqrt); R(salu); R(salu64);
 	R(cmpcnd); R(ifblock);
+	R(or_b32); R(sub_u32); R(min_u32); R(cvt_i32); R(mul_u24); R(mad_i24); R(and_or); R(lshl_or); R(perm); R(cvt_pk_u8); R(lerp_u8);
+	R(f64_mul); R(f64_add); R(cvt_f64_f32); R(lshr_b64); R(cvt_f32_f64); R(cvt_i32_f64);
 	if(only == NULL || strcmp(only, "mix_vs") == 0) run<16>("mix_vs(8v+8s)", k_mix_vs, d, ncu);
 	return 0;
 }
