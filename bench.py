@@ -719,6 +719,18 @@ def main():
         r.tiled_balance(0)
         r.tiled_set_cuts([min(k * tinfo["rows_per_rank"], h) for k in range(world)] + [h])
         point("equal_strips", "pwn_tiled_balance(0) with the equal split (the reference's static schedule, screen.h:63-64)")
+        # rank 0 takes in every other rank's finished strip and sends none: with a taller strip of its own the strips that cross the
+        # links into it get shorter (the gather is what the prediction says binds)
+        tall = min(tinfo["max_rows"], (int(tinfo["rows_per_rank"] * 1.4) + 7) // 8 * 8)
+        rest = h - tall
+        if world > 2 and rest // (world - 1) >= max(tinfo["halo_rows"], 16):
+            each = rest // (world - 1) // 8 * 8
+            cuts_tall = [0] + [tall + k * each for k in range(world - 1)] + [h]
+            try:
+                r.tiled_set_cuts(cuts_tall)
+                point("rank0_tall", "rank 0 traces %d rows, the others %d: less crosses the links into rank 0 per frame" % (tall, each))
+            except Exception as e:                                   # noqa: BLE001 -- (cuts outside the library's bounds: no point)
+                sweep["rank0_tall"] = {"error": str(e)}
         r.tiled_balance(bal)
         barrier()
         r.tiled_shutdown()
