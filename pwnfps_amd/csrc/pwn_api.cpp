@@ -133,7 +133,13 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
 			int prio = greatest < 0 ? greatest : -1;          // (numerically lower = more urgent; 0 is the default level)
 			if(const char *e = getenv("PWN_DBG_STREAM2_PRIORITY")) if(*e) prio = atoi(e);
-			if(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio) != hipSuccess) { rc = PWN_EHIP; break; }
+			if(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio) != hipSuccess)
+			{
+				// (a runtime without stream priorities: an ordinary stream -- the frames then overlap only if it happens
+				// to get a hardware queue of its own)
+				(void)hipGetLastError();
+				if(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+			}
 		}
 		for(int i = 0; i < 4; i++) if(hipEventCreate(&c->ev[i]) != hipSuccess) { rc = PWN_EHIP; break; }
 		for(int i = 0; i < PWN_NBLOB && rc == PWN_OK; i++)

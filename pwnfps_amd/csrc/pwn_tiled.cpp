@@ -473,7 +473,11 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 		{
 			int least = 0, greatest = 0;
 			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-			if(hipStreamCreateWithPriority(&t->comm, hipStreamNonBlocking, greatest < 0 ? greatest : -1) != hipSuccess) { rc = PWN_EHIP; break; }
+			if(hipStreamCreateWithPriority(&t->comm, hipStreamNonBlocking, greatest < 0 ? greatest : -1) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				if(hipStreamCreateWithFlags(&t->comm, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+			}
 		}
 		if(hipMalloc((void **)&t->cost_acc, 128) != hipSuccess) { rc = PWN_ENOMEM; break; }
 		if(hipMemset(t->cost_acc, 0, 128) != hipSuccess) { rc = PWN_EHIP; break; }
