@@ -359,16 +359,23 @@ pwn_trace_kernel(pwn_trace_params P)
 	if(blockIdx.x == 0 && threadIdx.x == PWN_QUEUES && P.clear_word != NULL) *P.clear_word = 0u;
 	uint32_t q = (blockIdx.x * (PWN_BLOCK / 64) + (uint32_t)wave) % PWN_QUEUES;
 	uint32_t ticket;
-	{
-		uint32_t t = 0;
-		if(lane == 0) t = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], 1u);
-		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-	}
+	// The first ticket of a wave is its place among the home waves of its queue: nobody draws it, and the counters
+	// hand out the tickets after those (QBASE).  With a drawn first ticket every wave of the grid waits for a
+	// returning atomic at the start of the launch, 80 of them per counter at once on a full grid (a draw that a wave
+	// waits for costs it 0.7 us on average at 4K and 2.7 us in a strip of an 8-way tiling, tools/r3/draw_probe.py);
+	// static first tickets measured +1.3 % at 4K, +2.5 % at 720p, -0.8 % on the strips' kernel time
+	// (profiles/r3_strips/static_first.txt).
+	const uint32_t nwaves_all = gridDim.x * (PWN_BLOCK / 64);
+#define QBASE(qq) ((nwaves_all + PWN_QUEUES - 1u - (qq)) / PWN_QUEUES)
+	ticket = (blockIdx.x * (PWN_BLOCK / 64) + (uint32_t)wave) / PWN_QUEUES;
 	// A wave that keeps finding queues empty although they looked open stops helping after a
 	// few rounds: every queue is drained by its home waves anyway (a wave leaves its home queue
 	// only when that is empty), so this costs parallelism at the very end at worst and makes
 	// sure every wave's loop ends whatever the loads return.
 	int misses = 0;
+#ifdef PWN_DRAW_PROBE
+	unsigned long long probe_ticks = 0ull, probe_n = 0ull;
+#endif
 	// Tickets are drawn two at a time when the launch is long (>= 16 units per wave): the returning atomic is a
 	// 32-byte write at the memory side, 4 MB per 4K frame with one per unit, 2 MB with pairs.  Strips and small
 	// frames keep single tickets for the balance of their tail; three per draw measured 2.5 % slower at 4K (the
@@ -398,7 +405,7 @@ pwn_trace_kernel(pwn_trace_params P)
 			if(ql < PWN_QUEUES)
 				seen = __hip_atomic_load(&P.tickets[ql * PWN_QUEUE_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const uint32_t len_l = (units + PWN_QUEUES - 1u - (ql & (PWN_QUEUES - 1u))) / PWN_QUEUES;
-			const unsigned long long open = __ballot(ql < PWN_QUEUES && seen < len_l);
+			const unsigned long long open = __ballot(ql < PWN_QUEUES && seen < len_l - min(len_l, QBASE(ql & (PWN_QUEUES - 1u))));
 			if(open == 0ull) break;
 			// the next open queue after q, cyclically: bit i of the shifted double mask is queue q+1+i
 			static_assert(PWN_QUEUES <= 64u && (PWN_QUEUES & (PWN_QUEUES - 1u)) == 0u, "a power of two, one lane per queue");
@@ -412,7 +419,7 @@ pwn_trace_kernel(pwn_trace_params P)
 				q = (q + 1u + (uint32_t)__builtin_ctzll((open | (open << (PWN_QUEUES & 31u))) >> (q + 1u))) & (PWN_QUEUES - 1u);
 			uint32_t t = 0;
 			if(lane == 0) t = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], 1u);
-			ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+			ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) + QBASE(q);
 			continue;
 		}
 		//@R k_unit
@@ -425,10 +432,13 @@ pwn_trace_kernel(pwn_trace_params P)
 		// while its neighbours find the queues empty and leave.  Drawing only when a unit is done, throughout or for the
 		// last tickets of a queue, was built and measured in round 3 (profiles/r3_strips/late_draws.txt, commit 5a68fef):
 		// slower everywhere (a strip of an 8-way tiling 64 -> 65..77 us, 720p 58 -> 62..75 us, 4K equal), also with the
-		// draw issued in front of the unit's colour store: a draw costs a wave ~6 us in this kernel, and the waves of a
-		// SIMD, which run in step, wait for theirs together.
+		// draw issued in front of the unit's colour store.  tools/r3/draw_probe.py times the wait in place: 0.7 us per
+		// draw at 4K (4.7 % of a wave's life), 2.7 us in a strip of an 8-way tiling (13.8 %: its 5 120 waves draw
+		// in step, 80 per counter), profiles/r3_strips/draw_probe.txt.
 		uint32_t next_raw = ticket + 1u;
-		if(draw && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n);
+#ifndef PWN_DRAW_PROBE
+		if(draw && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n) + QBASE(q);
+#endif
 		// rows from the middle outwards: the horizon band, where rays run longest,
 		// is started first and the cheap top and bottom edges make up the tail
 		// (this arithmetic is the same for the whole wave, but the compiler does it per lane because q starts
@@ -500,7 +510,19 @@ pwn_trace_kernel(pwn_trace_params P)
 			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
+#ifdef PWN_DRAW_PROBE
+		// experiment build (tools/r3/draw_probe.py): the draw AFTER the unit, and how long the wave waits for it
+		{
+			const unsigned long long p0 = __builtin_amdgcn_s_memrealtime();
+			if(draw && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n) + QBASE(q);
+			ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
+			asm volatile("" : "+s"(ticket));
+			probe_ticks += __builtin_amdgcn_s_memrealtime() - p0;
+			probe_n++;
+		}
+#else
 		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)next_raw);
+#endif
 		left = draw ? draw_n - 1u : left - 1u;
 	}
 
@@ -530,7 +552,11 @@ pwn_trace_kernel(pwn_trace_params P)
 		static_assert(PWN_BLOCK == 256, "one wave per SIMD: simd_id tells the waves of a workgroup apart");
 		const unsigned simd = __builtin_amdgcn_s_getreg(4 | (4 << 6) | ((2 - 1) << 11));
 		const size_t wid = 1u + (size_t)blockIdx.x * 4u + simd;
+#ifdef PWN_DRAW_PROBE
+		P.wave_log[2 * wid] = probe_ticks | (probe_n << 40); P.wave_log[2 * wid + 1] = __builtin_amdgcn_s_memrealtime() - t_begin;
+#else
 		P.wave_log[2 * wid] = t_begin; P.wave_log[2 * wid + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 	}
 	// Row tiling with moving cuts (pwn_tiled.cpp): what this strip COST, as the sum of its waves' lifetimes in ticks of
 	// the constant 100 MHz clock -- a wave lives exactly as long as it finds units, so the sum is the strip's work
