@@ -532,6 +532,24 @@ extern "C" int pwn_get_bins(pwn_ctx *c, uint16_t counts[4096], int32_t *idx, int
 
 // screen.h:43-57 in the reference build's operation order:
 // rayb = (cam.x + cam.z) + (-yrat)*cam.y
+
+// The trace kernel turns a unit number into (row of units, unit in the row): a division by the units per row, which
+// is the same number for every unit of a launch.  For d >= 2 and s the largest shift with 2^s < d, M = ceil(2^(32+s) / d)
+// fits 32 bits, and with 2^(32+s) = M d - e, 0 <= e < d: n M / 2^(32+s) = n / d + n e / (d 2^(32+s)), whose floor is
+// floor(n / d) while n e < 2^(32+s); e < d <= 2^(s+1), so every n < 2^31 divides exactly (a frame has at most 2^24 units).
+// d == 1 (frames up to 16 pixels wide): shift -1, the kernel divides.
+static void unit_div_magic(uint32_t d, uint32_t *magic, int *shift)
+{
+	*magic = 0u; *shift = -1;
+	if(d < 2u) return;
+	int s = 0;
+	while((2u << s) < d) s++;                  // 2^s < d <= 2^(s+1)
+	const unsigned long long two = 1ull << (32 + s);
+	const unsigned long long M = (two + d - 1u) / d;
+	if(M >> 32) return;
+	*magic = (uint32_t)M; *shift = s;
+}
+
 static void frame_setup(int w, int h, const float cam[16], pwn_trace_params *P)
 {
 	float dimx = (float)w, dimy = (float)h;
@@ -568,6 +586,7 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	P.tiles_x = (c->w + tw - 1) / tw;
 	const int th = pwn_trace_tile_h();
 	P.tiles_total = P.tiles_x * ((y1 - y0 + th - 1) / th);
+	unit_div_magic((uint32_t)P.tiles_x, &P.ux_magic, &P.ux_shift);
 	P.blob_bytes = (uint32_t)c->blob.size();
 	P.off_sph = c->off_sph;
 	P.sbuf = d_sbuf; P.zbuf = d_zbuf;

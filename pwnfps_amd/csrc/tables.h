@@ -132,6 +132,7 @@ struct pwn_trace_params
 	float sec_current;                        // defs.h:23
 	int w, h, y0, y1;
 	int tiles_x, tiles_total;                 // 16 x 4 pixel units (one wave64 each): per row, in all
+	uint32_t ux_magic; int ux_shift;          // unit / tiles_x = (unit * ux_magic >> 32) >> ux_shift for unit < 2^31; ux_shift < 0: divide
 	uint32_t blob_bytes, off_sph;
 	uint32_t *sbuf;                           // full frame, pitch w
 	float *zbuf;                              // full frame, pitch w

@@ -304,6 +304,28 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	out_x = vx; out_y = vy; out_z = vz; out_w = vw + w_acc;
 }
 
+// Rounds 1..15 of the add chain of screen.h:12-18 (see the unit loop): in round k the lanes k..15 of every 16-lane row add
+// rdx once more, so lane j ends with j adds on top of the row's start value -- the same sequence of fp32 additions for
+// every pixel as the reference's "+= rdx" per pixel of the tile.  Written with the execution mask set by hand: a
+// v_add_f32 under a mask issues at full rate, the DPP form of the same systolic chain (v[j] = v[j-1] + rdx, round 2) at
+// half rate, and this is 45 of a unit's ~170 vector instructions.  All 64 lanes are active on entry (wave-uniform
+// control flow); rdx is wave-uniform (kernel argument).
+//@R k_unit
+#define PWN_CHAIN_ROUND3(m) "s_mov_b32 exec_lo, " m "\n\ts_mov_b32 exec_hi, " m "\n\tv_add_f32 %0, %4, %0\n\tv_add_f32 %1, %5, %1\n\tv_add_f32 %2, %6, %2\n\t"
+#define PWN_CHAIN_ROUND4(m) "s_mov_b32 exec_lo, " m "\n\ts_mov_b32 exec_hi, " m "\n\tv_add_f32 %0, %5, %0\n\tv_add_f32 %1, %6, %1\n\tv_add_f32 %2, %7, %2\n\tv_add_f32 %3, %8, %3\n\t"
+#define PWN_CHAIN_ALL(R) R("0xfffefffe") R("0xfffcfffc") R("0xfff8fff8") R("0xfff0fff0") R("0xffe0ffe0") R("0xffc0ffc0") R("0xff80ff80") \
+	R("0xff00ff00") R("0xfe00fe00") R("0xfc00fc00") R("0xf800f800") R("0xf000f000") R("0xe000e000") R("0xc000c000") R("0x80008000")
+template<bool HAS_W> __device__ __forceinline__ void chain_rounds(Vec<HAS_W> &v, const Vec<HAS_W> &rdx)
+{
+	unsigned long long saved;
+	if constexpr(HAS_W)
+		asm volatile("s_mov_b64 %4, exec\n\t" PWN_CHAIN_ALL(PWN_CHAIN_ROUND4) "s_mov_b64 exec, %4"
+			: "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "=&s"(saved) : "s"(rdx.x), "s"(rdx.y), "s"(rdx.z), "s"(rdx.w));
+	else
+		asm volatile("s_mov_b64 %3, exec\n\t" PWN_CHAIN_ALL(PWN_CHAIN_ROUND3) "s_mov_b64 exec, %3"
+			: "+v"(v.x), "+v"(v.y), "+v"(v.z), "=&s"(saved) : "s"(rdx.x), "s"(rdx.y), "s"(rdx.z));
+}
+
 template<bool COUNT, bool HAS_W>
 __global__ void __launch_bounds__(PWN_BLOCK, PWN_MIN_WAVES)
 pwn_trace_kernel(pwn_trace_params P)
@@ -445,7 +467,12 @@ pwn_trace_kernel(pwn_trace_params P)
 		// from the wave number, which it derives from threadIdx.  Declaring q uniform and dividing by a multiply-high
 		// with a host-computed reciprocal moves ~35 VALU instructions per unit to the scalar unit: measured 0.8 %
 		// SLOWER at 4K, three runs -- a wave's scalar instructions issue one at a time and in order)
-		const uint32_t ux = unit % units_x, k = unit / units_x;
+		// unit / units_x by the host's reciprocal (pwn_trace_params.ux_magic: exact for every unit < 2^31, pwn_api.cpp
+		// unit_div_magic): two instructions where the compiler's division takes thirteen; frames one unit wide divide
+		uint32_t k;
+		if(P.ux_shift >= 0) k = __umulhi(unit, P.ux_magic) >> P.ux_shift;
+		else k = unit / units_x;
+		const uint32_t ux = unit - k * units_x;
 		const uint32_t rows_u = ((uint32_t)(P.y1 - P.y0) + 3u) >> 2;
 		// ... of the FRAME: a strip of a row tiling starts at its rows nearest the frame's middle row (the strip of
 		// the whole frame at its own middle), not at its own middle
@@ -482,6 +509,9 @@ pwn_trace_kernel(pwn_trace_params P)
 		}
 		//@R k_unit
 		rayl = vadd<HAS_W>(rayl, rdx);
+#ifndef PWN_CHAIN_DPP
+		chain_rounds<HAS_W>(rayl, rdx);
+#else
 		{
 			const bool first = (l16 == 0);
 			V add;
@@ -496,6 +526,7 @@ pwn_trace_kernel(pwn_trace_params P)
 				if constexpr(HAS_W) rayl.w = dpp_row_shr1(rayl.w) + add.w;
 			}
 		}
+#endif
 
 		if(x < P.w && y < P.y1)
 		{
@@ -506,7 +537,7 @@ pwn_trace_kernel(pwn_trace_params P)
 			seed <<= 1;                               // the generator runs on the doubled state (lcg2_fs, dev_math.h)
 
 			float ox, oy, oz, ow;
-			const size_t o = (size_t)y * (size_t)P.w + (size_t)x;
+			const uint32_t o = __umul24((uint32_t)y, (uint32_t)P.w) + (uint32_t)x;      // w, h <= 32768 (pwn_init)
 			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
