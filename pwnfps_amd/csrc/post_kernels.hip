@@ -26,7 +26,8 @@ struct pwn_blur_params
 	// repeats the strip with the whole frame present).  miss == NULL: every row is valid.
 	int avail_y0, avail_y1;
 	uint32_t *miss;
-	int tile_h;                    // rows of a workgroup's tile: 32, 16 or 8 (pwn_launch_blur picks it by the size of the launch)
+	int tile_h, tile_w, batch;     // a workgroup's tile of output pixels (rows, columns) and the form of its staging loop: pwn_i_launch_blur picks
+	                               // them by the size of the launch, pwn_launch_blur has the instantiations
 	// row tiling with moving cuts: the trace launch in front of this one on the stream added up what its strip cost
 	// in *cost_acc (pwn_trace_params.cost_word); this launch moves the sum to *cost_out, the word that travels with
 	// the frame, and clears the accumulator for the stream's next trace.  Both NULL otherwise.
@@ -120,13 +121,11 @@ pwn_blur_kernel(pwn_blur_params P)
 // bound by that, not by HBM); LDS serves the same gather an order of
 // magnitude faster and the staging adds only (1 + 2*HALO/TW)(1 + 2*HALO/TH)
 // coalesced reads per output pixel.
-#ifndef BLUR_TW
-#define BLUR_TW 128
-#endif
-// Tile height BLUR_TH is a template parameter: 32 rows (1024 threads) for whole frames -- the least staging per
-// output pixel --, 16 or 8 rows for the short launches of a row tiling (a 272-row strip of a 4K frame is 270 tiles
-// of 32 rows for 256 CUs: one round of workgroups that each run their two phases, staging then taps, with
-// nothing to overlap them with; smaller tiles give every CU several workgroups in different phases).
+// The tile (BLUR_TW x BLUR_TH) and the form of the staging loop (BATCH) are template parameters; pwn_i_launch_blur
+// (pwn_api.cpp) picks them.  Rounds 1-2 ran 128 x 32 tiles (1024 threads, 42 KB of LDS: the least staging per output
+// pixel and the fastest launch BY ITSELF); judged by the frame rate with the next frame's trace grid on the chip
+// beside it, small workgroups win -- 32 x 32 (256 threads, 17 KB) on wide frames, 128 x 16 on narrow ones
+// (profiles/r3_blur_sweep.txt).
 #ifndef BLUR_HALO
 #define BLUR_HALO 16        // measured 8 / 16 / 24 / 32: 45.6 / 45.4 / 46.6 / 48.0 us at 4K (less staging beats fewer fall-backs)
 #endif
@@ -135,7 +134,7 @@ pwn_blur_kernel(pwn_blur_params P)
 #define BLUR_PITCH (BLUR_LW + 4)                   // words; +4 keeps rows 16-B aligned and off one bank
 #define BLUR_THREADS (BLUR_TW / 4 * BLUR_TH)       // one thread per 4-pixel group
 
-template<bool CHECK, int BLUR_TH>
+template<bool CHECK, int BLUR_TW, int BLUR_TH, bool BATCH>
 __global__ void __launch_bounds__(BLUR_THREADS)
 pwn_blur_tiled_kernel(pwn_blur_params P)
 {
@@ -161,7 +160,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	uint2 ac;
 	float4 zv;
 	// stage: uint4 = 4 pixels; w % 4 == 0 and lx0 % 4 == 0, so a uint4 is inside the frame or outside
-	if constexpr(BLUR_TH >= 32)
+	if constexpr(!BATCH)
 	{
 		for(int i = threadIdx.x; i < BLUR_LH * (BLUR_LW / 4); i += BLUR_THREADS)
 		{
@@ -177,20 +176,18 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	}
 	else
 	{
-		// The small tiles of short launches (strips of a row tiling, frames up to ~1080p): a workgroup has little beside it
-		// on its CU to hide its staging behind, so (1) the thread's own two loads from HBM (skip-ahead constants,
-		// depths) are asked for first and used behind the barrier, and (2) all of its staging loads are in flight
-		// together, from an address clamped into the frame (what lies outside is not stored) -- as the plain loop above
-		// the compiler waits for every load before it issues the next.  Measured: 720p +3.7 %, the strips of an 8-way
-		// 4K tiling -0.6 % kernel time; on the 32-row tiles of large frames the same change measured 0 (4K) to -0.7 %
-		// (8K), so those keep the loop (profiles/r3_blur_staging.txt).
+		// The shipped form: (1) the thread's own two loads from HBM (skip-ahead constants, depths) are asked for first and
+		// used behind the barrier, and (2) all of its staging loads are in flight together, from an address clamped into the
+		// frame (what lies outside is not stored) -- as the plain loop above the compiler waits for every load before it
+		// issues the next, and a workgroup has nothing else to do until its tile is there (profiles/r3_blur_staging.txt,
+		// r3_blur_sweep.txt: batch 1 against batch 0).
 		const int gq = mine ? g : 0, cyq = mine ? cy : P.y0;
 		ac = P.skip[gq];
 		zv = *(const float4 *)(P.zbuf + (size_t)cyq * (size_t)P.w + (size_t)(gq * 4));
 		typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 		constexpr int NV = BLUR_LH * (BLUR_LW / 4);
 		constexpr int NT = (NV + BLUR_THREADS - 1) / BLUR_THREADS;
-		static_assert(BLUR_TH >= 32 || NT == 4 || NT == 7, "the barrier below names its operands");
+		static_assert(NT >= 1 && NT <= 8, "the barrier below names its operands");
 		u32x4 r[NT];
 		int dst[NT];
 #pragma unroll
@@ -204,8 +201,14 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 			const int gyc = min(max(gy, 0), P.h - 1), gxc = min(max(gx, 0), P.w - 4);
 			r[k] = *(const u32x4 *)(P.pre + (size_t)gyc * (size_t)P.w + (size_t)gxc);
 		}
+		// (all of them live at one point: the loads cannot be sunk to their stores one by one)
+		if constexpr(NT == 2) asm volatile("" : "+v"(r[0]), "+v"(r[1]));
+		if constexpr(NT == 3) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]));
 		if constexpr(NT == 4) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]));
+		if constexpr(NT == 5) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]));
+		if constexpr(NT == 6) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]));
 		if constexpr(NT == 7) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]));
+		if constexpr(NT == 8) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
 #pragma unroll
 		for(int k = 0; k < NT; k++)
 			if(dst[k] >= 0) *(u32x4 *)__builtin_assume_aligned(tile + dst[k], 16) = r[k];
@@ -275,10 +278,10 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	if(CHECK) { if(missed) atomicAdd(P.miss, 1u); }
 }
 
-template<bool CHECK, int TH>
+template<bool CHECK, int TW, int TH, bool BATCH>
 static hipError_t launch_blur_variant(const pwn_blur_params *P, hipStream_t stream)
 {
-	const int BLUR_TH = TH;
+	const int BLUR_TW = TW, BLUR_TH = TH;
 	const size_t lds = (size_t)BLUR_PITCH * BLUR_LH * sizeof(uint32_t);
 	static bool lds_mark[64];
 	static std::mutex lds_lock;      // contexts of several threads share the per-function attribute
@@ -289,15 +292,21 @@ static hipError_t launch_blur_variant(const pwn_blur_params *P, hipStream_t stre
 		bool &lds_set = lds_mark[dev & 63];
 		if(!lds_set)
 		{
-			hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<CHECK, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipError_t e = hipFuncSetAttribute((const void *)pwn_blur_tiled_kernel<CHECK, TW, TH, BATCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 			if(e != hipSuccess) return e;
 			lds_set = true;
 		}
 	}
 	const int ntiles = ((P->w + BLUR_TW - 1) / BLUR_TW) * ((P->y1 - P->y0 + BLUR_TH - 1) / BLUR_TH);
 	dim3 grid(((ntiles + 7) / 8) * 8);
-	hipLaunchKernelGGL((pwn_blur_tiled_kernel<CHECK, TH>), grid, dim3(BLUR_THREADS), lds, stream, *P);
+	hipLaunchKernelGGL((pwn_blur_tiled_kernel<CHECK, TW, TH, BATCH>), grid, dim3(BLUR_THREADS), lds, stream, *P);
 	return hipGetLastError();
+}
+
+template<int TW, int TH, bool BATCH>
+static hipError_t launch_blur_check(const pwn_blur_params *P, hipStream_t stream)
+{
+	return P->miss != NULL ? launch_blur_variant<true, TW, TH, BATCH>(P, stream) : launch_blur_variant<false, TW, TH, BATCH>(P, stream);
 }
 
 extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream)
@@ -308,12 +317,25 @@ extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stre
 	hipLaunchKernelGGL(pwn_blur_kernel, grid, dim3(256), 0, stream, *P);
 	return hipGetLastError();
 #else
-	const bool check = P->miss != NULL;
-	switch(P->tile_h)
+	// tile shape (tile_w x tile_h output pixels per workgroup) and staging form: chosen by pwn_i_launch_blur
+	const int key = P->tile_w * 1000 + P->tile_h * 10 + (P->batch ? 1 : 0);
+	switch(key)
 	{
-		case 8: return check ? launch_blur_variant<true, 8>(P, stream) : launch_blur_variant<false, 8>(P, stream);
-		case 16: return check ? launch_blur_variant<true, 16>(P, stream) : launch_blur_variant<false, 16>(P, stream);
-		default: return check ? launch_blur_variant<true, 32>(P, stream) : launch_blur_variant<false, 32>(P, stream);
+#ifdef PWN_BLUR_SWEEP
+		case 128320: return launch_blur_check<128, 32, false>(P, stream);
+		case 128321: return launch_blur_check<128, 32, true>(P, stream);
+		case 128160: return launch_blur_check<128, 16, false>(P, stream);
+		case 128080: return launch_blur_check<128, 8, false>(P, stream);
+		case 128081: return launch_blur_check<128, 8, true>(P, stream);
+		case 64320: return launch_blur_check<64, 32, false>(P, stream);
+		case 64160: return launch_blur_check<64, 16, false>(P, stream);
+		case 64161: return launch_blur_check<64, 16, true>(P, stream);
+		case 64081: return launch_blur_check<64, 8, true>(P, stream);
+		case 64321: return launch_blur_check<64, 32, true>(P, stream);
+#endif
+		case 128161: return launch_blur_check<128, 16, true>(P, stream);
+		case 32321: return launch_blur_check<32, 32, true>(P, stream);
+		default: return hipErrorInvalidValue;
 	}
 #endif
 }

@@ -66,6 +66,9 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->dbg_blocks_per_cu = 0;
 	c->dbg_blur_th = 0;
 	if(const char *e = getenv("PWN_DBG_BLUR_TH")) c->dbg_blur_th = atoi(e);
+	c->dbg_blur_tw = 0; c->dbg_blur_batch = -1;          // (sweeps with a -DPWN_BLUR_SWEEP build: tools/r3/run_w.sh)
+	if(const char *e = getenv("PWN_DBG_BLUR_TW")) c->dbg_blur_tw = atoi(e);
+	if(const char *e = getenv("PWN_DBG_BLUR_BATCH")) if(*e) c->dbg_blur_batch = atoi(e);
 	if(const char *e = getenv("PWN_DBG_BLOCKS_PER_CU")) { int v = atoi(e); if(v > 0) c->dbg_blocks_per_cu = v; }
 	c->blob_cur = 0; c->blob_dirty = true; c->off_sph = 0; c->stage_next = 0; c->up_stream = NULL;
 	for(int i = 0; i < PWN_NBLOB; i++)
@@ -697,13 +700,17 @@ int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const f
 	B.pre = d_pre; B.zbuf = d_z; B.out = d_out; B.skip = c->d_skip;
 	B.avail_y0 = avail_y0; B.avail_y1 = avail_y1; B.miss = d_miss;
 	B.cost_acc = d_cost_acc; B.cost_out = d_cost_out;
-	// rows per workgroup tile (post_kernels.hip): 32 while that still gives every CU a few workgroups, less for
-	// the short launches of a row tiling
+	// The workgroup's tile of output pixels (post_kernels.hip), chosen by what the frame rate on two streams said
+	// (profiles/r3_blur_sweep.txt): 32 x 32 for wide frames and their strips (256-thread workgroups with 17 KB of LDS find room
+	// beside the trace grid's workgroups that a 1024-thread one with 42 KB does not: 4K +1.9 %, 8K +5.3 %, the strips of an
+	// 8-way 4K tiling -3.5 % kernel time against the 128 x 32 of rounds 1-2), 128 x 16 for narrow ones (720p +4.8 %, 1080p
+	// +3.4 %; 32 x 32 loses 6 % at 720p).  Any shape gives the same pixels.
 	{
-		const int tiles_x = (c->w + 127) / 128, rows = y1 - y0;
-		B.tile_h = 32;
-		if(tiles_x * ((rows + 31) / 32) < 4 * c->num_cus) B.tile_h = 16;        // (8 rows: no better than 16 on a 272-row strip, 11.5 against 10.7 us)
+		B.tile_w = 32; B.tile_h = 32; B.batch = 1;
+		if(c->w < 2560) { B.tile_w = 128; B.tile_h = 16; }
 		if(c->dbg_blur_th == 8 || c->dbg_blur_th == 16 || c->dbg_blur_th == 32) B.tile_h = c->dbg_blur_th;
+		if(c->dbg_blur_tw == 32 || c->dbg_blur_tw == 64 || c->dbg_blur_tw == 128) B.tile_w = c->dbg_blur_tw;
+		if(c->dbg_blur_batch >= 0) B.batch = c->dbg_blur_batch ? 1 : 0;
 	}
 	HIPCHK(c, pwn_launch_blur(&B, stream));
 	return PWN_OK;

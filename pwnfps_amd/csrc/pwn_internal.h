@@ -19,7 +19,7 @@ struct pwn_blur_params
 	const uint2 *skip;
 	int avail_y0, avail_y1;
 	uint32_t *miss;
-	int tile_h;
+	int tile_h, tile_w, batch;
 	uint32_t *cost_acc, *cost_out;
 };
 
@@ -107,7 +107,7 @@ struct pwn_ctx
 	unsigned long long *d_counters;
 	unsigned long long *d_wave_log; int wave_log_on; size_t wave_log_cap;   // PWN_OPT_WAVE_LOG; entries (16 B) allocated
 	bool dbg_force_hasw; int dbg_blocks_per_cu;      // PWN_DBG_* hooks, read at pwn_init
-	int dbg_blur_th;                 // PWN_DBG_BLUR_TH: tile height of every blur launch (8 / 16 / 32), 0 = the launcher's choice
+	int dbg_blur_th, dbg_blur_tw, dbg_blur_batch;                 // PWN_DBG_BLUR_TH: tile height of every blur launch (8 / 16 / 32), 0 = the launcher's choice
 	int grid_reserve;                // workgroups the persistent trace grid leaves free (row tiling over RCCL), else 0
 	uint32_t *trace_cost_word;       // likewise: pwn_trace_params.cost_word for the next launch
 	uint32_t *trace_clear_word;      // set by a caller of pwn_i_launch_trace for its next launch: see pwn_trace_params.clear_word
