@@ -332,6 +332,11 @@ extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stre
 		case 64161: return launch_blur_check<64, 16, true>(P, stream);
 		case 64081: return launch_blur_check<64, 8, true>(P, stream);
 		case 64321: return launch_blur_check<64, 32, true>(P, stream);
+		case 32161: return launch_blur_check<32, 16, true>(P, stream);
+		case 16321: return launch_blur_check<16, 32, true>(P, stream);
+		case 32641: return launch_blur_check<32, 64, true>(P, stream);
+		case 64641: return launch_blur_check<64, 64, true>(P, stream);
+		case 16641: return launch_blur_check<16, 64, true>(P, stream);
 #endif
 		case 128161: return launch_blur_check<128, 16, true>(P, stream);
 		case 32321: return launch_blur_check<32, 32, true>(P, stream);

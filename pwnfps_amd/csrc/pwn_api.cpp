@@ -708,8 +708,8 @@ int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const f
 	{
 		B.tile_w = 32; B.tile_h = 32; B.batch = 1;
 		if(c->w < 2560) { B.tile_w = 128; B.tile_h = 16; }
-		if(c->dbg_blur_th == 8 || c->dbg_blur_th == 16 || c->dbg_blur_th == 32) B.tile_h = c->dbg_blur_th;
-		if(c->dbg_blur_tw == 32 || c->dbg_blur_tw == 64 || c->dbg_blur_tw == 128) B.tile_w = c->dbg_blur_tw;
+		if(c->dbg_blur_th > 0) B.tile_h = c->dbg_blur_th;          // (a shape without an instantiation: the launch fails with hipErrorInvalidValue)
+		if(c->dbg_blur_tw > 0) B.tile_w = c->dbg_blur_tw;
 		if(c->dbg_blur_batch >= 0) B.batch = c->dbg_blur_batch ? 1 : 0;
 	}
 	HIPCHK(c, pwn_launch_blur(&B, stream));
