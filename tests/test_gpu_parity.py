@@ -174,6 +174,30 @@ def test_ragged_large_frames_vs_oracle(oracle_lib):
         r.close()
 
 
+def test_extreme_aspect_frames_vs_oracle(oracle_lib):
+    """The widest and the tallest frame pwn_init takes (32768), one unit high / one unit wide, and widths whose units per
+    row are 1, a power of two, and neither: the kernel turns a unit number into (row, column) with a reciprocal the host
+    computes per launch (pwn_api.cpp unit_div_magic; frames one unit wide divide), the blur picks its tile shape by
+    the width, and the pixel index is 32-bit arithmetic.  Every pixel and depth against the oracle, blur included."""
+    import pwnfps_amd
+    from oracle import Oracle
+    O = Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    O.set_spheres(load_spheres("t0"))
+    for (w, h), ang in (((32768, 4), 0.3), ((4, 32768), 1.9), ((16, 2048), -0.7), ((2048, 12), 2.6), ((2064, 20), 0.9), ((4096, 36), -2.2)):
+        cam = pwnfps_amd.spawn_camera((9, 4), ang_y=ang, ang_x=-0.04)
+        r = _renderer(w, h)
+        r.level_load(level_path("pwnfps_level"))
+        r.set_objects(load_spheres("t0"))
+        for blur in (0, 1):
+            ob, oz = O.render(w, h, cam, sec=0.7, blur=blur)
+            r.set_blur_passes(blur)
+            sb, zb = r.trace_screen_centred(cam, 0.7)
+            assert (sb == ob).all(), (w, h, blur, int((sb != ob).sum()))
+            assert (zb.view(np.uint32) == oz.view(np.uint32)).all(), (w, h, blur)
+        r.close()
+
+
 def test_campaign(oracle_lib):
     c = np.load(os.path.join(GOLD, "campaign.npz"))
     ctxs = {}
