@@ -230,7 +230,8 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	// absorb the difference: the staged rectangle's origin, the rows this rank holds, and the frame's base
 	// address (moved back by one row and one pixel -- as an integer, no pointer outside the allocation is formed
 	// until the offset of a real tap, >= w + 1, has been added).
-	const int lx1 = lx0 + 1, ly1 = ly0 + 1;
+	int lx1 = lx0 + 1, ly1 = ly0 + 1;
+	asm volatile("" : "+s"(lx1), "+s"(ly1));       // (one scalar each: left to itself the compiler subtracts the tile's origin and adds the constant per tap)
 	const uint32_t w1 = (uint32_t)P.w + 1u;
 	const uintptr_t pre1 = (uintptr_t)P.pre - (uintptr_t)w1 * 4u;
 	uint32_t t2 = seed << 1;                               // the LCG state doubled (lcg2_fs, dev_math.h)
