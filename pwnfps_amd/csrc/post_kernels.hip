@@ -252,21 +252,21 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 			const float fy = fcy + (lcg2_fs(t2) * fstr) * z[j];
 			const int x1 = blur_coord1(fx, vw), y1 = blur_coord1(fy, vh);
 			if(CHECK) missed |= (unsigned)(y1 - (P.avail_y0 + 1)) >= (unsigned)(P.avail_y1 - P.avail_y0);
-			// from the staged rectangle (every lane reads LDS, at a clamped index); a tap outside it is
-			// fetched from the frame afterwards
 			const unsigned tx = (unsigned)(x1 - lx1), ty = (unsigned)(y1 - ly1);
-			uint32_t v = tile[min(ty * BLUR_PITCH + tx, (unsigned)(BLUR_PITCH * BLUR_LH - 1))];
+			// ONE load through a generic pointer: into the staged rectangle, or -- behind a real branch around the address
+			// arithmetic of the rare case (left alone the compiler computes both addresses and selects) -- into the frame.
+			// hipcc emits a flat load for it, through the LDS aperture or a global address.  (Forcing a ds_read plus a separate
+			// global load serialises the taps on their waits: 46.2 against 45.5 us at 4K with 128 x 32 tiles; without the
+			// branch -- every lane loading from the frame as well, then a select -- 5 % fewer vector instructions, all 32
+			// loads in flight, and 1-2 us SLOWER.  Round 3: the LDS index is no longer clamped for the lanes that do not use
+			// it -- one v_min_u32 per tap.)
+			const uint32_t *p = tile + (ty * BLUR_PITCH + tx);
 			if(!(tx < (unsigned)BLUR_LW && ty < (unsigned)BLUR_LH))
 			{
-				// a real branch around the address arithmetic of the rare case (left alone the compiler selects between
-				// the two pointers with both computed).  What it emits is still ONE flat load after the branch, through
-				// an LDS-aperture or a global address; forcing a ds_read plus a separate global load serialises the
-				// taps on their waits: 46.2 against 45.5 us.  Without the branch -- every lane loading from the frame
-				// as well, staged lanes all from one address, then a select -- there are 5 % fewer vector instructions
-				// and all 32 loads are in flight together, and the kernel is 1-2 us SLOWER (42.2 us).
 				asm volatile("");
-				v = *(const uint32_t *)(pre1 + ((uintptr_t)__umul24((unsigned)y1, (unsigned)P.w) + (uintptr_t)(unsigned)x1) * 4u);
+				p = (const uint32_t *)(pre1 + ((uintptr_t)__umul24((unsigned)y1, (unsigned)P.w) + (uintptr_t)(unsigned)x1) * 4u);
 			}
+			const uint32_t v = *p;
 			tap[i][j] = v;
 		}
 	}
