@@ -277,7 +277,7 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
  *                        with its miss words; then this frame's halo rows).  At most three frames in
  *                        flight (PWN_EBUSY): a frame then costs max(kernels, exchange), not their sum, and
  *                        waiting for frame f-2 right after submitting f does not wait for f's trace.
- *   pwn_tiled_wait       every rank: block until the oldest frame in flight is complete; on rank 0
+ *   pwn_tiled_wait       every rank: block until the oldest frame in flight is complete; on rank 0 (the frame's root)
  *                        out->d_sbuf is the full frame on the device (valid until three more frames
  *                        were submitted) and, with PWN_TILED_HOST, out->sbuf a pinned host copy.
  *   pwn_tiled_host_sink  optional, every rank, after pwn_tiled_init and before the first frame: frames are
@@ -290,6 +290,14 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
  *                        rank's copy, so that a frame is delivered when every strip has landed.  pwn_tiled_wait
  *                        then gives out->sbuf on EVERY rank (valid until the second next pwn_tiled_submit),
  *                        out->d_sbuf is NULL.
+ *   pwn_tiled_gather_root  optional, collective (the same call on every rank, no frame in flight): which rank a frame is
+ *                        gathered on.  PWN_TILED_ROOT_FIXED (default): rank 0, every frame -- its links then carry (N-1)/N
+ *                        of every frame, which bounds the frame rate of a tiling whose kernels are faster than that
+ *                        (xGMI is point to point: 7 links into one GPU).  PWN_TILED_ROOT_ROTATE: frame f
+ *                        (pwn_tiled_frame.seq - 1) is gathered on rank f mod N, for consumers that sit on every GPU
+ *                        (an encoder per device, N displays): every rank then takes in 1/N of the frames and each of
+ *                        its links carries one strip every N-th frame.  pwn_tiled_wait gives out->d_sbuf (and, with
+ *                        PWN_TILED_HOST, out->sbuf) on the frame's root, out->root says which rank that is.
  *   pwn_tiled_shutdown   collective; pwn_destroy does it too.
  * PWN_TRANSPORT_SHM moves the same messages through POSIX shared memory instead: for tests
  * on a box with one GPU, where RCCL cannot run two ranks; the ranks may share a device.
@@ -300,10 +308,12 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
 #define PWN_TILED_HOST     1
 #define PWN_TILED_SLOTS    4       /* frames a host sink holds (three in flight and the one being reused) */
 #define PWN_TILED_MAX_WORLD 64
+#define PWN_TILED_ROOT_FIXED  0
+#define PWN_TILED_ROOT_ROTATE 1
 typedef struct pwn_tiled_frame
 {
-	const void *d_sbuf;          /* rank 0: the frame on the device, BGRA8, pitch = width; NULL elsewhere */
-	const uint32_t *sbuf;        /* rank 0 with PWN_TILED_HOST: pinned host copy; with a host sink: the frame, on every rank */
+	const void *d_sbuf;          /* the frame's root (rank 0 unless pwn_tiled_gather_root): the frame on the device, BGRA8, pitch = width; NULL elsewhere */
+	const uint32_t *sbuf;        /* the root with PWN_TILED_HOST: pinned host copy; with a host sink: the frame, on every rank */
 	uint64_t seq;                /* 1, 2, ... in submission order */
 	int redone;                  /* 1: a tap left the halo and the frame was repeated with whole strips */
 	int timed;                   /* PWN_OPT_FRAME_TIMING sampled this frame: */
@@ -314,6 +324,7 @@ typedef struct pwn_tiled_frame
 	float enqueue_us;            /* host time inside pwn_tiled_submit for this frame (every frame) */
 	int y0, y1;                  /* the rows this rank traced of this frame (the cuts move: pwn_tiled_balance) */
 	uint32_t cost;               /* what they cost: sum of the trace waves' lifetimes, ticks of the GPU's 100 MHz clock */
+	int root;                    /* the rank this frame was gathered on (pwn_tiled_gather_root; -1 with a host sink) */
 } pwn_tiled_frame;
 typedef struct pwn_tiled_info
 {
@@ -327,12 +338,14 @@ typedef struct pwn_tiled_info
 	int grid_reserve;                              /* workgroups the trace grid leaves free for RCCL's kernels (pwn_tiled_set_reserve) */
 	int two_streams;                               /* 1: frames alternate between two compute streams (PWN_OPT_FRAME_OVERLAP at init) */
 	uint64_t recuts;                               /* how often the cuts moved */
+	int gather_root;                               /* PWN_TILED_ROOT_* (pwn_tiled_gather_root) */
 } pwn_tiled_info;
 int pwn_tiled_unique_id(void *id128, int transport);
 int pwn_tiled_init(pwn_ctx *ctx, int rank, int world, const void *id128, int transport, int halo_rows);
 int pwn_tiled_submit(pwn_ctx *ctx, const float cam[16], float sec_current);
 int pwn_tiled_wait(pwn_ctx *ctx, int flags, pwn_tiled_frame *out);
 int pwn_tiled_host_sink(pwn_ctx *ctx, void *base, size_t bytes);
+int pwn_tiled_gather_root(pwn_ctx *ctx, int mode);
 int pwn_tiled_get_info(pwn_ctx *ctx, pwn_tiled_info *out);
 void pwn_tiled_shutdown(pwn_ctx *ctx);
 /*

@@ -48,14 +48,14 @@ class TiledFrame(C.Structure):
     _fields_ = [("d_sbuf", C.c_void_p), ("sbuf", C.c_void_p), ("seq", C.c_uint64), ("redone", C.c_int),
                 ("timed", C.c_int), ("trace_ms", C.c_float), ("frame_ms", C.c_float), ("blur_ms", C.c_float),
                 ("halo_ms", C.c_float), ("gather_ms", C.c_float), ("enqueue_us", C.c_float),
-                ("y0", C.c_int), ("y1", C.c_int), ("cost", C.c_uint32)]
+                ("y0", C.c_int), ("y1", C.c_int), ("cost", C.c_uint32), ("root", C.c_int)]
 
 
 class TiledInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("rank", "world", "y0", "y1", "rows_per_rank", "halo_rows", "transport")] + \
                [(n, C.c_uint64) for n in ("frames", "frames_redone", "groups", "bytes_sent", "bytes_received", "bytes_to_host")] + \
                [(n, C.c_int) for n in ("host_sink", "max_rows", "balance_every", "grid_reserve", "two_streams")] + \
-               [("recuts", C.c_uint64)]
+               [("recuts", C.c_uint64), ("gather_root", C.c_int)]
 
 
 PWN_TILED_ID_BYTES = 128
@@ -98,6 +98,7 @@ ABI = [
     ("pwn_tiled_submit", _i, [_vp, _vp, _f]),
     ("pwn_tiled_wait", _i, [_vp, _i, C.POINTER(TiledFrame)]),
     ("pwn_tiled_host_sink", _i, [_vp, _vp, C.c_size_t]),
+    ("pwn_tiled_gather_root", _i, [_vp, _i]),
     ("pwn_tiled_get_info", _i, [_vp, C.POINTER(TiledInfo)]),
     ("pwn_tiled_shutdown", None, [_vp]),
     ("pwn_tiled_balance", _i, [_vp, _i]),

@@ -235,6 +235,7 @@ struct pwn_tiled
 	int want_halo;                      // the halo asked for at init; moving cuts keep every strip at least this tall
 	int halo;                           // rows exchanged with each neighbour; 0 = whole strips to everybody
 	int fhalo[NSLOT];                   // ... as used for the frame in that slot (the mode changes after a miss)
+	int root_mode, froot[NSLOT];     // pwn_tiled_gather_root: PWN_TILED_ROOT_*; the rank the slot's frame is gathered on
 	int balance_every;                  // re-cut every this many delivered frames from the ranks' cost words; 0 = never
 	uint32_t last_cost[MAXW];           // the cost words of the last delivered frame (pwn_tiled_get_cuts)
 	// what the re-cut works from: per rank the SMALLEST cost among the delivered frames that were traced with acc_cuts
@@ -557,6 +558,28 @@ extern "C" int pwn_tiled_set_reserve(pwn_ctx *c, int workgroups)
 	return PWN_OK;
 }
 
+extern "C" int pwn_tiled_gather_root(pwn_ctx *c, int mode)
+{
+	if(c == NULL || c->tiled == NULL || (mode != PWN_TILED_ROOT_FIXED && mode != PWN_TILED_ROOT_ROTATE)) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	if(t->submitted != t->delivered) return PWN_EBUSY;
+	if(mode == PWN_TILED_ROOT_ROTATE && t->host_base == NULL)
+	{
+		// every rank is the root of some frames: the buffers a root assembles frames in
+		(void)hipSetDevice(c->device);
+		const size_t n = (size_t)c->w * (size_t)c->h;
+		for(int s = 0; s < NSLOT; s++)
+			if(t->fin[s] == NULL)
+			{
+				if(hipMalloc((void **)&t->fin[s], n * 4) != hipSuccess) return PWN_ENOMEM;
+				if(hipMemset(t->fin[s], 0, n * 4) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return PWN_EHIP;
+			}
+	}
+	t->root_mode = mode;
+	t->info.gather_root = mode;
+	return PWN_OK;
+}
+
 extern "C" int pwn_tiled_set_cuts(pwn_ctx *c, const int *cuts, int n)
 {
 	if(c == NULL || c->tiled == NULL || cuts == NULL) return PWN_EINVAL;
@@ -639,17 +662,19 @@ static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 	int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
 	// host sink: no strips; the words go out behind this rank's copy to the host
 	if(t->host_base != NULL) return add_words(c, t, s);
-	if(t->rank == 0)
+	const int root = t->froot[s];
+	if(t->rank == root)
 	{
-		for(int r = 1; r < t->world; r++)
+		for(int r = 0; r < t->world; r++)
 		{
+			if(r == root) continue;
 			int a, b; rows_of(t, s, r, &a, &b);
 			if(b > a) { TPCHK(c, t->tp->recv(t->fin[s] + (size_t)a * c->w, (size_t)(b - a) * w4, r)); t->info.bytes_received += (unsigned long long)(b - a) * w4; }
 		}
 	}
 	else if(y1 > y0)
 	{
-		TPCHK(c, t->tp->send(mine + (size_t)y0 * c->w, (size_t)(y1 - y0) * w4, 0));
+		TPCHK(c, t->tp->send(mine + (size_t)y0 * c->w, (size_t)(y1 - y0) * w4, root));
 		t->info.bytes_sent += (unsigned long long)(y1 - y0) * w4;
 	}
 	return add_words(c, t, s);
@@ -706,7 +731,7 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 	{
 		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
 		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k2[s], cs));
-		uint32_t *dst = (t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->out[s];
+		uint32_t *dst = (t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->out[s];
 		// the trace of this frame, in front of this launch on the stream, added up what the strip cost: the blur
 		// moves that into the frame's second word and clears the accumulator for the stream's next trace
 		uint32_t *acc = t->cost_acc + 16 * (k & 1u);
@@ -745,12 +770,13 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	const size_t w4 = (size_t)c->w * 4;
 	hipStream_t cs = t->cs[f & 1u];
 	t->fhalo[s] = t->halo;
+	t->froot[s] = t->root_mode == PWN_TILED_ROOT_ROTATE ? (int)(f % (unsigned long long)t->world) : 0;
 	memcpy(t->fcuts[s], t->cuts, sizeof(t->cuts));
 	const int y0 = t->cuts[t->rank], y1 = t->cuts[t->rank + 1];
 	// The slot's buffers were frame f-4's.  Its blur ran on this stream; its strips left in G(f-4) and in
 	// the group that carried its gather, and the frame was delivered (three in flight at most), which
 	// waited for that group on the host: nothing to wait for here.
-	uint32_t *plane = c->blur_passes ? t->pre[s] : ((t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->pre[s]);
+	uint32_t *plane = c->blur_passes ? t->pre[s] : ((t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->pre[s]);
 	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
 	t->timed_g2[s] = false;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
@@ -898,7 +924,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		TPCHK(c, t->tp->end());
 		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
 		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_d[s], 0));
-		uint32_t *dst = (t->rank == 0 && t->host_base == NULL) ? t->fin[s] : t->out[s];
+		uint32_t *dst = (t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->out[s];
 		// (this stream's cost accumulator may hold the trace of frame d+2 by now: it is left alone, the frame's
 		// cost word was moved by its first blur)
 		rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL, NULL, NULL);
@@ -953,6 +979,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		out->timed = t->timed[s] ? 1 : 0;
 		out->y0 = t->fcuts[s][t->rank]; out->y1 = t->fcuts[s][t->rank + 1];
 		out->cost = cost[t->rank];
+		out->root = t->host_base != NULL ? -1 : t->froot[s];
 		out->enqueue_us = t->enqueue_us[s];
 		if(t->timed[s])
 		{
@@ -967,7 +994,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 			if(hipGetLastError() != hipSuccess) { /* (an event without timing data: the figure stays 0) */ }
 		}
 		if(t->host_base != NULL) out->sbuf = (const uint32_t *)(t->host_base + (size_t)s * n * 4);
-		else if(t->rank == 0)
+		else if(t->rank == t->froot[s])
 		{
 			out->d_sbuf = t->fin[s];
 			if(flags & PWN_TILED_HOST)

@@ -240,14 +240,15 @@ class Renderer:
         self._chk(lib.pwn_tiled_submit(self._ctx, cam.ctypes.data, float(sec_current)), "pwn_tiled_submit")
 
     def tiled_wait(self, host=False):
-        """Oldest frame in flight.  Rank 0: dict with d_sbuf (device pointer) and, with host=True,
-        sbuf (numpy view of the pinned copy); other ranks: dict without them.  With a host sink
+        """Oldest frame in flight.  The frame's root (rank 0, or rank (seq - 1) mod world after tiled_gather_root(True)):
+        dict with d_sbuf (device pointer) and, with host=True, sbuf (numpy view of the pinned copy); other ranks: dict
+        without them ("root" says which rank has it).  With a host sink
         (tiled_host_sink) every rank gets sbuf, a view of the frame in the shared host memory."""
         fr = _lib.TiledFrame()
         self._chk(lib.pwn_tiled_wait(self._ctx, _lib.PWN_TILED_HOST if host else 0, C.byref(fr)), "pwn_tiled_wait")
         out = {"seq": fr.seq, "redone": bool(fr.redone), "d_sbuf": fr.d_sbuf, "timed": bool(fr.timed),
                "trace_ms": fr.trace_ms, "frame_ms": fr.frame_ms, "blur_ms": fr.blur_ms, "halo_ms": fr.halo_ms,
-               "gather_ms": fr.gather_ms, "enqueue_us": fr.enqueue_us, "y0": fr.y0, "y1": fr.y1, "cost": fr.cost}
+               "gather_ms": fr.gather_ms, "enqueue_us": fr.enqueue_us, "y0": fr.y0, "y1": fr.y1, "cost": fr.cost, "root": fr.root}
         if fr.sbuf:
             out["sbuf"] = np.ctypeslib.as_array(C.cast(fr.sbuf, C.POINTER(C.c_uint32)), shape=(self.w * self.h,)).reshape(self.h, self.w)
         return out
@@ -258,6 +259,11 @@ class Renderer:
         arr = np.frombuffer(buf, np.uint8)
         self._host_sink = (buf, arr)                      # keep it mapped for as long as the context lives
         self._chk(lib.pwn_tiled_host_sink(self._ctx, arr.ctypes.data, arr.size), "pwn_tiled_host_sink")
+
+    def tiled_gather_root(self, rotate):
+        """pwn_tiled_gather_root: frames gathered on rank 0 (False, the default) or on rank f mod world in turn (True);
+        the same call on every rank, with no frame in flight."""
+        self._chk(lib.pwn_tiled_gather_root(self._ctx, 1 if rotate else 0), "pwn_tiled_gather_root")
 
     def tiled_info(self):
         inf = _lib.TiledInfo()

@@ -22,7 +22,7 @@ _runs = [0]
 
 
 def run_ranks(world, w, h, level, frames, halo, tmp_path, transport="shm", blur=None, hostsink=False, seen=None, balance=None, cuts_at=None,
-              rows=None, extra_env=None):
+              rows=None, extra_env=None, by_rank=None):
     _runs[0] += 1
     idfile = str(tmp_path / ("id_%d" % _runs[0]))          # a fresh file per run: the ranks wait for it to appear
     env = dict(os.environ)
@@ -48,6 +48,8 @@ def run_ranks(world, w, h, level, frames, halo, tmp_path, transport="shm", blur=
         assert p.returncode == 0, e[-3000:]
         outs.append(o)
     hashes = re.findall(r"frame (\d+) fnv64 ([0-9a-f]{16}) redone (\d)", outs[0])
+    if by_rank is not None:                               # rotating gather root: which rank printed which frame
+        by_rank.extend(re.findall(r"frame (\d+) fnv64 ([0-9a-f]{16}) redone (\d)", o) for o in outs)
     if seen is not None:                                  # host sink: what the other ranks saw in the shared frame
         seen.extend([h for _, h in re.findall(r"seen (\d+) fnv64 ([0-9a-f]{16})", o)] for o in outs[1:])
     infos = [json.loads(re.search(r"info (\{.*\})", o).group(1)) for o in outs]
@@ -95,6 +97,39 @@ def test_tiled_frames_are_the_oracles_frames(world, tmp_path, oracle_lib):
             assert all(i["halo_rows"] == int(0.002 * h * 24) + 2 for i in infos)
             # two grouped launches per frame: its halo rows, and (two frames later, or when the run drains) its gather
             assert all(i["groups"] == 2 * frames for i in infos)
+
+
+@pytest.mark.parametrize("world,halo,balance,blur", [(3, -1, 0, 1), (4, 1, 2, 1), (2, 0, None, 1), (3, -1, None, 0)])
+def test_tiled_with_rotating_gather_root(world, halo, balance, blur, tmp_path, oracle_lib):
+    """pwn_tiled_gather_root(PWN_TILED_ROOT_ROTATE): frame k is assembled on rank k mod world (the strips of every frame go to
+    another GPU, so that no rank's links carry every frame).  Every frame is the oracle's, and is handed out by its root and
+    by nobody else -- with the default halo, with a 1-row halo that the taps leave (the frame repeated with whole strips, on
+    its own root) while the cuts move, with whole strips, and without blur (the trace writes a root's own strip straight
+    into the assembled frame)."""
+    w, h, frames = 640, 360, 9
+    want = oracle_hashes(w, h, "pwnfps_level", frames, oracle_lib, blur=blur)
+    by_rank = []
+    _, infos = run_ranks(world, w, h, "pwnfps_level", frames, halo, tmp_path, balance=balance, blur=blur, extra_env={"TILED_ROTATE": "1"}, by_rank=by_rank)
+    assert all(i["gather_root"] == 1 and i["frames"] == frames for i in infos)
+    got = {}
+    for r, lines in enumerate(by_rank):
+        for k, hsh, _ in lines:
+            assert int(k) % world == r, (k, r)                 # only a frame's root hands it out
+            assert int(k) not in got
+            got[int(k)] = hsh
+    assert [got[k] for k in range(frames)] == want
+    if halo == 1:
+        assert all(i["frames_redone"] >= 1 and i["halo_rows"] == 0 for i in infos)
+    if halo == -1 and blur:
+        # what a rank's links carried: its own strip out for the frames it is not the root of, the others' strips in for
+        # those it is (equal strips of 120 / 90 rows here), and the halo rows both ways
+        for i in infos:
+            mine = i["y1"] - i["y0"]
+            roots = len(range(i["rank"], frames, world))
+            H = i["halo_rows"]
+            nb = (1 if i["rank"] > 0 else 0) + (1 if i["rank"] < world - 1 else 0)
+            assert i["bytes_sent"] == (frames - roots) * mine * w * 4 + frames * nb * H * w * 4, i
+            assert i["bytes_received"] == roots * (h - mine) * w * 4 + frames * nb * H * w * 4, i
 
 
 def test_tiled_without_blur_and_uneven_strips(tmp_path, oracle_lib):

@@ -9,7 +9,8 @@ file.  Every frame has its own camera, sec_current and sphere set (tools/tiled_r
 frame that is delivered late or from the wrong buffers shows.  Rank 0 prints one line per frame:
     frame K fnv64 HASH redone R
 and every rank a line `info {...}` (pwn_tiled_info) and per frame `rows K Y0 Y1 COST` (the rows it traced of that frame and
-what they cost).  TILED_BALANCE=k: pwn_tiled_balance(k) (moving cuts); TILED_CUTS_AT="K:c0,c1,..;K2:.." calls
+what they cost).  TILED_ROTATE=1: pwn_tiled_gather_root(ROTATE), the `frame` lines then come from the frame's root, rank K mod
+WORLD.  TILED_BALANCE=k: pwn_tiled_balance(k) (moving cuts); TILED_CUTS_AT="K:c0,c1,..;K2:.." calls
 pwn_tiled_set_cuts in front of frame K.  TILED_HOSTSINK=1: frames are delivered into POSIX shared
 memory by every rank (pwn_tiled_host_sink); the other ranks then print `seen K fnv64 HASH` too."""
 import json
@@ -81,6 +82,8 @@ def main():
         os.close(fd)
         r.tiled_host_sink(mm)
 
+    if os.environ.get("TILED_ROTATE") == "1":
+        r.tiled_gather_root(True)
     if os.environ.get("TILED_BALANCE") is not None:
         r.tiled_balance(int(os.environ["TILED_BALANCE"]))
     cuts_at = {}
@@ -92,7 +95,9 @@ def main():
         fr = r.tiled_wait(host=True)
         assert fr["seq"] == k + 1
         print("rows %d %d %d %d" % (k, fr["y0"], fr["y1"], fr["cost"]), flush=True)
-        if rank == 0:
+        if (rank == 0 and hostsink) or (not hostsink and fr.get("sbuf") is not None):
+            # (without a host sink: the frame's root has it -- rank 0, or rank k mod world with TILED_ROTATE=1)
+            assert hostsink or fr["root"] == rank
             print("frame %d fnv64 %s redone %d" % (k, oracle.fnv64(fr["sbuf"]), int(fr["redone"])), flush=True)
         elif hostsink:
             # with a host sink every rank holds the whole frame when its wait returns
