@@ -28,8 +28,8 @@ hashed and compared with the golden hash of the compiled reference.
 N > 1: the line carries what it takes to read a first multi-GPU run from the driver's output alone --
 `tiling.per_rank` (every rank's trace / blur kernel times, the durations of the two grouped exchanges on the
 comm stream, host enqueue time per frame, rows and cost of its strip), the moving cuts, and `tiling.sweep`: short
-legs in the same run with the trace grid's room for RCCL at 0 / 16 / 64 workgroups, equal strips, one compute
-stream, and whole strips instead of the bounded halo.  `transport` says at top level what carried the data; over
+legs in the same run with the trace grid's room for RCCL at 0 / 16 / 64 workgroups, the gather spread over the
+ranks (`rotating_root`), equal strips, one compute stream, and whole strips instead of the bounded halo.  `transport` says at top level what carried the data; over
 the shared-memory fallback the metric string says that the figure is NOT RCCL over xGMI.
 """
 import argparse
@@ -715,6 +715,15 @@ def main():
             r.tiled_set_reserve(rsv)
             point("reserve_%d" % rsv, "PWN_TILED_RESERVE = %d workgroups of the persistent trace grid left free for the transport's kernels" % rsv)
         r.tiled_set_reserve(reserve0)
+        # the gather spread over the ranks: frame f assembled on rank f mod N (pwn_tiled_gather_root) -- no rank's links carry every
+        # frame; what a consumer on every GPU would get
+        try:
+            r.tiled_gather_root(True)
+            point("rotating_root", "pwn_tiled_gather_root(ROTATE): frame f is gathered on rank f mod N in turn instead of always on rank 0")
+        except Exception as e:                                       # noqa: BLE001
+            sweep["rotating_root"] = {"error": str(e)}
+        finally:
+            r.tiled_gather_root(False)
         bal = tinfo["balance_every"]
         r.tiled_balance(0)
         r.tiled_set_cuts([min(k * tinfo["rows_per_rank"], h) for k in range(world)] + [h])

@@ -152,7 +152,7 @@ class TiledFrames:
     """pwn_tiled_init / _submit / _wait of pwn_tiled.cpp, restated.  Names follow the C code."""
 
     def __init__(self, w, h, backend, device, rank=None, world=None, blur_passes=1, halo_rows=-1, group=None, host_sink=None,
-                 balance_every=None):
+                 balance_every=None, rotate_root=False):
         self.w, self.h = int(w), int(h)
         self.group = group
         if world is None:
@@ -187,7 +187,10 @@ class TiledFrames:
         mk = lambda dt: [torch.zeros((self.h, self.w), dtype=dt, **kw) for _ in range(NSLOT)]   # noqa: E731
         # int32 views of the uint32 BGRA pixels (the transport does not care)
         self.pre, self.out, self.z = mk(torch.int32), mk(torch.int32), mk(torch.float32)
-        self.fin = mk(torch.int32) if rank == 0 else [None] * NSLOT
+        # pwn_tiled_gather_root: frame f is assembled on rank 0, or on rank f mod world in turn
+        self.rotate_root = bool(rotate_root)
+        self.froot = [0] * NSLOT            # ... the root of the frame in that slot
+        self.fin = mk(torch.int32) if (rank == 0 or self.rotate_root) else [None] * NSLOT
         # the two words a rank says about a frame: [0] taps that left its halo, [1] what its strip cost
         self.missw = [torch.zeros(2, dtype=torch.int32, **kw) for _ in range(NSLOT)]
         self.missv = [torch.zeros(2 * world, dtype=torch.int32, **kw) for _ in range(NSLOT)]
@@ -257,13 +260,16 @@ class TiledFrames:
             # no strips: the words go out behind this rank's copy to the host
             self._add_words(s)
             return
-        if self.rank == 0:
-            for r in range(1, self.world):
+        root = self.froot[s]
+        if self.rank == root:
+            for r in range(self.world):
+                if r == root:
+                    continue
                 a, b = self._rows_of(s, r)
                 if b > a:
                     self._recv(self.fin[s][a:b], r, TAG_GATHER)
         elif y1 > y0:
-            self._send(mine[y0:y1], 0, TAG_GATHER)
+            self._send(mine[y0:y1], root, TAG_GATHER)
         self._add_words(s)
 
     def _add_allgather(self, s):
@@ -290,7 +296,7 @@ class TiledFrames:
         s = k % NSLOT
         y0, y1 = self._rows_of(s, self.rank)
         if self.blur_passes:
-            dst = self.fin[s] if (self.rank == 0 and self.host is None) else self.out[s]
+            dst = self.fin[s] if (self.rank == self.froot[s] and self.host is None) else self.out[s]
             if self.fhalo[s]:
                 H = self.fhalo[s]
                 a0 = y0 - H if self.rank > 0 else 0
@@ -308,10 +314,11 @@ class TiledFrames:
         f = self.submitted
         s = f % NSLOT
         self.fhalo[s] = self.halo
+        self.froot[s] = f % self.world if self.rotate_root else 0
         self.fcuts[s] = list(self.cuts)
         y0, y1 = self.cuts[self.rank], self.cuts[self.rank + 1]
         cam = np.ascontiguousarray(cam, np.float32).reshape(16)
-        plane = self.pre[s] if self.blur_passes else (self.fin[s] if (self.rank == 0 and self.host is None) else self.pre[s])
+        plane = self.pre[s] if self.blur_passes else (self.fin[s] if (self.rank == self.froot[s] and self.host is None) else self.pre[s])
         self.missw[s].zero_()
         cost = self.backend.trace_rows(cam, float(sec), y0, y1, plane, self.z[s])
         # (in the C code the trace launch adds up its waves' lifetimes and the frame's blur moves the sum into the
@@ -350,7 +357,8 @@ class TiledFrames:
     # ---- pwn_tiled_wait -------------------------------------------------------------------------
     def wait(self):
         """Oldest frame in flight, on every rank.  Returns (frame, redone): frame = the full frame
-        tensor on rank 0 (valid until three more frames were submitted), None elsewhere; with a host
+        tensor on the frame's root (rank 0, or rank f mod world with rotate_root; valid until three more frames were
+        submitted), None elsewhere; with a host
         sink the frame in the shared host memory, on every rank."""
         if self.delivered >= self.submitted:
             raise RuntimeError("nothing in flight")
@@ -383,7 +391,7 @@ class TiledFrames:
             self._begin()
             self._add_allgather(s)
             self._end()
-            dst = self.fin[s] if (self.rank == 0 and self.host is None) else self.out[s]
+            dst = self.fin[s] if (self.rank == self.froot[s] and self.host is None) else self.out[s]
             self.backend.blur_rows(y0, y1, self.pre[s], self.z[s], dst)
             if self.host is not None:
                 self._copy_strip_to_host(s)            # the strip again, and the words behind it
@@ -404,7 +412,7 @@ class TiledFrames:
         self.info["frames"] += 1
         if self.host is not None:
             return self.host[s], miss                  # on every rank (valid until the second next submit)
-        return (self.fin[s] if self.rank == 0 else None), miss
+        return (self.fin[s] if self.rank == self.froot[s] else None), miss
 
     def to_host(self, t):
         """uint32 numpy copy of a frame tensor."""

@@ -65,7 +65,7 @@ class OracleStripBackend:
         self.o.L.pwno_blur_rows(self.w, self.h, y0, y1, 1, pre.data_ptr(), z.data_ptr(), out.data_ptr())
 
 
-def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=None, balance=None, cuts_at=None):
+def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=None, balance=None, cuts_at=None, rotate=False):
     import sys
     sys.path.insert(0, HERE)
     sys.path.insert(0, ROOT)
@@ -86,7 +86,7 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=Non
             # pwn_tiled_host_sink: one file mapped by every rank plays the shared host memory
             sink = np.memmap(sink_path, dtype=np.uint32, mode="r+", shape=(4, h, w))
         fr = TiledFrames(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur, halo_rows=halo, host_sink=sink,
-                         balance_every=balance)
+                         balance_every=balance, rotate_root=rotate)
         assert (fr.y0, fr.y1) == strip_range(h, world, rank)
         halo0 = fr.halo
         got = []
@@ -98,8 +98,9 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=Non
             if sink is not None:
                 got.append((oracle.fnv64(np.array(frame)), redone))        # every rank sees the whole frame
                 return
-            assert (frame is not None) == (rank == 0)
-            got.append((oracle.fnv64(fr.to_host(frame)) if rank == 0 else None, redone))
+            root = k % world if rotate else 0                          # pwn_tiled_gather_root
+            assert (frame is not None) == (rank == root)
+            got.append((oracle.fnv64(fr.to_host(frame)) if rank == root else None, redone))
         for k in range(frames):
             cam, sec, sph = tiled_rank.scene(k, base, spawn)
             be.o.set_spheres(sph)
@@ -127,11 +128,11 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=Non
         dist.destroy_process_group()
 
 
-def _run(world, w, h, level, frames, blur, halo, sink_path=None, balance=None, cuts_at=None):
+def _run(world, w, h, level, frames, blur, halo, sink_path=None, balance=None, cuts_at=None, rotate=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, level, frames, blur, halo, q, sink_path, balance, cuts_at)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, level, frames, blur, halo, q, sink_path, balance, cuts_at, rotate)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -190,6 +191,30 @@ def test_tiled_frames_are_the_oracles_frames(world, blur, halo):
         # a strip's neighbours send it 13 rows each, rank 0 takes in every other strip
         per = res[0][3]["bytes_received"] / (frames + 1)
         assert per >= (h - 32) * w * 4 if world == 8 else per > 0
+
+
+@pytest.mark.parametrize("world,blur,halo,balance", [(3, 1, -1, 0), (8, 1, 1, 2), (2, 0, -1, None), (4, 1, 0, None)])
+def test_rotating_gather_root(world, blur, halo, balance):
+    """pwn_tiled_gather_root(ROTATE) restated: frame k is assembled on rank k mod world and handed out there and nowhere
+    else; every frame is the oracle's whether the halo holds, is left (the repeat lands on the frame's own root), or
+    whole strips travel, with and without blur, while the cuts move.  With the default halo and fixed cuts a rank
+    receives exactly the other ranks' strips of the frames it is the root of (plus its neighbours' halo rows)."""
+    w, h, frames = 320, 240, 8
+    want = _want(w, h, "pwnfps_level", frames + 1, blur)
+    res = _run(world, w, h, "pwnfps_level", frames, blur, halo, balance=balance, rotate=True)
+    for k in range(frames + 1):
+        for r in range(world):
+            assert res[r][0][k][0] == (want[k] if r == k % world else None), (k, r)
+    assert len({tuple(x[1] for x in res[r][0]) for r in range(world)}) == 1        # every rank made the same decisions
+    if halo == -1 and blur:
+        for r in range(world):
+            info = res[r][3]
+            mine = info["cuts_seen"][0][r + 1] - info["cuts_seen"][0][r]
+            roots = len(range(r, frames + 1, world))
+            nb = (1 if r > 0 else 0) + (1 if r < world - 1 else 0)
+            words = (frames + 1) * (world - 1) * 2
+            assert info["bytes_received"] == (roots * (h - mine) * w + (frames + 1) * nb * 13 * w + words) * 4, (r, info)
+            assert info["bytes_sent"] == ((frames + 1 - roots) * mine * w + (frames + 1) * nb * 13 * w + words) * 4, (r, info)
 
 
 def test_uneven_strips_and_a_strip_shorter_than_the_halo():

@@ -57,7 +57,7 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     assert d["roofline"]["pixels_per_launch"] in [rows * size[0] for rows in pr["rows"]]
     # the in-run sweep: room left for the transport's kernels, equal strips, one compute stream, whole strips
     sw = t["sweep"]
-    assert set(sw) - {"rank0_tall"} == {"reserve_0", "reserve_16", "reserve_64", "equal_strips", "one_stream", "whole_strips"}
+    assert set(sw) - {"rank0_tall"} == {"reserve_0", "reserve_16", "reserve_64", "rotating_root", "equal_strips", "one_stream", "whole_strips"}
     assert ("rank0_tall" in sw) == (world > 2)
     for name, pt in sw.items():
         assert pt["value"] > 0 and pt["ms_per_step"] > 0 and len(pt["trace_ms"]) == world and len(pt["rows"]) == world, name
