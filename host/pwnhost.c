@@ -35,6 +35,7 @@
  * presents the frames.  -H ROWS sets the halo (default -1 = depth 24, 0 = whole strips).
  * -M 1: the frames are delivered to the host by every rank (pwn_tiled_host_sink): one frame buffer in POSIX
  * shared memory, every rank copies its strip into it over its own PCIe link, nothing is gathered to rank 0.
+ * -G 1: the gather's root rotates over the ranks (pwn_tiled_gather_root): frame f is assembled, and presented, on rank f mod WORLD.
  * -q SLOTS (2..4) keeps that many frames in flight (pwn_submit_frame /
  * pwn_wait_frame): the frame and its upscaled surface arrive in the library's
  * pinned host buffers while the next frame's kernels run; frame f is presented
@@ -176,6 +177,7 @@ int main(int argc, char **argv)
 	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL, *luafile = NULL, *keyfile = NULL;
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
 	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL, window = 0, frames_given = 0, hostsink = 0;
+	int rotate_root = 0;
 	int rank_given = 0, device_given = 0;
 	const char *idfile = NULL, *nonce = "";
 	const time_t started = time(NULL);
@@ -209,6 +211,7 @@ int main(int argc, char **argv)
 			case 'N': nonce = argv[++i]; break;
 			case 'H': halo = atoi(argv[++i]); break;
 			case 'M': hostsink = atoi(argv[++i]); break;
+			case 'G': rotate_root = atoi(argv[++i]); break;
 			case 'T': transport = strcmp(argv[++i], "shm") == 0 ? PWN_TRANSPORT_SHM : PWN_TRANSPORT_RCCL; break;
 			default: fprintf(stderr, "unknown option %s\n", argv[i]); return 2;
 		}
@@ -217,7 +220,7 @@ int main(int argc, char **argv)
 	{
 		fprintf(stderr, "usage: pwnhost level.txt [-s spheres.txt | -g game_objects.txt] [-w W] [-h H] [-x SCALE] "
 			"[-n FRAMES] [-t SEC_PER_FRAME] [-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE] [-v 1] [-q SLOTS]\n"
-			"       [-W WORLD -R RANK -I IDFILE [-N LAUNCH_NONCE] [-T rccl|shm] [-H HALO_ROWS]]\n");
+			"       [-W WORLD -R RANK -I IDFILE [-N LAUNCH_NONCE] [-T rccl|shm] [-H HALO_ROWS] [-M 1 | -G 1]]\n");
 		return 2;
 	}
 	/* -W WORLD without -R: this process starts the other ranks itself (fork, before anything touches a GPU): rank r
@@ -394,6 +397,7 @@ int main(int argc, char **argv)
 			if(host_frames == MAP_FAILED) { fprintf(stderr, "rank %d: mmap %s\n", rank, shm_name); pwn_destroy(ctx); return 1; }
 			CHK(pwn_tiled_host_sink(ctx, host_frames, host_bytes));
 		}
+		if(rotate_root && !hostsink) CHK(pwn_tiled_gather_root(ctx, PWN_TILED_ROOT_ROTATE));
 		if(fixed_dt < 0.0f) fixed_dt = 0.0f;
 		pwn_tiled_frame tf;
 		memset(&tf, 0, sizeof(tf));
@@ -410,7 +414,7 @@ int main(int argc, char **argv)
 			if(f >= 2)
 			{
 				CHK(pwn_tiled_wait(ctx, PWN_TILED_HOST, &tf));
-				if((rank == 0 || hostsink) && verbose)
+				if(tf.sbuf != NULL && verbose)                 /* (the frame's root -- rank 0 unless -G 1 --, or every rank with a host sink) */
 					printf("frame %d sec %.9g fnv64 %016llx\n", f - 2, (double)(fixed_dt * (float)(f - 2)), (unsigned long long)fnv64(tf.sbuf, npix));
 				if(f == 2) t1 = now_s();
 			}
@@ -430,7 +434,7 @@ int main(int argc, char **argv)
 		printf("rank %d of %d: rows [%d,%d) now (the cuts moved %llu times; %d rows to begin with), halo %d rows, %llu frames (%llu repeated with whole strips), %llu grouped exchanges, sent %.1f MB, received %.1f MB\n",
 			inf.rank, inf.world, inf.y0, inf.y1, (unsigned long long)inf.recuts, inf.rows_per_rank, inf.halo_rows, (unsigned long long)inf.frames,
 			(unsigned long long)inf.frames_redone, (unsigned long long)inf.groups, (double)inf.bytes_sent / 1e6, (double)inf.bytes_received / 1e6);
-		if(rank == 0)
+		if(hostsink ? rank == 0 : tf.sbuf != NULL)         /* whoever holds the last frame presents it */
 		{
 			CHK(pwn_screen_upscale(ctx, tf.sbuf, rscale, surface.pitch, surface.pixels));      /* main.c:108 */
 			printf("frame %dx%d x%d: sbuf fnv64 %016llx, surface fnv64 %016llx\n", rwidth, rheight, rscale,

@@ -145,6 +145,17 @@ def test_host_row_tiled_over_three_processes(host_bin, tmp_path):
             assert re.search(r"surface fnv64 ([0-9a-f]{16})", o.decode()).group(1) == sa
 
 
+    # -G 1: the gather's root rotates (pwn_tiled_gather_root): frame f is presented by rank f mod 3, the last one (7) by rank 1
+    procs = [subprocess.Popen(base + ["-W", "3", "-R", str(r), "-I", idfile, "-N", "launch3", "-T", "shm", "-G", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+             for r in range(3)]
+    for r, p in enumerate(procs):
+        o, e = p.communicate(timeout=300)
+        assert p.returncode == 0, e.decode()
+        assert re.findall(r"frame (\d+) sec \S+ fnv64 ([0-9a-f]{16})", o.decode()) == [x for x in fa if int(x[0]) % 3 == r], r
+        assert (re.search(r"surface fnv64 ([0-9a-f]{16})", o.decode()) is not None) == (r == 1)
+        if r == 1:
+            assert re.search(r"surface fnv64 ([0-9a-f]{16})", o.decode()).group(1) == sa
+
     # -W 3 alone: the host forks the ranks itself (all on device 0 here)
     p = subprocess.run(base[:-2] + ["-W", "3", "-d", "0", "-T", "shm", "-M", "1"], capture_output=True, timeout=300)
     assert p.returncode == 0, p.stderr.decode()
