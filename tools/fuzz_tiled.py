@@ -62,8 +62,11 @@ for run in range(runs):
     env["TILED_BALANCE"] = "2"
     if cuts_at:
         env["TILED_CUTS_AT"] = ";".join("%d:%s" % (k, ",".join(str(v) for v in c)) for k, c in cuts_at.items())
+    rotate = (not hostsink) and bool(rng.integers(0, 2))      # pwn_tiled_gather_root(ROTATE): frame k comes from rank k mod world
     if hostsink:
         env["TILED_HOSTSINK"] = "1"
+    if rotate:
+        env["TILED_ROTATE"] = "1"
     with tempfile.TemporaryDirectory() as td:
         idfile = os.path.join(td, "id_%d" % run)
         procs = [subprocess.Popen([sys.executable, RANK, str(r), str(world), idfile, "shm", str(w), str(h), level, str(frames), str(halo)],
@@ -81,7 +84,14 @@ for run in range(runs):
                 ok = False
                 print("run %d: a rank failed: %s" % (run, e[-500:]))
             outs.append(o)
-    got = [hh for _, hh in re.findall(r"frame (\d+) fnv64 ([0-9a-f]{16})", outs[0])]
+    if rotate:
+        by = {}
+        for r, o in enumerate(outs):
+            for k, hh in re.findall(r"frame (\d+) fnv64 ([0-9a-f]{16})", o):
+                by[int(k)] = hh if int(k) % world == r else "from the wrong rank"
+        got = [by.get(k, "") for k in range(frames)]
+    else:
+        got = [hh for _, hh in re.findall(r"frame (\d+) fnv64 ([0-9a-f]{16})", outs[0])]
     mism = [k for k in range(frames) if k >= len(got) or got[k] != want[k]]
     seen_bad = 0
     if hostsink:
@@ -94,7 +104,7 @@ for run in range(runs):
         bad += 1
         print("MISMATCH run %d: world %d %dx%d %s halo %d sink %d: frames %s, other ranks' views %d" % (run, world, w, h, level, halo, hostsink, mism[:8], seen_bad))
     else:
-        print("run %d ok: world %d %dx%d %s halo %d sink %d, %d frames, %d cuts by hand, the cuts moved %s times, %s frames repeated" % (
-            run, world, w, h, level, halo, hostsink, frames, len(cuts_at), info.get("recuts"), info.get("frames_redone")), flush=True)
+        print("run %d ok: world %d %dx%d %s halo %d sink %d rotating root %d, %d frames, %d cuts by hand, the cuts moved %s times, %s frames repeated" % (
+            run, world, w, h, level, halo, hostsink, int(rotate), frames, len(cuts_at), info.get("recuts"), info.get("frames_redone")), flush=True)
 print("fuzz_tiled: %d runs, %d frames, %d bad runs (seed %d)" % (runs, frames_done, bad, seed))
 sys.exit(1 if bad else 0)
