@@ -131,10 +131,10 @@ pwn_blur_kernel(pwn_blur_params P)
 #endif
 #define BLUR_LW (BLUR_TW + 2 * BLUR_HALO)          // staged columns
 #define BLUR_LH (BLUR_TH + 2 * BLUR_HALO)          // staged rows
-#define BLUR_PITCH (BLUR_LW + 4)                   // words; +4 keeps rows 16-B aligned and off one bank
+#define BLUR_PITCH (BLUR_LW + (BATCH == 2 ? 0 : 4)) // words; +4 keeps rows 16-B aligned and off one bank (direct-to-LDS staging: rows back to back)
 #define BLUR_THREADS (BLUR_TW / 4 * BLUR_TH)       // one thread per 4-pixel group
 
-template<bool CHECK, int BLUR_TW, int BLUR_TH, bool BATCH>
+template<bool CHECK, int BLUR_TW, int BLUR_TH, int BATCH>
 __global__ void __launch_bounds__(BLUR_THREADS)
 pwn_blur_tiled_kernel(pwn_blur_params P)
 {
@@ -159,8 +159,9 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	const bool mine = g < P.groups && cy < P.y1;
 	uint2 ac;
 	float4 zv;
+	constexpr int NV = BLUR_LH * (BLUR_LW / 4);                  // uint4s of the staged rectangle
 	// stage: uint4 = 4 pixels; w % 4 == 0 and lx0 % 4 == 0, so a uint4 is inside the frame or outside
-	if constexpr(!BATCH)
+	if constexpr(BATCH == 0)
 	{
 		for(int i = threadIdx.x; i < BLUR_LH * (BLUR_LW / 4); i += BLUR_THREADS)
 		{
@@ -174,6 +175,38 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 		ac = P.skip[g];
 		zv = *(const float4 *)(P.zbuf + (size_t)cy * (size_t)P.w + (size_t)(g * 4));
 	}
+	else if constexpr(BATCH == 2)
+	{
+		// (sweep builds only: measured, not shipped -- the launch by itself is as fast as with the loads through registers, the
+		// frame rate on two streams 5.5 % LOWER at 4K, profiles/r3_blur_sweep.txt)
+		// Staging without registers: global_load_lds_dwordx4 (gfx950) writes a wave's 64 x 16 bytes straight into 1 KB of LDS,
+		// lane after lane from M0's base, from per-lane global addresses -- the tile's rows lie back to back for it (pitch =
+		// the staged width), uint4 number i of the tile comes from lane i % 64 of load i / 64.  Addresses are clamped into
+		// the frame; what lies outside is loaded from there and never read (tap coordinates are clamped into the frame).
+		const int gq = mine ? g : 0, cyq = mine ? cy : P.y0;
+		ac = P.skip[gq];
+		zv = *(const float4 *)(P.zbuf + (size_t)cyq * (size_t)P.w + (size_t)(gq * 4));
+		constexpr int NL = (NV + 63) / 64;                         // wave-loads in all
+		constexpr int NW = BLUR_THREADS / 64;
+		const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+#pragma unroll
+		for(int k = 0; k < (NL + NW - 1) / NW; k++)
+		{
+			const int l = wave + k * NW;                           // wave-uniform
+			if(l < NL)
+			{
+				const int i = min(l * 64 + lane, NV - 1);
+				const int row = i / (BLUR_LW / 4), c4 = i - row * (BLUR_LW / 4);
+				const int gyc = min(max(ly0 + row, 0), P.h - 1), gxc = min(max(lx0 + c4 * 4, 0), P.w - 4);
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(P.pre + (size_t)gyc * (size_t)P.w + (size_t)gxc),
+					(__attribute__((address_space(3))) void *)(tile + l * 256), 16, 0, 0);
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		asm volatile("" : "+v"(ac.x), "+v"(ac.y), "+v"(zv.x), "+v"(zv.y), "+v"(zv.z), "+v"(zv.w));
+		__syncthreads();
+		if(!mine) return;
+	}
 	else
 	{
 		// The shipped form: (1) the thread's own two loads from HBM (skip-ahead constants, depths) are asked for first and
@@ -185,7 +218,6 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 		ac = P.skip[gq];
 		zv = *(const float4 *)(P.zbuf + (size_t)cyq * (size_t)P.w + (size_t)(gq * 4));
 		typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-		constexpr int NV = BLUR_LH * (BLUR_LW / 4);
 		constexpr int NT = (NV + BLUR_THREADS - 1) / BLUR_THREADS;
 		static_assert(NT >= 1 && NT <= 8, "the barrier below names its operands");
 		u32x4 r[NT];
@@ -279,11 +311,12 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	if(CHECK) { if(missed) atomicAdd(P.miss, 1u); }
 }
 
-template<bool CHECK, int TW, int TH, bool BATCH>
+template<bool CHECK, int TW, int TH, int BATCH>
 static hipError_t launch_blur_variant(const pwn_blur_params *P, hipStream_t stream)
 {
 	const int BLUR_TW = TW, BLUR_TH = TH;
-	const size_t lds = (size_t)BLUR_PITCH * BLUR_LH * sizeof(uint32_t);
+	// (direct-to-LDS staging writes whole 1 KB pieces: room for the last one)
+	const size_t lds = BATCH == 2 ? ((size_t)BLUR_LH * (BLUR_LW / 4) + 63) / 64 * 1024 : (size_t)BLUR_PITCH * BLUR_LH * sizeof(uint32_t);
 	static bool lds_mark[64];
 	static std::mutex lds_lock;      // contexts of several threads share the per-function attribute
 	int dev = 0;
@@ -304,7 +337,7 @@ static hipError_t launch_blur_variant(const pwn_blur_params *P, hipStream_t stre
 	return hipGetLastError();
 }
 
-template<int TW, int TH, bool BATCH>
+template<int TW, int TH, int BATCH>
 static hipError_t launch_blur_check(const pwn_blur_params *P, hipStream_t stream)
 {
 	return P->miss != NULL ? launch_blur_variant<true, TW, TH, BATCH>(P, stream) : launch_blur_variant<false, TW, TH, BATCH>(P, stream);
@@ -319,10 +352,13 @@ extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stre
 	return hipGetLastError();
 #else
 	// tile shape (tile_w x tile_h output pixels per workgroup) and staging form: chosen by pwn_i_launch_blur
-	const int key = P->tile_w * 1000 + P->tile_h * 10 + (P->batch ? 1 : 0);
+	const int key = P->tile_w * 1000 + P->tile_h * 10 + P->batch;
 	switch(key)
 	{
 #ifdef PWN_BLUR_SWEEP
+		case 128162: return launch_blur_check<128, 16, 2>(P, stream);
+		case 32322: return launch_blur_check<32, 32, 2>(P, stream);
+		case 64322: return launch_blur_check<64, 32, 2>(P, stream);
 		case 128320: return launch_blur_check<128, 32, false>(P, stream);
 		case 128321: return launch_blur_check<128, 32, true>(P, stream);
 		case 128160: return launch_blur_check<128, 16, false>(P, stream);

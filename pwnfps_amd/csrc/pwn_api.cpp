@@ -710,7 +710,7 @@ int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const f
 		if(c->w < 2560) { B.tile_w = 128; B.tile_h = 16; }
 		if(c->dbg_blur_th > 0) B.tile_h = c->dbg_blur_th;          // (a shape without an instantiation: the launch fails with hipErrorInvalidValue)
 		if(c->dbg_blur_tw > 0) B.tile_w = c->dbg_blur_tw;
-		if(c->dbg_blur_batch >= 0) B.batch = c->dbg_blur_batch ? 1 : 0;
+		if(c->dbg_blur_batch >= 0) B.batch = c->dbg_blur_batch;
 	}
 	HIPCHK(c, pwn_launch_blur(&B, stream));
 	return PWN_OK;
