@@ -283,7 +283,21 @@ def test_host_sink_argument_checks_and_one_rank(oracle_lib, cases):
     with pytest.raises(PwnError) as e:
         r.tiled_host_sink(frames)
     assert e.value.code == -8
+    # pwn_tiled_gather_root: not with a frame in flight, not with a mode the header does not name; with one rank every
+    # frame's root is rank 0 either way
+    with pytest.raises(PwnError) as e:
+        r.tiled_gather_root(True)
+    assert e.value.code == -8
     r.tiled_wait()
+    assert pwnfps_amd.render.lib.pwn_tiled_gather_root(r._ctx, 7) == -1
+    r.tiled_gather_root(True)
+    for k in range(3):
+        r.tiled_submit(cam, c["sec"])
+        fr = r.tiled_wait(host=True)
+        assert fr["root"] == 0 and oracle_lib.fnv64(fr["sbuf"]) == c["post"]
+    assert r.tiled_info()["gather_root"] == 1
+    r.tiled_gather_root(False)
+    assert r.tiled_info()["gather_root"] == 0
     r.tiled_shutdown()
     r.close()
 
