@@ -320,6 +320,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prepare", choices=("early", "late"), default="early",
                     help="set_objects of a frame before (early) or after (late) the host waits for a free slot")
+    ap.add_argument("--trace-room", type=int, default=None, help="PWN_OPT_TRACE_ROOM (default: the library's, -1 = it measures)")
     ap.add_argument("--one-stream", action="store_true",
                     help="N = 1: PWN_OPT_FRAME_OVERLAP 0 for the whole run -- every launch by itself, for rocprofv3 --kernel-trace runs whose "
                          "average kernel durations are to be compared with roofline.avg_launch_ms")
@@ -363,6 +364,8 @@ def main():
         spheres = np.load(os.path.join(GOLD, "levels", args.level + "_spheres.npy"))
 
     r = pwnfps_amd.Renderer(w, h, device=local)
+    if args.trace_room is not None:
+        r.set_trace_room(args.trace_room)
     r.level_load(level_file)
     r.set_objects(spheres)
     r.set_blur_passes(args.blur)
@@ -542,6 +545,7 @@ def main():
         # microseconds of pipeline each: the headline leg records none, the roofline leg below times solo launches
         r.set_frame_timing(0)
     dt, block_s = leg(args.warmup, args.min_time)
+    room_state = r.trace_room_state()          # PWN_OPT_TRACE_ROOM as the headline leg left it
     roofline_leg = None
     if world == 1 and overlap_on:
         # ---- the roofline's launch duration: the same loop on ONE compute stream, every time_every-th frame between HIP
@@ -629,6 +633,7 @@ def main():
                                    "%dx%d, POSTPROC_BLUR=%d, one frame per step" % (w, h, args.blur),
                        "level": args.level, "width": w, "height": h, "blur_passes": args.blur,
                        "parallelism": par,
+                       "trace_room": dict(room_state, what="PWN_OPT_TRACE_ROOM: workgroups the persistent trace grid leaves free for the other stream's kernels; option -1 = the library compares 0 with one per CU on windows of delivered frames and keeps the faster"),
                        "host_loop": ("set_objects(i) / wait for a free slot / submit(i)" if args.prepare == "early"
                                      else "wait for a free slot / set_objects(i) / submit(i)") + ", every frame re-bins and re-uploads the spheres",
                        "frames_repeated_with_whole_strips": int(redone) if world > 1 else 0},

@@ -107,6 +107,12 @@ typedef struct pwn_stats
                                   A frame counted (PWN_OPT_COUNTERS) or wave-logged runs on one stream: one set of counters.
                                   The second stream is created at another priority level than the first so that it gets a
                                   hardware queue of its own.  The row tiling reads the option at pwn_tiled_init. */
+#define PWN_OPT_TRACE_ROOM 8   /* frames on two compute streams (PWN_OPT_FRAME_OVERLAP, and the row tiling): workgroups the persistent
+                                  trace grid leaves free so that the other stream's kernels find room on every CU beside it
+                                  instead of waiting for its end.  -1 (default): the library measures -- windows of delivered
+                                  frames with no room and with one workgroup per CU, the better kept for ~500 frames, then
+                                  again (the answer depends on the scene: +3.5 % at 4K on level.txt, -3 % on a hall of
+                                  mirrors); >= 0: that many, always.  Results never depend on it. */
 #define PWN_OPT_FRAME_TIMING 5 /* frames in flight: record HIP events around the trace and blur kernels of every N-th
                                   frame (pwn_frame.timed, .trace_ms ...); 1 = every frame (default), 0 = never.  An event
                                   between two kernels costs a few microseconds of pipeline */
@@ -120,6 +126,9 @@ typedef struct pwn_stats
 int pwn_init(pwn_ctx **out, int device, int width, int height);
 void pwn_destroy(pwn_ctx *ctx);
 int pwn_set_option(pwn_ctx *ctx, int option, int value);
+/* PWN_OPT_TRACE_ROOM as it stands: out[0] the option's value (-1 = measuring), out[1] the workgroups the next two-stream trace launch
+   leaves free, out[2] how often the two settings were compared, out[3] how often the setting changed */
+int pwn_trace_room_state(pwn_ctx *ctx, int out[4]);
 const char *pwn_strerror(int code);
 const char *pwn_last_error(pwn_ctx *ctx);
 

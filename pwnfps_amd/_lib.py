@@ -13,6 +13,7 @@ PWN_OK, PWN_EINVAL, PWN_ENODEV, PWN_ENOMEM, PWN_EIO, PWN_EHIP, PWN_ENOLEVEL, PWN
 PWN_EBUSY, PWN_ENOTSUP = -8, -9
 PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER, PWN_OPT_REFILL_LIMIT, PWN_OPT_FRAME_TIMING, PWN_OPT_WAVE_LOG = 1, 2, 3, 4, 5, 6
 PWN_OPT_FRAME_OVERLAP = 7
+PWN_OPT_TRACE_ROOM = 8
 PWN_SCHED_UNITS, PWN_SCHED_REFILL = 0, 1
 PWN_MAX_SLOTS = 4
 PWN_FRAME_SBUF, PWN_FRAME_ZBUF, PWN_FRAME_SURFACE = 1, 2, 4
@@ -70,6 +71,7 @@ ABI = [
     ("pwn_init", _i, [C.POINTER(_vp), _i, _i, _i]),
     ("pwn_destroy", None, [_vp]),
     ("pwn_set_option", _i, [_vp, _i, _i]),
+    ("pwn_trace_room_state", _i, [_vp, _vp]),
     ("pwn_strerror", C.c_char_p, [_i]),
     ("pwn_last_error", C.c_char_p, [_vp]),
     ("pwn_level_load", _i, [_vp, C.c_char_p]),

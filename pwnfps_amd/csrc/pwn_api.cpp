@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <new>
 #include <vector>
 
@@ -80,6 +81,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	for(int i = 0; i < PWN_NSTAGE; i++) { c->h_stage[i] = NULL; c->ev_stage[i] = NULL; c->stage_used[i] = false; }
 	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0;
 	c->trace_clear_word = NULL; c->trace_cost_word = NULL; c->trace_tables_event = NULL; c->grid_reserve = 0;
+	memset(&c->room, 0, sizeof(c->room)); c->room.mode = -1; c->launch_room = 0;
+	if(const char *e = getenv("PWN_TRACE_ROOM")) if(*e) c->room.mode = atoi(e) < 0 ? -1 : atoi(e);      // (the option's default for every context of a process)
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 8; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
 	c->stream = NULL; c->copy_stream = NULL; c->stream2 = NULL; c->d_pre2 = NULL;
@@ -204,6 +207,48 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 	delete c;
 }
 
+// ---- PWN_OPT_TRACE_ROOM (pwn_internal.h) ----
+#define ROOM_WINDOW 24        // delivered frames timed per setting
+#define ROOM_SKIP 6           // ... after this many that are not (frames in flight were launched with the old setting)
+#define ROOM_HOLD 480         // frames the better setting is kept before the next look
+int pwn_room_for_launch(pwn_ctx *c)
+{
+	if(c->room.mode >= 0) return c->room.mode;
+	return c->room.arm ? c->num_cus : 0;
+}
+
+void pwn_room_frame_done(pwn_ctx *c)
+{
+	pwn_room_ctl &r = c->room;
+	if(r.mode >= 0) return;
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	const double now = (double)ts.tv_sec + (double)ts.tv_nsec * 1e-9, dt = now - r.t_prev;
+	const bool first = r.t_prev == 0.0;
+	r.t_prev = now;
+	if(first) { r.skip = ROOM_SKIP; return; }
+	if(r.hold > 0) { if(--r.hold == 0) { r.arm = 1 - r.best; r.skip = ROOM_SKIP; r.sum[0] = r.sum[1] = 0.0; r.cnt[0] = r.cnt[1] = 0; r.switches++; } return; }
+	if(r.skip > 0) { r.skip--; return; }
+	// (a host that stops between frames -- a debugger, a vsync -- is not the GPU's time: intervals far above the window's mean are left out)
+	if(r.cnt[r.arm] >= 4 && dt > 4.0 * r.sum[r.arm] / r.cnt[r.arm]) return;
+	r.sum[r.arm] += dt; r.cnt[r.arm]++;
+	if(r.cnt[r.arm] < ROOM_WINDOW) return;
+	if(r.cnt[1 - r.arm] < ROOM_WINDOW) { r.arm = 1 - r.arm; r.skip = ROOM_SKIP; r.switches++; return; }
+	// both windows are in: the better one (the one in use stays on a tie within 0.5 %)
+	const double m0 = r.sum[0] / r.cnt[0], m1 = r.sum[1] / r.cnt[1];
+	int best = m1 < m0 ? 1 : 0;
+	if(r.looks > 0 && best != r.best && (best ? m1 > 0.995 * m0 : m0 > 0.995 * m1)) best = r.best;
+	if(best != r.arm) { r.skip = ROOM_SKIP; r.switches++; }
+	r.best = best; r.arm = best; r.hold = ROOM_HOLD; r.looks++;
+}
+
+extern "C" int pwn_trace_room_state(pwn_ctx *c, int out[4])
+{
+	if(c == NULL || out == NULL) return PWN_EINVAL;
+	out[0] = c->room.mode; out[1] = pwn_room_for_launch(c); out[2] = (int)c->room.looks; out[3] = (int)c->room.switches;
+	return PWN_OK;
+}
+
 extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 {
 	if(c == NULL) return PWN_EINVAL;
@@ -221,6 +266,7 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 		case PWN_OPT_WAVE_LOG: c->wave_log_on = value ? 1 : 0; return PWN_OK;
 		case PWN_OPT_FRAME_TIMING: if(value < 0) return PWN_EINVAL; c->frame_timing = value; return PWN_OK;
 		case PWN_OPT_REFILL_LIMIT: if(value < 1 || value > 64000) return PWN_EINVAL; c->refill_limit = value; return PWN_OK;
+		case PWN_OPT_TRACE_ROOM: if(value < -1 || value > 4096) return PWN_EINVAL; memset(&c->room, 0, sizeof(c->room)); c->room.mode = value; return PWN_OK;
 		case PWN_OPT_FRAME_OVERLAP:
 			for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
 			c->frame_overlap = value ? 1 : 0; return PWN_OK;
@@ -646,7 +692,13 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	// row tiling over RCCL: a persistent grid that fills every CU leaves RCCL's send / recv kernels no registers
 	// to start with (5 waves x 96 VGPRs of 512 per SIMD), and the exchange would only run in the gaps between the
 	// kernels; a few workgroups fewer leave room on some CUs (pwn_tiled.cpp sets the number)
-	if(c->grid_reserve > 0 && grid > 2 * c->grid_reserve) grid -= c->grid_reserve;
+	// ... and frames on two compute streams: room for the other stream's kernels (PWN_OPT_TRACE_ROOM; the caller says how much)
+	{
+		if(c->room.mode >= 0) c->launch_room = c->room.mode;        // (a host that set a number gets it for every launch)
+		const int reserve = c->grid_reserve > c->launch_room ? c->grid_reserve : c->launch_room;
+		c->launch_room = 0;
+		if(reserve > 0 && grid > 2 * reserve) grid -= reserve;
+	}
 	// fewer units than resident waves (a 320 x 240 frame is 1200 units for 5120 waves): one unit per wave, a
 	// workgroup per four of them -- a workgroup whose waves find nothing still copies the tables into LDS
 	{
@@ -896,6 +948,7 @@ extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int 
 	// the next frame's kernels reuse the context's d_pre / d_out
 	uint32_t *cur = c->blur_passes > 0 ? pre : sl.d_out;
 	c->trace_tables_event = sl.ev_k[2];        // recorded below, behind the frame's last kernel
+	c->launch_room = overlap ? pwn_room_for_launch(c) : 0;
 	int rc = pwn_i_launch_trace(c, cam, sec, 0, c->h, cur, sl.d_z, s);
 	if(rc != PWN_OK) return rc;
 	if(timing) HIPCHK(c, hipEventRecord(sl.ev_k[1], s));
@@ -925,7 +978,7 @@ extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int 
 				hipMemcpyDeviceToHost, c->copy_stream));
 		HIPCHK(c, hipEventRecord(sl.ev_done, c->copy_stream));
 	}
-	sl.in_flight = true; sl.sec = sec; sl.seq = ++c->frame_seq; sl.timed = timing;
+	sl.in_flight = true; sl.sec = sec; sl.seq = ++c->frame_seq; sl.timed = timing; sl.beside = overlap;
 	return PWN_OK;
 }
 
@@ -959,6 +1012,7 @@ extern "C" int pwn_wait_frame(pwn_ctx *c, int slot, pwn_frame *out)
 	{
 		HIPCHK(c, hipEventSynchronize(c->frame_flags != 0 ? sl.ev_done : sl.ev_k[2]));
 		sl.in_flight = false;
+		if(sl.beside) pwn_room_frame_done(c);          // PWN_OPT_TRACE_ROOM: one more delivered frame of a two-stream sequence
 	}
 	if(out != NULL)
 	{

@@ -55,10 +55,27 @@ struct pwn_slot
 	uint32_t *h_sbuf; float *h_zbuf; uint32_t *h_surface;  // pinned host copies handed to the caller
 	hipEvent_t ev_k[4];                                    // compute stream: start, after trace, after blur, after sink
 	hipEvent_t ev_done;                                    // copy stream: this frame's host buffers are complete
-	bool in_flight, timed;
+	bool in_flight, timed, beside;                         // (beside: launched while frames alternate between two streams)
 	float sec;
 	uint64_t seq;
 };
+
+// PWN_OPT_TRACE_ROOM: how many workgroups the persistent trace grid leaves free while frames alternate between two compute
+// streams, so that the OTHER stream's kernels (the previous frame's blur, the next frame's grid) find room on every CU instead
+// of waiting for this grid's end.  Worth +3.5 % at 4K and -11 % kernel time on the strips of an 8-way tiling on level.txt,
+// and -3 % on synth256: so the default measures -- pwn_room_frame_done() is told of every delivered frame,
+// times a window of frames with no room and one with a workgroup per CU, keeps the better for a while, and looks again.
+struct pwn_room_ctl
+{
+	int mode;                 // -1: measure (default); >= 0: that many workgroups, always
+	int arm, best;            // 0 = no room, 1 = one workgroup per CU
+	int skip, hold;           // delivered frames not counted after a switch; frames left before the next look
+	double sum[2]; int cnt[2];
+	double t_prev;
+	unsigned long long looks, switches;
+};
+int pwn_room_for_launch(struct pwn_ctx *c);          // workgroups to leave free for a launch on one of two alternating streams
+void pwn_room_frame_done(struct pwn_ctx *c);         // a frame of such a sequence was delivered to the host
 
 struct pwn_tiled;        // pwn_tiled.cpp
 
@@ -117,6 +134,7 @@ struct pwn_ctx
 	hipStream_t stream;              // compute
 	hipStream_t stream2;             // frames in flight alternate between `stream` and this one (PWN_OPT_FRAME_OVERLAP)
 	uint32_t *d_pre2;                // the pre-blur plane of the frames on stream2 (allocated with the first of them)
+	pwn_room_ctl room; int launch_room;   // PWN_OPT_TRACE_ROOM; what the next trace launch leaves free (set by its caller, cleared by the launch)
 	int frame_overlap;               // PWN_OPT_FRAME_OVERLAP
 	hipEvent_t last_frame_done; hipStream_t last_frame_stream;   // "kernels done" of the frame submitted last, and its stream
 	hipStream_t copy_stream;         // frames in flight: D2H of finished frames

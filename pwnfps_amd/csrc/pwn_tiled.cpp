@@ -783,6 +783,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	c->trace_clear_word = t->missw[s];           // the frame's miss word is cleared by its trace launch (no memset between the kernels)
 	c->trace_cost_word = c->blur_passes ? t->cost_acc + 16 * (f & 1u) : NULL;      // (the blur moves it on: enqueue_blur)
 	c->trace_tables_event = t->ev_t[s];          // ... and ev_t, recorded right behind it, also tells when its tables are free again
+	c->launch_room = t->cs[1] != t->cs[0] ? pwn_room_for_launch(c) : 0;          // PWN_OPT_TRACE_ROOM
 	int rc = pwn_i_launch_trace(c, cam, sec, y0, y1, plane, t->z[s], cs);
 	if(rc != PWN_OK) { (void)hipEventRecord(t->ev_t[s], cs); return rc; }
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
@@ -971,6 +972,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	}
 	t->delivered = d + 1;
 	t->info.frames++;
+	if(t->cs[1] != t->cs[0]) pwn_room_frame_done(c);
 	if(out != NULL)
 	{
 		memset(out, 0, sizeof(*out));

@@ -72,6 +72,16 @@ class Renderer:
         """frames in flight: successive frames alternate between two compute streams (default) or all run on one"""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_FRAME_OVERLAP, 1 if on else 0), "pwn_set_option")
 
+    def set_trace_room(self, workgroups):
+        """PWN_OPT_TRACE_ROOM: workgroups the persistent trace grid leaves free for the other stream's kernels while frames
+        alternate between two streams; -1 (default) = the library measures which of 0 / one per CU is faster and keeps it"""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_TRACE_ROOM, int(workgroups)), "pwn_set_option")
+
+    def trace_room_state(self):
+        out = (C.c_int * 4)()
+        self._chk(lib.pwn_trace_room_state(self._ctx, out), "pwn_trace_room_state")
+        return {"option": out[0], "room_now": out[1], "comparisons": out[2], "changes": out[3]}
+
     def set_wave_log(self, on):
         """stats()["wave_time"] / (["waves"] * ["kernel_span"]) = mean wave residency of the last frame"""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_WAVE_LOG, 1 if on else 0), "pwn_set_option")

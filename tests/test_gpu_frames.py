@@ -105,3 +105,40 @@ def test_frames_without_blur_and_at_4k(oracle_lib, cases):
         for f in range(3):
             assert oracle_lib.fnv64(r.wait_frame(f)["sbuf"]) == want[key]
     r.close()
+
+
+def test_trace_room_never_changes_a_frame(oracle_lib, cases):
+    """PWN_OPT_TRACE_ROOM: the persistent trace grid leaves workgroups free for the other stream's kernels -- a fixed number,
+    or (-1, the default) whatever the library's own comparison of 0 against one per CU says.  A frame is the golden frame
+    whatever the setting, also while the setting changes under frames in flight; the state call reports what it did."""
+    import pwnfps_amd
+    c = [x for x in cases if x["name"] == "level_pose1_1280x720"][0]
+    w, h = c["w"], c["h"]
+    r = pwnfps_amd.Renderer(w, h)
+    r.level_load(level_path(c["level"]))
+    r.set_objects(load_spheres(c["spheres"]))
+    cam = np.array(c["cam"], np.float32)
+    r.frames_config(3, sbuf=True)
+    assert r.trace_room_state()["option"] == -1            # the library measures unless told otherwise
+    for room, frames in ((0, 6), (256, 6), (64, 6), (4096, 4), (-1, 140)):
+        r.set_trace_room(room)
+        for f in range(frames + 2):
+            if f >= 2:
+                fr = r.wait_frame((f - 2) % 3)
+                assert oracle_lib.fnv64(fr["sbuf"]) == c["post"], (room, f)
+            if f < frames:
+                r.submit_frame(cam, c["sec"], f % 3)
+        st = r.trace_room_state()
+        assert st["option"] == room
+        if room >= 0:
+            assert st["room_now"] == room and st["comparisons"] == 0
+    # 140 delivered frames: windows of 24 with each setting (6 skipped after every change), then a choice
+    assert st["comparisons"] >= 1 and st["changes"] >= 1 and st["room_now"] in (0, 256)        # (256 CUs: one workgroup per CU)
+    with pytest.raises(pwnfps_amd.PwnError) as e:
+        r.set_trace_room(-2)
+    assert e.value.code == -1
+    # the blocking call takes a fixed number too (and ignores the measuring mode: nothing runs beside it)
+    r.set_trace_room(128)
+    sb, _ = r.trace_screen_centred(cam, c["sec"])
+    assert oracle_lib.fnv64(sb) == c["post"]
+    r.close()

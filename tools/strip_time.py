@@ -28,6 +28,8 @@ r = pwnfps_amd.Renderer(w, h)
 r.level_load(os.path.join(gold, "levels", level + ".txt"))
 r.set_objects(np.load(os.path.join(gold, "spheres_t0.npy" if level == "pwnfps_level" else os.path.join("levels", level + "_spheres.npy"))))
 _, _, spawn = r.get_level()
+if os.environ.get("STRIP_ROOM") is not None:          # PWN_OPT_TRACE_ROOM: what the tiling's trace launches leave free on two streams
+    r.set_trace_room(int(os.environ["STRIP_ROOM"]))
 cam = pwnfps_amd.spawn_camera(spawn)
 if level != "pwnfps_level":
     cam = np.load(os.path.join(gold, "levels", level + "_cams.npy"))[0]
