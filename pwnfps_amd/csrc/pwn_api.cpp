@@ -758,8 +758,10 @@ int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const f
 	// 8-way 4K tiling -3.5 % kernel time against the 128 x 32 of rounds 1-2), 128 x 16 for narrow ones (720p +4.8 %, 1080p
 	// +3.4 %; 32 x 32 loses 6 % at 720p).  Any shape gives the same pixels.
 	{
+		// With room beside the trace grid (PWN_OPT_TRACE_ROOM, what level.txt-like scenes settle on) 32 x 32 wins on narrow frames
+		// too: 720p 16.4-17.5 -> 19.4 Gpixels/s (profiles/r3_blur_sweep.txt, last block).
 		B.tile_w = 32; B.tile_h = 32; B.batch = 1;
-		if(c->w < 2560) { B.tile_w = 128; B.tile_h = 16; }
+		if(c->w < 2560 && pwn_room_for_launch(c) == 0) { B.tile_w = 128; B.tile_h = 16; }
 		if(c->dbg_blur_th > 0) B.tile_h = c->dbg_blur_th;          // (a shape without an instantiation: the launch fails with hipErrorInvalidValue)
 		if(c->dbg_blur_tw > 0) B.tile_w = c->dbg_blur_tw;
 		if(c->dbg_blur_batch >= 0) B.batch = c->dbg_blur_batch;
