@@ -32,6 +32,7 @@ struct pwn_blur_params
 	// in *cost_acc (pwn_trace_params.cost_word); this launch moves the sum to *cost_out, the word that travels with
 	// the frame, and clears the accumulator for the stream's next trace.  Both NULL otherwise.
 	uint32_t *cost_acc, *cost_out;
+	uint32_t cost_mul, cost_div;   // ... scaled on the way: the resident grid over the grid the trace ran with (PWN_OPT_TRACE_ROOM), so that ranks with and without room compare
 };
 
 __device__ __forceinline__ uint32_t avg_u8x4(uint32_t a, uint32_t b)
@@ -144,7 +145,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	// contiguous eighth of the tiles in row-major order: the halo re-reads then
 	// hit that XCD's L2 instead of each going out to the Infinity Cache.
 	// (Placement only changes speed, never results.)
-	if(P.cost_acc != NULL && blockIdx.x == 0 && threadIdx.x == 0) { *P.cost_out = *P.cost_acc; *P.cost_acc = 0u; }
+	if(P.cost_acc != NULL && blockIdx.x == 0 && threadIdx.x == 0) { *P.cost_out = (uint32_t)((unsigned long long)*P.cost_acc * P.cost_mul / P.cost_div); *P.cost_acc = 0u; }
 	const int tiles_x = (P.w + BLUR_TW - 1) / BLUR_TW;
 	const int ntiles = tiles_x * ((P.y1 - P.y0 + BLUR_TH - 1) / BLUR_TH);
 	const int per_xcd = (ntiles + 7) >> 3;

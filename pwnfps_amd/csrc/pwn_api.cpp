@@ -82,6 +82,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0;
 	c->trace_clear_word = NULL; c->trace_cost_word = NULL; c->trace_tables_event = NULL; c->grid_reserve = 0;
 	memset(&c->room, 0, sizeof(c->room)); c->room.mode = -1; c->launch_room = 0;
+	c->cost_mul = c->cost_div = 1u; c->blur_cost_mul = c->blur_cost_div = 0u;
 	if(const char *e = getenv("PWN_TRACE_ROOM")) if(*e) c->room.mode = atoi(e) < 0 ? -1 : atoi(e);      // (the option's default for every context of a process)
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 8; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
@@ -697,7 +698,9 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 		if(c->room.mode >= 0) c->launch_room = c->room.mode;        // (a host that set a number gets it for every launch)
 		const int reserve = c->grid_reserve > c->launch_room ? c->grid_reserve : c->launch_room;
 		c->launch_room = 0;
+		c->cost_mul = c->cost_div = (uint32_t)grid;
 		if(reserve > 0 && grid > 2 * reserve) grid -= reserve;
+		c->cost_div = (uint32_t)grid;
 	}
 	// fewer units than resident waves (a 320 x 240 frame is 1200 units for 5120 waves): one unit per wave, a
 	// workgroup per four of them -- a workgroup whose waves find nothing still copies the tables into LDS
@@ -752,6 +755,8 @@ int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const f
 	B.pre = d_pre; B.zbuf = d_z; B.out = d_out; B.skip = c->d_skip;
 	B.avail_y0 = avail_y0; B.avail_y1 = avail_y1; B.miss = d_miss;
 	B.cost_acc = d_cost_acc; B.cost_out = d_cost_out;
+	B.cost_mul = c->blur_cost_mul ? c->blur_cost_mul : 1u; B.cost_div = c->blur_cost_div ? c->blur_cost_div : 1u;
+	c->blur_cost_mul = c->blur_cost_div = 0u;
 	// The workgroup's tile of output pixels (post_kernels.hip), chosen by what the frame rate on two streams said
 	// (profiles/r3_blur_sweep.txt): 32 x 32 for wide frames and their strips (256-thread workgroups with 17 KB of LDS find room
 	// beside the trace grid's workgroups that a 1024-thread one with 42 KB does not: 4K +1.9 %, 8K +5.3 %, the strips of an

@@ -21,6 +21,7 @@ struct pwn_blur_params
 	uint32_t *miss;
 	int tile_h, tile_w, batch;
 	uint32_t *cost_acc, *cost_out;
+	uint32_t cost_mul, cost_div;   // ... scaled on the way: the resident grid over the grid the trace ran with (PWN_OPT_TRACE_ROOM), so that ranks with and without room compare
 };
 
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream);
@@ -134,6 +135,8 @@ struct pwn_ctx
 	hipStream_t stream;              // compute
 	hipStream_t stream2;             // frames in flight alternate between `stream` and this one (PWN_OPT_FRAME_OVERLAP)
 	uint32_t *d_pre2;                // the pre-blur plane of the frames on stream2 (allocated with the first of them)
+	uint32_t cost_mul, cost_div;     // set by pwn_i_launch_trace: resident grid / grid it launched (what its cost word is to be scaled by); read by the tiling
+	uint32_t blur_cost_mul, blur_cost_div;   // ... handed to the next pwn_i_launch_blur by its caller (0 = 1 / 1)
 	pwn_room_ctl room; int launch_room;   // PWN_OPT_TRACE_ROOM; what the next trace launch leaves free (set by its caller, cleared by the launch)
 	int frame_overlap;               // PWN_OPT_FRAME_OVERLAP
 	hipEvent_t last_frame_done; hipStream_t last_frame_stream;   // "kernels done" of the frame submitted last, and its stream

@@ -235,6 +235,7 @@ struct pwn_tiled
 	int want_halo;                      // the halo asked for at init; moving cuts keep every strip at least this tall
 	int halo;                           // rows exchanged with each neighbour; 0 = whole strips to everybody
 	int fhalo[NSLOT];                   // ... as used for the frame in that slot (the mode changes after a miss)
+	uint32_t fcost_mul[NSLOT], fcost_div[NSLOT];   // what the slot's trace launch says its cost word is to be scaled by (pwn_ctx.cost_mul / _div)
 	int root_mode, froot[NSLOT];     // pwn_tiled_gather_root: PWN_TILED_ROOT_*; the rank the slot's frame is gathered on
 	int balance_every;                  // re-cut every this many delivered frames from the ranks' cost words; 0 = never
 	uint32_t last_cost[MAXW];           // the cost words of the last delivered frame (pwn_tiled_get_cuts)
@@ -736,6 +737,7 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 		// moves that into the frame's second word and clears the accumulator for the stream's next trace
 		uint32_t *acc = t->cost_acc + 16 * (k & 1u);
 		int rc;
+		c->blur_cost_mul = t->fcost_mul[s]; c->blur_cost_div = t->fcost_div[s];
 		if(t->fhalo[s])
 		{
 			const int H = t->fhalo[s];
@@ -786,6 +788,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	c->launch_room = t->cs[1] != t->cs[0] ? pwn_room_for_launch(c) : 0;          // PWN_OPT_TRACE_ROOM
 	int rc = pwn_i_launch_trace(c, cam, sec, y0, y1, plane, t->z[s], cs);
 	if(rc != PWN_OK) { (void)hipEventRecord(t->ev_t[s], cs); return rc; }
+	t->fcost_mul[s] = c->cost_mul; t->fcost_div[s] = c->cost_div;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
 	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
 
