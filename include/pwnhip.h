@@ -110,8 +110,8 @@ typedef struct pwn_stats
 #define PWN_OPT_TRACE_ROOM 8   /* frames on two compute streams (PWN_OPT_FRAME_OVERLAP, and the row tiling): workgroups the persistent
                                   trace grid leaves free so that the other stream's kernels find room on every CU beside it
                                   instead of waiting for its end.  -1 (default): the library measures -- windows of delivered
-                                  frames with no room and with one workgroup per CU, the better kept for ~500 frames, then
-                                  again (the answer depends on the scene: +3.5 % at 4K on level.txt, -3 % on a hall of
+                                  frames with no room and with one workgroup per CU, the better kept for ~500 frames (half a second
+                                  at least), then again (the answer depends on the scene: +3.5 % at 4K on level.txt, -3 % on a hall of
                                   mirrors); >= 0: that many, always.  Results never depend on it. */
 #define PWN_OPT_FRAME_TIMING 5 /* frames in flight: record HIP events around the trace and blur kernels of every N-th
                                   frame (pwn_frame.timed, .trace_ms ...); 1 = every frame (default), 0 = never.  An event

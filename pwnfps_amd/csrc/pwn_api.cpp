@@ -228,7 +228,7 @@ void pwn_room_frame_done(pwn_ctx *c)
 	const bool first = r.t_prev == 0.0;
 	r.t_prev = now;
 	if(first) { r.skip = ROOM_SKIP; return; }
-	if(r.hold > 0) { if(--r.hold == 0) { r.arm = 1 - r.best; r.skip = ROOM_SKIP; r.sum[0] = r.sum[1] = 0.0; r.cnt[0] = r.cnt[1] = 0; r.switches++; } return; }
+	if(r.hold > 0) { if(r.hold > 1) r.hold--; else if(now - r.t_hold > 0.5) { r.hold = 0; r.arm = 1 - r.best; r.skip = ROOM_SKIP; r.sum[0] = r.sum[1] = 0.0; r.cnt[0] = r.cnt[1] = 0; r.switches++; } return; }
 	if(r.skip > 0) { r.skip--; return; }
 	// (a host that stops between frames -- a debugger, a vsync -- is not the GPU's time: intervals far above the window's mean are left out)
 	if(r.cnt[r.arm] >= 4 && dt > 4.0 * r.sum[r.arm] / r.cnt[r.arm]) return;
@@ -240,7 +240,7 @@ void pwn_room_frame_done(pwn_ctx *c)
 	int best = m1 < m0 ? 1 : 0;
 	if(r.looks > 0 && best != r.best && (best ? m1 > 0.995 * m0 : m0 > 0.995 * m1)) best = r.best;
 	if(best != r.arm) { r.skip = ROOM_SKIP; r.switches++; }
-	r.best = best; r.arm = best; r.hold = ROOM_HOLD; r.looks++;
+	r.best = best; r.arm = best; r.hold = ROOM_HOLD; r.t_hold = now; r.looks++;       // (kept for ROOM_HOLD frames and at least half a second)
 }
 
 extern "C" int pwn_trace_room_state(pwn_ctx *c, int out[4])

@@ -72,7 +72,7 @@ struct pwn_room_ctl
 	int arm, best;            // 0 = no room, 1 = one workgroup per CU
 	int skip, hold;           // delivered frames not counted after a switch; frames left before the next look
 	double sum[2]; int cnt[2];
-	double t_prev;
+	double t_prev, t_hold;
 	unsigned long long looks, switches;
 };
 int pwn_room_for_launch(struct pwn_ctx *c);          // workgroups to leave free for a launch on one of two alternating streams
