@@ -467,6 +467,7 @@ def main():
         """every rank's means of what it measured since diag_reset(), gathered over the control plane"""
         mine = {k: (round(float(np.mean(v)), 4) if v else None) for k, v in diag.items() if isinstance(v, list)}
         mine.update(rows=diag["rows"], cost=diag["cost"], frames_redone=diag["redone"], timed_frames=len(diag["trace_ms"]))
+        mine.update(trace_room=r.trace_room_state()["room_now"])          # PWN_OPT_TRACE_ROOM as this rank's own measurement left it
         every = [None] * world
         dist.all_gather_object(every, mine)
         return {k: [e[k] for e in every] for k in mine}

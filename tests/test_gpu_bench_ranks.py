@@ -49,7 +49,7 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     assert d["transport"].startswith("shm") and "NOT RCCL" in d["transport"] and "NOT RCCL" in d["metric"]
     # every rank's own account of the headline leg, and the cuts (they move with what the strips cost)
     pr = t["per_rank"]
-    for k in ("trace_ms", "blur_ms", "halo_ms", "gather_ms", "frame_ms", "enqueue_us", "rows", "cost", "frames_redone", "timed_frames"):
+    for k in ("trace_ms", "blur_ms", "halo_ms", "gather_ms", "frame_ms", "enqueue_us", "rows", "cost", "frames_redone", "timed_frames", "trace_room"):
         assert len(pr[k]) == world, k
     assert sum(pr["rows"]) == size[1] and all(c > 0 for c in pr["cost"]) and all(v > 0 for v in pr["trace_ms"]) and all(v > 0 for v in pr["enqueue_us"])
     assert len(t["cuts"]) == world + 1 and t["cuts"][0] == 0 and t["cuts"][-1] == size[1]
