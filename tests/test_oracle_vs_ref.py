@@ -1,10 +1,12 @@
 """Direct oracle <-> compiled-reference comparisons.  They run wherever
 oracle/_ref/*.so exists (built by oracle/Makefile from /root/reference)."""
+import os
+
 import numpy as np
 import pytest
 
 import refharness
-from conftest import host_is_intel, level_path, load_spheres
+from conftest import GOLD, host_is_intel, level_path, load_spheres
 
 pytestmark = pytest.mark.skipif(not refharness.available("tab"), reason="oracle/_ref not built")
 
@@ -64,17 +66,32 @@ def test_w_lane_generality(oracle_lib):
 
 
 def test_native_and_table_builds_agree_on_intel():
+    """The goldens come from the build whose rcpps / rsqrtps read captured tables; on an Intel host the untouched build
+    (the host's own instructions) must render the same frames: one pose per level here, every golden case in
+    tools/check_hw_goldens.py (frames.json `hw_equal`, asserted by test_every_golden_case_is_pinned_by_the_native_build)."""
     if not (host_is_intel() and refharness.available("hw")):
         pytest.skip("needs an Intel host")
     H = refharness.RefHarness("hw")
     T = refharness.RefHarness("tab")
-    for X in (H, T):
-        X.load_level(level_path("pwnfps_level"))
-        X.set_spheres(load_spheres("t0"))
-    cam = _pose(9.5, 0.5, 4.5, 1.0, -0.1)
-    a, za = H.render(320, 240, cam, sec=3.0)
-    b, zb = T.render(320, 240, cam, sec=3.0)
-    assert (a == b).all() and (za.view(np.uint32) == zb.view(np.uint32)).all()
+    poses = (("pwnfps_level", "t0", _pose(9.5, 0.5, 4.5, 1.0, -0.1), 3.0, 320, 240),
+             ("synth64", "synth64", np.load(os.path.join(GOLD, "levels", "synth64_cams.npy"))[2], 0.75, 384, 216),
+             ("synth256", "synth256", np.load(os.path.join(GOLD, "levels", "synth256_cams.npy"))[1], 1.5, 384, 216))
+    for lvl, sph, cam, sec, w, h in poses:
+        for X in (H, T):
+            X.load_level(level_path(lvl))
+            X.set_spheres(load_spheres(sph))
+        a, za = H.render(w, h, cam, sec=sec)
+        b, zb = T.render(w, h, cam, sec=sec)
+        assert (a == b).all() and (za.view(np.uint32) == zb.view(np.uint32)).all(), lvl
+
+
+def test_every_golden_case_is_pinned_by_the_native_build(cases):
+    """frames.json: every case's blurred frame and depth plane were reproduced by the reference built with the host's
+    own rcpps / rsqrtps (tools/check_hw_goldens.py on the Intel build container) -- all of them, also the synthetic
+    levels and the 8K frames, not only the small level.txt cases the generator checked."""
+    missing = [c["name"] for c in cases if c.get("hw_equal") is not True]
+    assert not missing, missing
+    assert all("Intel" in c.get("hw_host", "") for c in cases)
 
 
 def test_upscale_vs_reference(oracle_lib):
