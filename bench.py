@@ -31,6 +31,16 @@ comm stream, host enqueue time per frame, rows and cost of its strip), the movin
 legs in the same run with the trace grid's room for RCCL at 0 / 16 / 64 workgroups, the gather spread over the
 ranks (`rotating_root`), equal strips, one compute stream, and whole strips instead of the bounded halo.  `transport` says at top level what carried the data; over
 the shared-memory fallback the metric string says that the figure is NOT RCCL over xGMI.
+
+N > 1 cannot fail silently (pwnfps_amd/watch.py): every rank marks the stage it is in in the control plane's key-value
+store (not a collective: a rank that hangs does not keep the others from reading it), and the bring-up, the headline
+leg and the legs after it each run under a deadline (--bringup-timeout, --headline-timeout, --post-timeout).  When one
+passes -- or the launcher sends SIGTERM because a rank died -- rank 0 prints the line anyway: "value": null (or the
+headline if that was measured), "incomplete": true, "error", and "stage_reached": per rank the stage, how long ago, the
+last error.  Every rank then leaves with exit status 3.  The library's own deadlines (pwn_tiled_set_timeouts) are set
+below the bench's, so that a communicator that does not come up comes back as an error the ranks can agree on
+(fallback to the shared-memory transport, said in the line) before the watchdog has to end the run.  `tiling.preflight`
+records, per rank, the devices it sees and can reach directly, the librccl that dlopen resolved and its version.
 """
 import argparse
 import json
@@ -100,16 +110,69 @@ def pmc_issue_rate(kernel, w, h, launch_ms):
         return None
 
 
-def issue_frac(w, h, level, launch_ms):
+def valu_fractions(kernel, w, h, launch_ms):
+    """The trace kernel against the ARCHITECTURAL VALU rate (MI355X_MICROARCH.md: a SIMD is 32 lanes wide, a wave64 VALU
+    instruction takes two cycles: 1.2 per ns and SIMD at 2.4 GHz; 1024 SIMDs):
+      valu_issue_frac_of_peak = SQ_INSTS_VALU / (1024 x launch ns x 1.2)      how busy the VALU issue ports are
+      lane_slot_frac          = that x mean active lanes per VALU instruction / 64   ... with useful lanes
+    Instruction counts from the committed PMC summary (profiles/pmc_latest.csv, they do not depend on the run), the
+    launch time from this run's HIP events.  None when the summary was taken at another frame size."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.csv")
+    try:
+        meta = [l for l in open(path) if l.startswith("#")]
+        if not any("%dx%d" % (w, h) in m for m in meta) or launch_ms <= 0:
+            return None
+        rows = [l.rstrip("\n").rsplit(",", 3) for l in open(path)]
+        v = {r[1]: float(r[3]) for r in rows if len(r) == 4 and kernel in r[0] and "<true" not in r[0]}
+        frac = v["SQ_INSTS_VALU"] / (1024.0 * launch_ms * 1e6 * 1.2)
+        lanes = v["SQ_THREAD_CYCLES_VALU"] / v["SQ_ACTIVE_INST_VALU"]
+        return {"valu_issue_frac_of_peak": round(frac, 4), "lane_slot_frac": round(frac * lanes / 64.0, 4),
+                "active_lanes_per_valu_instruction": round(lanes, 2), "sq_insts_valu_per_launch": int(v["SQ_INSTS_VALU"]),
+                "peak_valu_per_ns_per_simd": 1.2, "simds": 1024, "counters_from": "profiles/pmc_latest.csv"}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
+def nonfinite_scenes(pwnfps_amd):
+    """where the reference's arithmetic leaves the finite range (a ramp whose tilt cancels ray.y, trace.h:461) the
+    contract is the IEEE build everywhere and the shipped-flags build wherever depth is finite.  The three scenes the
+    repo holds with BOTH reference renderings (tests/golden/nonfinite, from tools/fuzz_parity.py --keep-nonfinite),
+    through the HIP path, outside every timed region."""
+    import glob
+    out = []
+    for path in sorted(glob.glob(os.path.join(GOLD, "nonfinite", "*.npz"))):
+        d = np.load(path)
+        r = pwnfps_amd.Renderer(int(d["w"]), int(d["h"]))
+        try:
+            r.level_load_text(str(d["text"]))
+            r.set_objects(d["sph"])
+            r.set_blur_passes(int(d["blur"]))
+            sb, z = r.trace_screen_centred(d["cam"], float(d["sec"]))
+        finally:
+            r.close()
+        fin = np.isfinite(d["ref_nf_z"])
+        out.append({"scene": os.path.basename(path), "pixels": int(sb.size),
+                    "equals_ieee_build": bool((sb == d["ref_nf"]).all() and (z.view(np.uint32) == d["ref_nf_z"].view(np.uint32)).all()),
+                    "pixels_with_nonfinite_depth": int((~fin).sum()),
+                    "pixels_differing_from_the_shipped_flags_build": int((sb != d["ref_shipped"]).sum()),
+                    "blur": int(d["blur"])})
+    return out
+
+
+def model_over_measured(w, h, level, launch_ms):
     """VALU issue time of one launch by the committed issue model (tools/issue_model.py -> profiles/r3_issue_model.json) over the
-    measured launch time.  None when the model was not made for this frame."""
+    measured launch time.  NOT a roofline fraction: the model's costs per opcode class come from this repo's own
+    microbenchmark, and a value near 1 says "this instruction stream has no stall slack", not "no faster kernel exists"
+    (the architectural fractions are roofline.valu_issue_frac_of_peak / lane_slot_frac).  None when the model was not made
+    for this frame."""
     try:
         with open(os.path.join(ROOT, "profiles", "r3_issue_model.json")) as f:
             m = json.load(f)
         for c in m["cases"]:
             if (c["w"], c["h"], c["level"]) == (w, h, level) and launch_ms > 0:
-                return {"valu_issue_ms_model": c["valu_issue_ms"], "frac": round(c["valu_issue_ms"] / launch_ms, 4),
-                        "model": "profiles/r3_issue_model.txt"}
+                return {"valu_issue_ms_model": c["valu_issue_ms"], "ratio": round(c["valu_issue_ms"] / launch_ms, 4),
+                        "model": "profiles/r3_issue_model.txt",
+                        "what": "the builder's cost model over the measured launch; > 1 only says the cost table over-predicts"}
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -210,7 +273,7 @@ def d2h_leg_one_gpu(r, args, w, h, cam, sec, spheres, blocking_best, same_as_res
     return pcie
 
 
-def host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks, same_as_resident):
+def host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks, same_as_resident, mark=lambda *a, **k: None):
     """The same metric with every frame delivered to the HOST on N > 1 GPUs (main.c:107-109 presents
     every frame there): pwn_tiled_host_sink -- every rank copies its finished strip straight into ONE frame in POSIX
     shared memory over its own PCIe link, there is no gather to rank 0.  Collective: every rank calls it."""
@@ -218,6 +281,7 @@ def host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barr
     import torch.distributed as dist
     import pwnfps_amd
     import mmap
+    mark("host_sink: shutdown of the resident tiling")
     barrier()
     r.tiled_shutdown()
     shm_name = [("/dev/shm/pwn_bench_frames_%d_%d" % (os.getpid(), int(time.time() * 1e3))) if rank == 0 else None]
@@ -230,7 +294,9 @@ def host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barr
     fd = os.open(shm_name[0], os.O_RDWR)
     frames_mm = mmap.mmap(fd, _lib_slots() * 4 * w * h)
     os.close(fd)
+    mark("host_sink: tiled_init", transport=transport)
     r.tiled_init(rank, world, uid2[0], transport, args.halo)
+    mark("host_sink: frames", transport=transport)
     sink_err = None
     try:
         r.tiled_host_sink(frames_mm)
@@ -307,6 +373,11 @@ def main():
     ap.add_argument("--min-time", type=float, default=3.0, help="repeat the K-step block until this many seconds were timed (each of the "
                     "resident and the d2h leg: the GPU is busy for >= 6 s of a default run)")
     ap.add_argument("--sweep-time", type=float, default=0.3, help="N > 1: seconds timed per leg of tiling.sweep (0 = no sweep)")
+    ap.add_argument("--bringup-timeout", type=float, default=150.0,
+                    help="N > 1: seconds the bring-up may take (control plane, preflight, communicator, four frames through every leg of the "
+                         "exchange; a fallback to the shared-memory transport starts the clock again); then rank 0 prints a diagnostic line "
+                         "(value null, the stage every rank reached) and every rank leaves with status 3")
+    ap.add_argument("--headline-timeout", type=float, default=120.0, help="N > 1: the same for the headline leg (warm-up + the timed blocks)")
     ap.add_argument("--post-timeout", type=float, default=240.0,
                     help="N > 1: seconds the legs AFTER the headline (sweep, host-sink leg) may take in all; then every rank stops and "
                          "rank 0 prints the line with what it has -- a hang in an extra leg must not cost the headline number")
@@ -355,6 +426,38 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
         dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+    from pwnfps_amd import watch
+    board = watch.Board(rank, world, watch.default_store() if world > 1 else None)
+    partial = {"line": None}             # what a diagnostic line can already say (filled as the run proceeds)
+
+    def diagnostic_line(reason, stages):
+        """rank 0, a deadline passed or the launcher sent SIGTERM: the line with what there is (no GPU call, no collective)"""
+        if partial.get("build") is not None:
+            try:
+                line = partial["build"]()            # the headline was measured: the whole line, with what the later legs have so far
+            except Exception as e:                   # noqa: BLE001 -- the diagnostic must come out whatever state the run is in
+                line = dict(partial["line"] or {}, line_error=str(e))
+        else:
+            line = dict(partial["line"] or {})
+        line.setdefault("metric", "Mpixels/s at %dx%d (level.txt scene, trace + blur), frames resident on the device" % (args.width, args.height))
+        line.setdefault("value", None)
+        line.setdefault("unit", "Mpixels/s")
+        line.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, incomplete=True, error=reason,
+                    stage_reached=stages)
+        return line
+    dog = watch.Watch(board, diagnostic_line)
+    _RUN.update(dog=dog, board=board, world=world, rank=rank)
+    if world > 1:
+        dog.catch_sigterm()
+        board.mark("control_plane_up")
+        dog.arm(args.bringup_timeout, "bring-up")
+
+    def die_here(stage):
+        """test hook (tests/test_gpu_bench_ranks.py): PWN_BENCH_DIE_AT=STAGE:RANK -- that rank leaves the process at that stage"""
+        want = os.environ.get("PWN_BENCH_DIE_AT", "")
+        if want and want.split(":")[0] == stage and int(want.split(":")[1]) == rank:
+            sys.stdout.flush()
+            os._exit(17)
 
     w, h = args.width, args.height
     level_file = os.path.join(GOLD, "levels", args.level + ".txt")
@@ -403,10 +506,27 @@ def main():
     if world == 1:
         r.frames_config(nres, sbuf=False)
     else:
+        # ---- preflight: what every rank sees (devices, direct peer access from its own, the librccl dlopen resolved, its
+        # version, how the communicator will be driven), marked on the board -- readable whatever happens next -- and
+        # gathered for the line
+        lib_init_s = max(5.0, min(60.0, args.bringup_timeout * 0.4))
+        lib_wait_s = max(3.0, min(30.0, args.headline_timeout * 0.25))
+        r.tiled_set_timeouts(lib_init_s, lib_wait_s)       # below the bench's own deadlines: an error the ranks can agree on comes first
+        try:
+            pre_mine = r.tiled_preflight()
+        except Exception as e:                                       # noqa: BLE001 -- reported in the line
+            pre_mine = {"error": str(e)}
+        pre_mine["rank"] = rank
+        board.mark("preflight", preflight=pre_mine)
+        die_here("preflight")
+        preflight = [None] * world
+        dist.all_gather_object(preflight, pre_mine)
+        partial["line"] = {"tiling": {"preflight": preflight}}
         # Every rank first checks that it can load the transport at all (a rank without librccl would leave the
         # others waiting inside ncclCommInitRank).  If one cannot, all ranks agree on the shared-memory test
         # transport instead -- the same kernels and messages, through the host -- and the line says so.
         transport_note = None
+        board.mark("transport_check", transport=transport)
         if transport == "rccl":
             try:
                 pwnfps_amd.Renderer.tiled_unique_id("rccl")
@@ -419,14 +539,22 @@ def main():
                 transport = "shm"
                 transport_note = transport_note or "librccl could not be loaded on another rank"
                 print("bench.py rank %d: %s -- falling back to the shared-memory transport" % (rank, transport_note), file=sys.stderr)
-        def bring_up(tp, halo=None):
+
+        def bring_up(tp, halo=None, tag=""):
             """Communicator plus four frames through every leg of the exchange (halo group, gather group, the ranks'
-            words); every rank learns whether ALL ranks got through."""
+            words); every rank learns whether ALL ranks got through.  Each step is marked on the board; an error of
+            this rank is marked too, BEFORE the collective that tells the others (which hangs if a peer is gone: the
+            watchdog then prints the marks)."""
+            board.mark(tag + "unique_id", transport=tp)
             u = [pwnfps_amd.Renderer.tiled_unique_id(tp) if rank == 0 else None]
             dist.broadcast_object_list(u, src=0)
             err = None
             try:
+                board.mark(tag + "tiled_init", transport=tp, limit_s=lib_init_s)
+                die_here(tag + "tiled_init")
                 r.tiled_init(rank, world, u[0], tp, args.halo if halo is None else halo)
+                board.mark(tag + "first_frames", transport=tp, limit_s=lib_wait_s)
+                die_here(tag + "first_frames")
                 for i in range(4):
                     r.set_objects(spheres)
                     r.tiled_submit(cam, sec)
@@ -437,22 +565,32 @@ def main():
                 torch.cuda.synchronize()
             except Exception as e:                                   # noqa: BLE001 -- reported in the line
                 err = "rank %d: %s" % (rank, e)
+                board.note_error(err)
+            board.mark(tag + "agree", transport=tp, error=err)
             good = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
             return float(good.item()) == 1.0, err
 
         up, err = bring_up(transport)
         if not up and transport == "rccl":
-            # (an error every rank can return from -- a communicator that cannot be made in this environment --
-            # not a peer that died inside a collective: that ends in the control plane's timeout)
+            # (an error every rank can return from -- a communicator that cannot be made in this environment, or one that
+            # did not come up within the library's deadline.  A peer that DIED leaves the agreement above hanging: that ends
+            # in the watchdog's diagnostic line)
             transport_note = "the RCCL transport did not come up (%s)" % (err or "on another rank")
             print("bench.py rank %d: %s -- falling back to the shared-memory transport" % (rank, transport_note), file=sys.stderr)
             r.tiled_shutdown()
             transport = "shm"
-            up, err = bring_up(transport)
+            dog.arm(args.bringup_timeout, "bring-up over the shared-memory fallback")
+            up, err = bring_up(transport, tag="fallback:")
         if not up:
-            sys.exit("bench.py rank %d: the row tiling did not come up over %s: %s" % (rank, transport, err or "error on another rank"))
+            board.mark("bring_up_failed", error=err or "error on another rank", transport=transport)
+            dog.bail("the row tiling did not come up over %s: %s" % (transport, err or "error on another rank (see stage_reached)"))
         tinfo = r.tiled_info()
+        partial["line"]["tiling"].update(transport=transport, transport_note=transport_note,
+                                         rccl_nonblocking=tinfo["rccl_nonblocking"], deadlines_s={"library_init": lib_init_s, "library_wait": lib_wait_s,
+                                                                                               "bring_up": args.bringup_timeout, "headline": args.headline_timeout, "post": args.post_timeout})
+        board.mark("bring_up_done", transport=transport)
+        dog.disarm()
 
     launch_ms = []
     last = {"f": None}
@@ -529,12 +667,18 @@ def main():
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
+    leg_name = ["headline"]
+
     def leg(warmup, min_time, max_blocks=500):
         """warm-up, then K-step blocks until min_time seconds were timed: (median block seconds, all blocks)"""
+        if world > 1:
+            board.mark("%s: warm-up" % leg_name[0])
         run(warmup)
         diag_reset()
         blocks = []
         while True:
+            if world > 1:
+                board.mark("%s: block %d" % (leg_name[0], len(blocks)))
             blocks.append(block())
             # all ranks see the same (max-reduced) times, so they stop together
             if sum(blocks) >= min_time or len(blocks) >= max_blocks:
@@ -545,7 +689,22 @@ def main():
         # events between the kernels of frames that share the chip would time neither kernel by itself and cost a few
         # microseconds of pipeline each: the headline leg records none, the roofline leg below times solo launches
         r.set_frame_timing(0)
-    dt, block_s = leg(args.warmup, args.min_time)
+    if world > 1:
+        board.mark("headline")
+        dog.arm(args.headline_timeout, "headline leg")
+        die_here("headline")
+    try:
+        dt, block_s = leg(args.warmup, args.min_time)
+    except Exception as e:                                           # noqa: BLE001
+        if world == 1:
+            raise
+        # a deadline of the library passed on THIS rank (PWN_ETIMEDOUT: a peer stopped answering) or a launch failed: say so
+        # on the board and leave; the others find it there when their own deadline, or the launcher's SIGTERM, ends them
+        board.note_error("rank %d: %s" % (rank, e))
+        dog.bail("rank %d: the headline leg failed: %s" % (rank, e))
+    if world > 1:
+        board.mark("headline_done")
+        dog.disarm()
     room_state = r.trace_room_state()          # PWN_OPT_TRACE_ROOM as the headline leg left it
     roofline_leg = None
     if world == 1 and overlap_on:
@@ -586,6 +745,12 @@ def main():
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("parity check skipped: %s\n" % e)
 
+    nonfinite = None
+    if world == 1 and rank == 0:
+        try:
+            nonfinite = nonfinite_scenes(pwnfps_amd)
+        except Exception as e:  # noqa: BLE001
+            nonfinite = {"error": str(e)}
     counters = None
     pcie = None
     kernel_ms = None
@@ -607,6 +772,7 @@ def main():
                 world, transport.upper(), ("%d halo rows per neighbour" % tinfo["halo_rows"]) if tinfo["halo_rows"] else "whole pre-blur strips to every rank",
                 "two compute streams" if tinfo["two_streams"] else "one compute stream")
         achieved = TRACE_BYTES_PER_PIXEL * strip_pix / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+        vf = valu_fractions("pwn_trace_kernel", w, h, trace_ms) if world == 1 else None
         line = {
             "metric": ("Mpixels/s at %dx%d (level.txt scene, trace + blur), frames resident on the device; mean steps/ray alongside"
                        % (w, h)) + ("; d2h_inclusive = the rate with every frame delivered to the host (SURVEY 8d)" if not args.no_d2h else "")
@@ -646,10 +812,17 @@ def main():
                          "instruction_issue": pmc_issue_rate("pwn_trace_kernel", w, h, trace_ms) if world == 1 and trace_ms > 0 else None,
                          "bytes_per_pixel": TRACE_BYTES_PER_PIXEL, "pixels_per_launch": strip_pix,
                          "avg_launch_ms": round(trace_ms, 4),
-                         # what really bounds the kernel: the VALU issue time of its instruction stream (profiles/r3_issue_model.json:
-                         # per-block instruction mix x measured execution counts x measured issue cost per opcode class) over the launch
-                         "issue_frac": issue_frac(w, h, args.level, trace_ms) if world == 1 else None,
-                         "note": "VALU-issue-bound DDA (issue_frac): tables live in LDS, compulsory HBM traffic is the 8 B/pixel written"},
+                         # what really bounds the kernel, against the ARCHITECTURE: VALU instructions issued over what 1024 SIMDs can
+                         # issue in the launch's time at 1.2 per ns, and the same weighted by the lanes that were active
+                         "valu_issue_frac_of_peak": vf["valu_issue_frac_of_peak"] if vf else None,
+                         "lane_slot_frac": vf["lane_slot_frac"] if vf else None,
+                         "valu": vf,
+                         # ... and against the builder's own cost model (profiles/r3_issue_model.json: per-block instruction mix x
+                         # measured execution counts x issue cost per opcode class from this repo's microbenchmark) -- a ratio, not a
+                         # roofline fraction (it was `issue_frac` until round 3)
+                         "model_over_measured": model_over_measured(w, h, args.level, trace_ms) if world == 1 else None,
+                         "note": "VALU-issue-bound DDA: tables live in LDS, compulsory HBM traffic is the 8 B/pixel written; read "
+                                 "valu_issue_frac_of_peak / lane_slot_frac for how far the kernel is from the chip's VALU rate"},
             # the second kernel of a frame, the one that really is a memory gather: 12 algorithmic
             # bytes per pixel (read colour 4 + depth 4, write 4), single-GPU figure from HIP events
             "blur_roofline": ({"bound": "hbm", "kernel": "pwn_blur_tiled_kernel", "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -661,11 +834,23 @@ def main():
             "frame_gbs": round(FRAME_BYTES_PER_PIXEL * pix * args.steps / dt / 1e9, 3),
             "parity_vs_reference_golden": parity,
             "frame_fnv64": frame_hash,
+            "parity": {"headline_frame_equals_reference_golden": parity,
+                       "golden_pinned_by": "oracle/_ref/libpwnref_tab.so (the reference's headers, its flags, rcpps/rsqrtps from captured tables) and, "
+                                           "for all 29 golden cases, by libpwnref_hw.so with the Intel host's own instructions (frames.json hw_equal)",
+                       "contract": "bit-exact, no tolerance: colour (four bytes), depth (fp32 bits) and the work counters.  Where the reference itself "
+                                   "divides by zero (a ramp whose tilt cancels ray.y, trace.h:461) its -ffinite-math-only build is not defined: "
+                                   "there the frames equal the same sources built with -fno-finite-math-only everywhere, and the shipped-flags "
+                                   "build wherever depth is finite (DESIGN.md 2)",
+                       "nonfinite_scenes": nonfinite},
         }
         if world > 1:
             line["tiling"] = {k: tinfo[k] for k in ("rows_per_rank", "halo_rows", "groups", "frames", "frames_redone", "bytes_sent", "bytes_received",
                                                     "max_rows", "balance_every", "grid_reserve", "two_streams", "recuts")}
             line["tiling"]["transport"] = transport
+            line["tiling"]["preflight"] = preflight
+            line["tiling"]["rccl_nonblocking"] = tinfo.get("rccl_nonblocking")
+            line["tiling"]["deadlines_s"] = {"library_init": lib_init_s, "library_wait": lib_wait_s, "bring_up": args.bringup_timeout,
+                                             "headline": args.headline_timeout, "post": args.post_timeout}
             if transport_note:
                 line["tiling"]["transport_note"] = transport_note
             line["tiling"]["cuts"] = cuts_now
@@ -686,31 +871,34 @@ def main():
             line["d2h_inclusive"] = pcie
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
+        # `vs_baseline` stays null: BASELINE.md holds no published number for this metric.  The ratio a reader wants -- the
+        # metric as SURVEY 8(d) words it (every frame delivered to the host) over the reference's own code on this box's
+        # cores in the same run -- is here:
+        if cpu_line is not None and pcie and pcie.get("value"):
+            line["vs_cpu_baseline"] = {"value": round(pcie["value"] / cpu_line["value"], 1),
+                                       "value_vs_1_thread": round(pcie["value"] / cpu_line["value_1_thread"], 1) if cpu_line.get("value_1_thread") else None,
+                                       "what": "d2h_inclusive.value / cpu_baseline.value: frames delivered to the host over PCIe against the reference CPU "
+                                               "path on %d host threads; a reported ratio, not the optimisation target" % cpu_line["cores"]}
         return line
 
     # ---- N > 1: what follows the headline (sweep, host-sink leg) runs under a deadline on every rank: a leg that hangs -- a transport
     # that does not come up a second time, a peer that died -- must not cost the headline number.  When it passes, rank 0 prints the
-    # line with what it has and every rank leaves (the process's exit takes its GPU queues down).
-    watchdog = None
-    if world > 1 and args.post_timeout > 0:
-        import threading
-
-        def bail():
-            post["note"] = "the legs after the headline did not finish within %.0f s (--post-timeout): sweep / d2h_inclusive hold what was measured until then" % args.post_timeout
-            try:
-                if rank == 0:
-                    print(json.dumps(build_line()), flush=True)
-            finally:
-                os._exit(0)
-        watchdog = threading.Timer(args.post_timeout, bail)
-        watchdog.daemon = True
-        watchdog.start()
+    # line with what it has ("incomplete": true, the stages) and every rank leaves with status 3 (the process's exit takes its GPU
+    # queues down; ADVICE r3: not status 0, a driver that keys on the exit code must not take a wedged run for a clean one).
+    if world > 1:
+        def line_so_far():
+            post["note"] = "the legs after the headline did not finish (--post-timeout %.0f s): sweep / d2h_inclusive hold what was measured until then" % args.post_timeout
+            return build_line()
+        partial["build"] = line_so_far
+        if args.post_timeout > 0:
+            dog.arm(args.post_timeout, "the legs after the headline")
 
     # ---- N > 1: the same run, other settings, a fraction of a second each: what a first multi-GPU run should look at
     if world > 1 and args.sweep_time > 0:
         sweep = {}
 
         def point(name, what):
+            leg_name[0] = "sweep." + name
             d2, bl = leg(max(2, args.warmup // 2), args.sweep_time, 60)
             pr = per_rank()
             sweep[name] = {"what": what, "value": round(w * h * args.steps / d2 / 1e6, 3), "ms_per_step": round(d2 / args.steps * 1e3, 4),
@@ -750,13 +938,13 @@ def main():
         barrier()
         r.tiled_shutdown()
         r.set_frame_overlap(False)
-        ok1, _ = bring_up(transport)
+        ok1, _ = bring_up(transport, tag="sweep.one_stream:")
         if ok1:
             point("one_stream", "PWN_OPT_FRAME_OVERLAP 0: every frame's kernels on ONE compute stream")
         barrier()
         r.tiled_shutdown()
         r.set_frame_overlap(True)
-        ok2, _ = bring_up(transport, halo=0)
+        ok2, _ = bring_up(transport, halo=0, tag="sweep.whole_strips:")
         if ok2:
             point("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows")
         # (the host-sink leg below sets the tiling up once more)
@@ -794,10 +982,11 @@ def main():
                                (lambda buf: oracle.fnv64(buf) == frame_hash) if (oracle is not None and frame_hash is not None) else None)
     if world > 1 and not args.no_d2h:
         pcie = host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks,
-                             (lambda buf: oracle.fnv64(buf) == frame_hash) if (rank == 0 and oracle is not None and frame_hash is not None) else None)
+                             (lambda buf: oracle.fnv64(buf) == frame_hash) if (rank == 0 and oracle is not None and frame_hash is not None) else None,
+                             mark=board.mark)
 
-    if watchdog is not None:
-        watchdog.cancel()
+    dog.disarm()
+    post["note"] = None
     if rank == 0:
         print(json.dumps(build_line()), flush=True)
 
@@ -809,5 +998,19 @@ def main():
         dist.destroy_process_group()
 
 
+_RUN = {"dog": None, "board": None, "world": 1, "rank": 0}
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as e:                                       # noqa: BLE001
+        # N > 1: an exception on one rank (a control-plane collective that lost its peer, a launch that failed) must
+        # not end in a traceback alone: the same diagnostic line, the same exit status as a deadline
+        if _RUN["dog"] is not None and _RUN["world"] > 1:
+            import traceback
+            traceback.print_exc()
+            _RUN["board"].note_error("rank %d: %s: %s" % (_RUN["rank"], type(e).__name__, e))
+            _RUN["dog"].bail("rank %d: %s: %s" % (_RUN["rank"], type(e).__name__, str(e)[:500]))
+        raise

@@ -38,6 +38,8 @@ extern "C" {
 #define PWN_ETOOBIG      -7  /* sphere tables exceed the on-chip (LDS) budget */
 #define PWN_EBUSY        -8  /* the frame slot is still in flight (pwn_wait_frame it first) */
 #define PWN_ENOTSUP      -9  /* not available here (RCCL could not be loaded; not configured) */
+#define PWN_ETIMEDOUT    -10 /* the row tiling waited longer than its deadline for a peer (pwn_tiled_set_timeouts); the tiling is
+                                dead from then on (its communicator was aborted): pwn_tiled_shutdown, or leave the process */
 
 typedef struct pwn_ctx pwn_ctx;
 
@@ -308,6 +310,23 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
  *                        its links carries one strip every N-th frame.  pwn_tiled_wait gives out->d_sbuf (and, with
  *                        PWN_TILED_HOST, out->sbuf) on the frame's root, out->root says which rank that is.
  *   pwn_tiled_shutdown   collective; pwn_destroy does it too.
+ *   pwn_tiled_set_timeouts  this rank, any time (also before pwn_tiled_init): how long a call of the tiling may wait for
+ *                        the other ranks before it gives up.  The reference's error model is print-and-return
+ *                        (level.h:35-37,110-115); a row tiling adds a failure the reference cannot have -- a peer that never
+ *                        arrives -- and that must come back as an error too, not as a hang.  init_ms bounds the bring-up
+ *                        of pwn_tiled_init (communicator + one word exchanged with EVERY other rank, so that every
+ *                        connection a frame will use exists when it returns), wait_ms bounds pwn_tiled_wait (and what
+ *                        pwn_tiled_submit may have to wait for inside the transport).  On expiry the RCCL communicator
+ *                        is aborted (ncclCommAbort; the kernels it has on the device leave), the call returns
+ *                        PWN_ETIMEDOUT with pwn_last_error() naming this rank, what it waited for and how far it got,
+ *                        and every later pwn_tiled_submit / _wait returns PWN_ETIMEDOUT at once.  0 keeps a value, < 0
+ *                        restores the default (PWN_TILED_INIT_TIMEOUT_MS / PWN_TILED_WAIT_TIMEOUT_MS in the environment,
+ *                        else 120 s / 60 s).
+ *   pwn_tiled_preflight  this rank, no tiling needed: what a first multi-GPU run wants to know before it starts, as one
+ *                        JSON object in `json` -- the devices this process sees and, from the context's device, which of
+ *                        them it can reach directly (hipDeviceCanAccessPeer), the librccl that dlopen resolved (path and
+ *                        version), how the communicator will be driven (PWN_TILED_RCCL_MODE) and the deadlines.  Returns
+ *                        the length written (the text is cut at n - 1), or PWN_E*.
  * PWN_TRANSPORT_SHM moves the same messages through POSIX shared memory instead: for tests
  * on a box with one GPU, where RCCL cannot run two ranks; the ranks may share a device.
  */
@@ -348,6 +367,11 @@ typedef struct pwn_tiled_info
 	int two_streams;                               /* 1: frames alternate between two compute streams (PWN_OPT_FRAME_OVERLAP at init) */
 	uint64_t recuts;                               /* how often the cuts moved */
 	int gather_root;                               /* PWN_TILED_ROOT_* (pwn_tiled_gather_root) */
+	int rccl_nonblocking;                          /* RCCL transport: 1 = a non-blocking communicator, every call polled against the deadline
+	                                                  (PWN_TILED_RCCL_MODE=nonblocking); 0 = a blocking one, bring-up on a helper thread under
+	                                                  the deadline (the default) */
+	int init_timeout_ms, wait_timeout_ms;          /* pwn_tiled_set_timeouts, as in force */
+	int dead;                                      /* 1: a deadline passed or the transport failed; the communicator is gone */
 } pwn_tiled_info;
 int pwn_tiled_unique_id(void *id128, int transport);
 int pwn_tiled_init(pwn_ctx *ctx, int rank, int world, const void *id128, int transport, int halo_rows);
@@ -357,6 +381,8 @@ int pwn_tiled_host_sink(pwn_ctx *ctx, void *base, size_t bytes);
 int pwn_tiled_gather_root(pwn_ctx *ctx, int mode);
 int pwn_tiled_get_info(pwn_ctx *ctx, pwn_tiled_info *out);
 void pwn_tiled_shutdown(pwn_ctx *ctx);
+int pwn_tiled_set_timeouts(pwn_ctx *ctx, int init_ms, int wait_ms);
+int pwn_tiled_preflight(pwn_ctx *ctx, char *json, size_t n);
 /*
  * Moving cuts.  Equal strips are not equal work (the horizon band of level.txt costs 1.2-1.3x the mean strip of an
  * 8-way tiling), and the reference's answer to that -- OpenMP's static schedule over 32-row chunks, screen.h:63-64 --

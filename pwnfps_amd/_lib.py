@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PWNHIP_LIB") or os.path.join(_HERE, "libpwnhip.so")
 
 PWN_OK, PWN_EINVAL, PWN_ENODEV, PWN_ENOMEM, PWN_EIO, PWN_EHIP, PWN_ENOLEVEL, PWN_ETOOBIG = 0, -1, -2, -3, -4, -5, -6, -7
-PWN_EBUSY, PWN_ENOTSUP = -8, -9
+PWN_EBUSY, PWN_ENOTSUP, PWN_ETIMEDOUT = -8, -9, -10
 PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER, PWN_OPT_REFILL_LIMIT, PWN_OPT_FRAME_TIMING, PWN_OPT_WAVE_LOG = 1, 2, 3, 4, 5, 6
 PWN_OPT_FRAME_OVERLAP = 7
 PWN_OPT_TRACE_ROOM = 8
@@ -56,7 +56,8 @@ class TiledInfo(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("rank", "world", "y0", "y1", "rows_per_rank", "halo_rows", "transport")] + \
                [(n, C.c_uint64) for n in ("frames", "frames_redone", "groups", "bytes_sent", "bytes_received", "bytes_to_host")] + \
                [(n, C.c_int) for n in ("host_sink", "max_rows", "balance_every", "grid_reserve", "two_streams")] + \
-               [("recuts", C.c_uint64), ("gather_root", C.c_int)]
+               [("recuts", C.c_uint64), ("gather_root", C.c_int), ("rccl_nonblocking", C.c_int),
+                ("init_timeout_ms", C.c_int), ("wait_timeout_ms", C.c_int), ("dead", C.c_int)]
 
 
 PWN_TILED_ID_BYTES = 128
@@ -103,6 +104,8 @@ ABI = [
     ("pwn_tiled_gather_root", _i, [_vp, _i]),
     ("pwn_tiled_get_info", _i, [_vp, C.POINTER(TiledInfo)]),
     ("pwn_tiled_shutdown", None, [_vp]),
+    ("pwn_tiled_set_timeouts", _i, [_vp, _i, _i]),
+    ("pwn_tiled_preflight", _i, [_vp, C.c_char_p, C.c_size_t]),
     ("pwn_tiled_balance", _i, [_vp, _i]),
     ("pwn_tiled_set_cuts", _i, [_vp, _vp, _i]),
     ("pwn_tiled_get_cuts", _i, [_vp, _vp, _vp]),

@@ -30,6 +30,7 @@ extern "C" const char *pwn_strerror(int code)
 		case PWN_ETOOBIG: return "sphere tables exceed the LDS budget";
 		case PWN_EBUSY: return "frame slot still in flight";
 		case PWN_ENOTSUP: return "not available (RCCL missing, or not configured)";
+		case PWN_ETIMEDOUT: return "the row tiling's deadline passed waiting for a peer";
 	}
 	return "unknown error";
 }
@@ -203,7 +204,7 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 	if(c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	if(c->up_stream) (void)hipStreamDestroy(c->up_stream);
 	(void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z); (void)hipFree(c->d_pre2);
-	(void)hipFree(c->d_wave_log);
+	(void)hipFree(c->d_wave_log); (void)hipFree(c->d_unit_cost);
 	(void)hipFree(c->d_skip); (void)hipFree(c->d_counters); (void)hipFree(c->d_tickets); (void)hipFree(c->d_scratch);
 	delete c;
 }
@@ -615,6 +616,14 @@ static void frame_setup(int w, int h, const float cam[16], pwn_trace_params *P)
 	}
 }
 
+// (the events of the launch history belong to frame slots / the row tiling: forget them where those go, with the
+// compute streams idle)
+void pwn_launch_history_clear(pwn_ctx *c)
+{
+	c->launch_stream[0] = c->launch_stream[1] = NULL;
+	c->launch_event[0] = c->launch_event[1] = NULL;
+}
+
 int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y1,
 	uint32_t *d_sbuf, float *d_zbuf, hipStream_t stream)
 {
@@ -716,16 +725,36 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 		const size_t entries = (size_t)grid * 4 + 1;
 		if(entries > c->wave_log_cap)
 		{
-			if(c->d_wave_log) { HIPCHK(c, hipStreamSynchronize(stream)); (void)hipFree(c->d_wave_log); c->d_wave_log = NULL; c->wave_log_cap = 0; }
+			// (a kernel of an earlier launch that writes the old buffer may be on either compute stream)
+			if(c->d_wave_log) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(c->d_wave_log); c->d_wave_log = NULL; c->wave_log_cap = 0; }
 			HIPCHK(c, hipMalloc((void **)&c->d_wave_log, entries * 16));
 			c->wave_log_cap = entries;
 		}
 		HIPCHK(c, hipMemsetAsync(c->d_wave_log, 0, c->wave_log_cap * 16, stream));
 		P.wave_log = c->d_wave_log;
+		// ... and every unit's cost (unit kernel only), for tools/unit_order_sim.py
+		if(!refill)
+		{
+			const size_t units = (size_t)P.tiles_total;
+			if(units > c->unit_cost_cap)
+			{
+				if(c->d_unit_cost) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(c->d_unit_cost); c->d_unit_cost = NULL; c->unit_cost_cap = 0; }
+				HIPCHK(c, hipMalloc((void **)&c->d_unit_cost, units * 2));
+				c->unit_cost_cap = units;
+			}
+			HIPCHK(c, hipMemsetAsync(c->d_unit_cost, 0, units * 2, stream));
+			P.unit_cost = c->d_unit_cost;
+			c->unit_cost_n = units;
+		}
 	}
+	// This launch clears the ticket set that the launch two before it drew from (above): it has to come after that one.
+	// On one stream and in the alternating pattern of two it does by itself; a launch that leaves the pattern waits.
+	if(c->launch_event[1] != NULL && c->launch_stream[1] != stream) HIPCHK(c, hipStreamWaitEvent(stream, c->launch_event[1], 0));
 	if(refill) HIPCHK(c, pwn_launch_trace_refill(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	else HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	c->ticket_set++;                     // only a launch that went out has cleared the other set
+	c->launch_stream[1] = c->launch_stream[0]; c->launch_event[1] = c->launch_event[0];
+	c->launch_stream[0] = stream; c->launch_event[0] = caller_event != NULL ? caller_event : c->ev_tables[cur];
 	if(caller_event != NULL)
 	{
 		// The caller is about to record this event again.  Its last record was behind a frame the caller has since
@@ -864,6 +893,7 @@ static void frames_release(pwn_ctx *c)
 		for(int i = 0; i < PWN_NBLOB; i++) c->tables_in_use[i] = false;
 	}
 	c->last_frame_done = NULL;       // (a slot's event, destroyed below)
+	pwn_launch_history_clear(c);
 	for(int i = 0; i < PWN_MAX_SLOTS; i++) slot_release(c->slot[i]);
 	c->nslots = 0;
 }
@@ -1069,6 +1099,13 @@ extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 		c->stats.wave_time = sum; c->stats.waves = n; c->stats.kernel_span = n ? last - first : 0;
 		if(const char *path = getenv("PWN_DBG_WAVE_LOG"))        // tools/wave_log.py: the raw log
 			if(FILE *fp = fopen(path, "wb")) { fwrite(log.data(), 8, log.size(), fp); fclose(fp); }
+		if(const char *path = getenv("PWN_DBG_UNIT_COST"))       // tools/unit_order_sim.py: u16 per unit, 40 ns each
+			if(c->d_unit_cost != NULL && c->unit_cost_n > 0)
+			{
+				std::vector<uint16_t> uc(c->unit_cost_n);
+				HIPCHK(c, hipMemcpy(uc.data(), c->d_unit_cost, uc.size() * 2, hipMemcpyDeviceToHost));
+				if(FILE *fp = fopen(path, "wb")) { fwrite(uc.data(), 2, uc.size(), fp); fclose(fp); }
+			}
 	}
 	*out = c->stats;
 	return PWN_OK;

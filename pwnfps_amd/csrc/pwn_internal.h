@@ -124,6 +124,7 @@ struct pwn_ctx
 	uint2 *d_skip;                   // blur LCG skip-ahead, w/4 entries
 	unsigned long long *d_counters;
 	unsigned long long *d_wave_log; int wave_log_on; size_t wave_log_cap;   // PWN_OPT_WAVE_LOG; entries (16 B) allocated
+	uint16_t *d_unit_cost; size_t unit_cost_cap, unit_cost_n;               // ... and what every unit of the launch cost its wave (pwn_trace_params.unit_cost)
 	bool dbg_force_hasw; int dbg_blocks_per_cu;      // PWN_DBG_* hooks, read at pwn_init
 	int dbg_blur_th, dbg_blur_tw, dbg_blur_batch;                 // PWN_DBG_BLUR_TH: tile height of every blur launch (8 / 16 / 32), 0 = the launcher's choice
 	int grid_reserve;                // workgroups the persistent trace grid leaves free (row tiling over RCCL), else 0
@@ -150,6 +151,13 @@ struct pwn_ctx
 	uint64_t frame_seq;
 
 	pwn_tiled *tiled;                // row tiling over RCCL, NULL until pwn_tiled_init
+	int tiled_init_ms, tiled_wait_ms;   // pwn_tiled_set_timeouts (0 = the default: environment, else 120 s / 60 s)
+
+	// The trace launch before the last one: the stream it went on and an event behind it.  Launch n clears the ticket set
+	// of launch n + 2 = the set launch n - 2 drew from, so it has to come after launch n - 2: true by itself on one
+	// stream and while frames alternate between two (n - 2 is then on n's stream), NOT when a launch leaves that pattern
+	// (a blocking call or a counted frame between alternating ones) -- pwn_i_launch_trace then waits for this event.
+	hipStream_t launch_stream[2]; hipEvent_t launch_event[2];     // [0] the last launch, [1] the one before
 
 	char err[256];
 };
@@ -161,5 +169,6 @@ struct pwn_ctx
 int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y1, uint32_t *d_sbuf, float *d_zbuf, hipStream_t stream);
 int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream,
 	int avail_y0, int avail_y1, uint32_t *d_miss, uint32_t *d_cost_acc, uint32_t *d_cost_out);
+void pwn_launch_history_clear(pwn_ctx *c);      // the launch-order events are about to be destroyed (streams idle)
 void pwn_tiled_destroy(pwn_ctx *c);
 bool pwn_tiled_busy(pwn_ctx *c);        // frames of the row tiling in flight

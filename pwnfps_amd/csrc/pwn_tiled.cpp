@@ -52,6 +52,12 @@
 #include <string.h>
 #include <new>
 #include <vector>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include <rccl/rccl.h>          // types only: the entry points are resolved at run time
 #include "pwn_internal.h"
@@ -66,8 +72,33 @@ struct pwn_transport
 	virtual int recv(void *d_dst, size_t bytes, int peer) = 0;
 	virtual int end() = 0;
 	virtual const char *name() const = 0;
+	// Deadlines (pwn_tiled_set_timeouts).  A transport never waits for a peer longer than wait_ms inside end(); `alive`
+	// asks it for an error that arrived asynchronously (a peer that died, a link that went down) while the caller polls
+	// an event; `abort` tears the connection down so that whatever it has on the device leaves -- after it the
+	// transport is dead (every later call fails) and its destructor frees nothing that the abort already freed.
+	virtual int alive() { return PWN_OK; }
+	virtual void abort() { dead = true; }
+	int wait_ms = 60000;
+	bool dead = false;
 	char err[200];
 };
+
+static double now_ms(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+static int env_ms(const char *name, int dflt)
+{
+	const char *e = getenv(name);
+	if(e == NULL || *e == 0) return dflt;
+	const long v = strtol(e, NULL, 10);
+	return (v > 0 && v < 86400000L) ? (int)v : dflt;
+}
+#define PWN_INIT_TIMEOUT_DEFAULT_MS 120000
+#define PWN_WAIT_TIMEOUT_DEFAULT_MS 60000
 
 // ---- RCCL over xGMI
 struct rccl_api
@@ -81,6 +112,13 @@ struct rccl_api
 	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
 	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
 	const char *(*GetErrorString)(ncclResult_t);
+	// present in every RCCL this was built against, but optional here: without them the non-blocking mode is refused and a
+	// deadline that passes cannot abort, only report
+	ncclResult_t (*CommInitRankConfig)(ncclComm_t *, int, ncclUniqueId, int, ncclConfig_t *);
+	ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *);
+	ncclResult_t (*CommAbort)(ncclComm_t);
+	ncclResult_t (*GetVersion)(int *);
+	char path[256];                 // the file dlopen resolved (dladdr of ncclGetUniqueId)
 };
 
 static rccl_api *rccl_load(char *err, size_t errlen)
@@ -99,27 +137,267 @@ static rccl_api *rccl_load(char *err, size_t errlen)
 	SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
 	SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+	*(void **)&api.CommInitRankConfig = dlsym(api.lib, "ncclCommInitRankConfig");
+	*(void **)&api.CommGetAsyncError = dlsym(api.lib, "ncclCommGetAsyncError");
+	*(void **)&api.CommAbort = dlsym(api.lib, "ncclCommAbort");
+	*(void **)&api.GetVersion = dlsym(api.lib, "ncclGetVersion");
+	{
+		Dl_info di;
+		api.path[0] = 0;
+		if(dladdr((void *)api.GetUniqueId, &di) != 0 && di.dli_fname != NULL) snprintf(api.path, sizeof(api.path), "%s", di.dli_fname);
+	}
 	state = 1;
 	return &api;
 }
 
+// How the communicator is driven (PWN_TILED_RCCL_MODE):
+//   blocking (default)  ncclCommInitRank and the first exchange with every peer -- the calls that wait for OTHER
+//                       processes -- run on a helper thread under the bring-up deadline; afterwards a grouped send / recv
+//                       launch only enqueues a kernel and returns, as in rounds 2-3, and what can still hang is that kernel
+//                       on the device: pwn_tiled_wait polls its events against the wait deadline.
+//   nonblocking         ncclCommInitRankConfig with blocking = 0: every call may return ncclInProgress and is polled with
+//                       ncclCommGetAsyncError against the deadline (a grouped launch is then handed to a thread of RCCL's
+//                       and this one waits for it).  Costs host time per group; `tiling.sweep` of bench.py times both.
+// On expiry, either way: ncclCommAbort, PWN_ETIMEDOUT, the transport is dead.
 struct rccl_transport : pwn_transport
 {
-	rccl_api *api; ncclComm_t comm; hipStream_t stream;
-	rccl_transport() : api(NULL), comm(NULL), stream(NULL) { err[0] = 0; }
-	~rccl_transport() { if(comm) (void)api->CommDestroy(comm); }
-	int chk(ncclResult_t r, const char *what)
+	rccl_api *api; ncclComm_t comm; hipStream_t stream; bool nb; int rank, world;
+	rccl_transport() : api(NULL), comm(NULL), stream(NULL), nb(false), rank(0), world(1) { err[0] = 0; }
+	~rccl_transport() { if(comm && !dead) (void)api->CommDestroy(comm); }
+	void abort()
+	{
+		if(!dead && comm && api->CommAbort) (void)api->CommAbort(comm);
+		dead = true;
+	}
+	// nonblocking: the call that returned ncclInProgress is complete when the communicator's state is ncclSuccess again
+	int settle(const char *what)
+	{
+		const double t0 = now_ms();
+		for(unsigned spins = 0;; spins++)
+		{
+			ncclResult_t st = ncclSuccess;
+			const ncclResult_t q = api->CommGetAsyncError(comm, &st);
+			if(q != ncclSuccess) { snprintf(err, sizeof(err), "rank %d: ncclCommGetAsyncError after %s: %s", rank, what, api->GetErrorString(q)); dead = true; return PWN_EHIP; }
+			if(st == ncclSuccess) return PWN_OK;
+			if(st != ncclInProgress) { snprintf(err, sizeof(err), "rank %d: %s: %s", rank, what, api->GetErrorString(st)); abort(); return PWN_EHIP; }
+			if(now_ms() - t0 > (double)wait_ms)
+			{
+				abort();
+				snprintf(err, sizeof(err), "rank %d of %d: %s still in progress after %d ms; communicator aborted", rank, world, what, wait_ms);
+				return PWN_ETIMEDOUT;
+			}
+			if(spins > 500) { struct timespec ts = { 0, 20 * 1000 }; nanosleep(&ts, NULL); }
+		}
+	}
+	int chk(ncclResult_t r, const char *what, bool wait_here)
 	{
 		if(r == ncclSuccess) return PWN_OK;
-		snprintf(err, sizeof(err), "%s: %s", what, api->GetErrorString(r));
+		if(r == ncclInProgress && nb) return wait_here ? settle(what) : PWN_OK;
+		snprintf(err, sizeof(err), "rank %d: %s: %s", rank, what, api->GetErrorString(r));
 		return PWN_EHIP;
 	}
-	int begin(hipStream_t s) { stream = s; return chk(api->GroupStart(), "ncclGroupStart"); }
-	int send(const void *p, size_t n, int peer) { return chk(api->Send(p, n, ncclUint8, peer, comm, stream), "ncclSend"); }
-	int recv(void *p, size_t n, int peer) { return chk(api->Recv(p, n, ncclUint8, peer, comm, stream), "ncclRecv"); }
-	int end() { return chk(api->GroupEnd(), "ncclGroupEnd"); }
+	int begin(hipStream_t s)
+	{
+		if(dead) { snprintf(err, sizeof(err), "rank %d: the communicator is gone (aborted earlier)", rank); return PWN_ETIMEDOUT; }
+		stream = s; return chk(api->GroupStart(), "ncclGroupStart", true);
+	}
+	int send(const void *p, size_t n, int peer) { return chk(api->Send(p, n, ncclUint8, peer, comm, stream), "ncclSend", false); }
+	int recv(void *p, size_t n, int peer) { return chk(api->Recv(p, n, ncclUint8, peer, comm, stream), "ncclRecv", false); }
+	int end() { return chk(api->GroupEnd(), "ncclGroupEnd", true); }
+	int alive()
+	{
+		if(dead) return PWN_ETIMEDOUT;
+		if(api->CommGetAsyncError == NULL) return PWN_OK;
+		ncclResult_t st = ncclSuccess;
+		if(api->CommGetAsyncError(comm, &st) != ncclSuccess) return PWN_OK;
+		if(st == ncclSuccess || st == ncclInProgress) return PWN_OK;
+		snprintf(err, sizeof(err), "rank %d: the communicator reports %s", rank, api->GetErrorString(st));
+		return PWN_EHIP;
+	}
 	const char *name() const { return "rccl"; }
 };
+
+// ---- bring-up of the RCCL communicator under a deadline: ncclCommInitRank, then one word to and from EVERY other
+// rank (to itself when alone) in one grouped launch, so that every connection a frame will use -- RCCL connects a pair
+// of ranks the first time they talk -- exists when pwn_tiled_init returns, and a peer that is not there is found out
+// here, under init_ms, not in the middle of the first frame.  Self-contained (its own stream and four-byte buffers, owned
+// by the shared state): in blocking mode it runs on a helper thread that the caller may have to leave behind.
+struct rccl_bringup
+{
+	std::mutex m; std::condition_variable cv; bool done = false;
+	std::atomic<int> stage{0};                     // 0 not started, 1 in ncclCommInitRank, 2 in the first exchange, 3 through
+	std::atomic<ncclComm_t> comm{nullptr};
+	std::atomic<bool> abandon{false};             // the deadline passed: whatever still runs gives up at its next look
+	int rc = PWN_OK; char err[200] = { 0 };
+	hipStream_t s = NULL; uint32_t *d = NULL;      // owned: freed by the last holder
+	int device = 0;
+	~rccl_bringup() { (void)hipSetDevice(device); if(d) (void)hipFree(d); if(s) (void)hipStreamDestroy(s); }
+};
+static const char *bringup_stage(int st)
+{
+	return st <= 0 ? "before ncclCommInitRank" : st == 1 ? "inside ncclCommInitRank (a rank that never called it, or no route to it)" :
+	       st == 2 ? "in the first exchange with every other rank (a connection that does not come up, or a peer that left)" : "done";
+}
+static void rccl_bringup_run(rccl_api *api, std::shared_ptr<rccl_bringup> st, ncclUniqueId uid, int world, int rank, bool nb, double deadline)
+{
+	rccl_bringup &b = *st;
+#define FAIL(code, ...) do { snprintf(b.err, sizeof(b.err), __VA_ARGS__); b.rc = (code); return; } while(0)
+	if(hipSetDevice(b.device) != hipSuccess) FAIL(PWN_EHIP, "rank %d: hipSetDevice(%d) failed", rank, b.device);
+	// nonblocking: wait for the communicator to settle; with a deadline of its own (no helper thread in this mode)
+	auto settle = [&](ncclComm_t cm, const char *what) -> int
+	{
+		for(unsigned spins = 0;; spins++)
+		{
+			ncclResult_t a = ncclSuccess;
+			const ncclResult_t q = api->CommGetAsyncError(cm, &a);
+			if(q != ncclSuccess) { snprintf(b.err, sizeof(b.err), "rank %d: ncclCommGetAsyncError after %s: %s", rank, what, api->GetErrorString(q)); return PWN_EHIP; }
+			if(a == ncclSuccess) return PWN_OK;
+			if(a != ncclInProgress) { snprintf(b.err, sizeof(b.err), "rank %d: %s: %s", rank, what, api->GetErrorString(a)); return PWN_EHIP; }
+			if(now_ms() > deadline || b.abandon.load()) { snprintf(b.err, sizeof(b.err), "rank %d of %d: %s still in progress at the bring-up deadline", rank, world, what); return PWN_ETIMEDOUT; }
+			if(spins > 200) { struct timespec ts = { 0, 50 * 1000 }; nanosleep(&ts, NULL); }
+		}
+	};
+	b.stage = 1;
+	ncclComm_t cm = NULL;
+	if(nb)
+	{
+		ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+		cfg.blocking = 0;
+		const ncclResult_t r = api->CommInitRankConfig(&cm, world, uid, rank, &cfg);
+		b.comm = cm;
+		if(r != ncclSuccess && r != ncclInProgress) FAIL(PWN_EHIP, "rank %d: ncclCommInitRankConfig: %s", rank, api->GetErrorString(r));
+		const int rc = settle(cm, "ncclCommInitRankConfig");
+		if(rc != PWN_OK) { b.rc = rc; return; }
+	}
+	else
+	{
+		const ncclResult_t r = api->CommInitRank(&cm, world, uid, rank);
+		b.comm = cm;
+		if(r != ncclSuccess) FAIL(PWN_EHIP, "rank %d: ncclCommInitRank: %s", rank, api->GetErrorString(r));
+	}
+	if(b.abandon.load())
+	{
+		// the caller gave up while this thread sat in ncclCommInitRank: whoever takes the handle out of the state aborts it
+		ncclComm_t mine = b.comm.exchange(nullptr);
+		if(mine && api->CommAbort) (void)api->CommAbort(mine);
+		FAIL(PWN_ETIMEDOUT, "rank %d: abandoned after ncclCommInitRank", rank);
+	}
+	b.stage = 2;
+	// d[0] = this rank's word, d[1 + r] = what rank r sent
+	if(hipStreamCreateWithFlags(&b.s, hipStreamNonBlocking) != hipSuccess) FAIL(PWN_EHIP, "rank %d: hipStreamCreate failed", rank);
+	if(hipMalloc((void **)&b.d, (size_t)(world + 1) * 4) != hipSuccess) FAIL(PWN_ENOMEM, "rank %d: hipMalloc failed", rank);
+	std::vector<uint32_t> h((size_t)world + 1, 0u);
+	h[0] = 0x50574e00u + (uint32_t)rank;
+	if(hipMemcpy(b.d, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) FAIL(PWN_EHIP, "rank %d: hipMemcpy failed", rank);
+	{
+		ncclResult_t r = api->GroupStart();
+		if(r != ncclSuccess && !(nb && r == ncclInProgress)) FAIL(PWN_EHIP, "rank %d: ncclGroupStart: %s", rank, api->GetErrorString(r));
+		for(int k = 0; k < world; k++)
+		{
+			const int peer = world == 1 ? 0 : k;
+			if(world > 1 && peer == rank) continue;
+			r = api->Send(b.d, 4, ncclUint8, peer, cm, b.s);
+			if(r != ncclSuccess && !(nb && r == ncclInProgress)) { (void)api->GroupEnd(); FAIL(PWN_EHIP, "rank %d: ncclSend to %d: %s", rank, peer, api->GetErrorString(r)); }
+			r = api->Recv(b.d + 1 + peer, 4, ncclUint8, peer, cm, b.s);
+			if(r != ncclSuccess && !(nb && r == ncclInProgress)) { (void)api->GroupEnd(); FAIL(PWN_EHIP, "rank %d: ncclRecv from %d: %s", rank, peer, api->GetErrorString(r)); }
+			if(world == 1) break;
+		}
+		r = api->GroupEnd();
+		if(nb && (r == ncclInProgress || r == ncclSuccess)) { const int rc = settle(cm, "the first ncclGroupEnd"); if(rc != PWN_OK) { b.rc = rc; return; } }
+		else if(r != ncclSuccess) FAIL(PWN_EHIP, "rank %d: ncclGroupEnd: %s", rank, api->GetErrorString(r));
+	}
+	// the launch is on the stream: it ends when every peer's word is here
+	for(unsigned spins = 0;; spins++)
+	{
+		const hipError_t e = hipStreamQuery(b.s);
+		if(e == hipSuccess) break;
+		if(e != hipErrorNotReady) FAIL(PWN_EHIP, "rank %d: the first exchange failed on the device: %s", rank, hipGetErrorString(e));
+		if(now_ms() > deadline || b.abandon.load()) FAIL(PWN_ETIMEDOUT, "rank %d of %d: the first exchange did not complete before the bring-up deadline", rank, world);
+		if(api->CommGetAsyncError != NULL && (spins & 63u) == 63u)
+		{
+			ncclResult_t a = ncclSuccess;
+			if(api->CommGetAsyncError(cm, &a) == ncclSuccess && a != ncclSuccess && a != ncclInProgress)
+				FAIL(PWN_EHIP, "rank %d: the first exchange: %s", rank, api->GetErrorString(a));
+		}
+		struct timespec ts = { 0, 100 * 1000 };
+		nanosleep(&ts, NULL);
+	}
+	(void)hipGetLastError();
+	if(hipMemcpy(h.data(), b.d, h.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) FAIL(PWN_EHIP, "rank %d: hipMemcpy failed", rank);
+	for(int k = 0; k < world; k++)
+	{
+		if(world > 1 && k == rank) continue;
+		if(h[1 + (size_t)k] != 0x50574e00u + (uint32_t)k)
+			FAIL(PWN_EHIP, "rank %d: the test word from rank %d arrived as %08x", rank, k, h[1 + (size_t)k]);
+	}
+	b.stage = 3;
+#undef FAIL
+}
+
+// returns PWN_OK with *out = the communicator, or an error with `err` filled; never hangs longer than init_ms (+ 5 s)
+static int rccl_bringup_bounded(rccl_api *api, int device, const ncclUniqueId &uid, int world, int rank, bool nb, int init_ms,
+	ncclComm_t *out, char *err, size_t errlen)
+{
+	std::shared_ptr<rccl_bringup> st = std::make_shared<rccl_bringup>();
+	st->device = device;
+	const double deadline = now_ms() + (double)init_ms;
+	*out = NULL;
+	if(nb)
+	{
+		// every wait inside polls against the deadline itself
+		rccl_bringup_run(api, st, uid, world, rank, true, deadline);
+		ncclComm_t cm = st->comm.load();
+		if(st->rc != PWN_OK)
+		{
+			st->comm = nullptr;
+			if(cm && api->CommAbort) (void)api->CommAbort(cm);
+			snprintf(err, errlen, "%s [stage: %s; limit %d ms; nonblocking]", st->err, bringup_stage(st->stage.load()), init_ms);
+			return st->rc;
+		}
+		*out = cm;
+		return PWN_OK;
+	}
+	std::thread th([api, st, uid, world, rank, deadline]()
+	{
+		rccl_bringup_run(api, st, uid, world, rank, false, deadline);
+		{ std::lock_guard<std::mutex> g(st->m); st->done = true; }
+		st->cv.notify_all();
+	});
+	bool through;
+	{
+		std::unique_lock<std::mutex> lk(st->m);
+		through = st->cv.wait_for(lk, std::chrono::milliseconds(init_ms), [&] { return st->done; });
+	}
+	if(!through)
+	{
+		// The helper sits in a call that waits for another process.  With a communicator in hand ncclCommAbort makes that
+		// call return; inside ncclCommInitRank there is none yet, and the thread is left behind (it owns everything it uses).
+		st->abandon = true;
+		{ struct timespec ts = { 0, 2 * 1000 * 1000 }; nanosleep(&ts, NULL); }      // (a helper that polls sees the flag before the handle goes)
+		ncclComm_t cm = st->comm.exchange(nullptr);
+		const int stage = st->stage.load();
+		if(cm && api->CommAbort) (void)api->CommAbort(cm);
+		{
+			std::unique_lock<std::mutex> lk(st->m);
+			through = st->cv.wait_for(lk, std::chrono::milliseconds(5000), [&] { return st->done; });
+		}
+		if(through) th.join(); else th.detach();
+		snprintf(err, errlen, "rank %d of %d: the RCCL bring-up did not finish within %d ms; it was %s%s", rank, world, init_ms,
+			bringup_stage(stage), cm ? "; communicator aborted" : "");
+		return PWN_ETIMEDOUT;
+	}
+	th.join();
+	if(st->rc != PWN_OK)
+	{
+		ncclComm_t cm = st->comm.exchange(nullptr);
+		if(cm && st->rc == PWN_ETIMEDOUT && api->CommAbort) (void)api->CommAbort(cm);
+		else if(cm) (void)api->CommDestroy(cm);
+		snprintf(err, errlen, "%s [stage: %s; limit %d ms]", st->err, bringup_stage(st->stage.load()), init_ms);
+		return st->rc;
+	}
+	*out = st->comm.load();
+	return PWN_OK;
+}
 
 // ---- shared memory through the host (tests: several ranks on ONE GPU).  One mailbox per
 // ordered pair of ranks: a ring of SHM_SLOTS messages of at most `slot_bytes`; a sender copies
@@ -176,16 +454,29 @@ struct shm_transport : pwn_transport
 		if(base == (unsigned char *)MAP_FAILED) { base = NULL; snprintf(err, sizeof(err), "mmap(%s): %s", shm_name, strerror(errno)); return PWN_ENOMEM; }
 		return PWN_OK;
 	}
-	int begin(hipStream_t s) { stream = s; ops.clear(); return PWN_OK; }
+	int begin(hipStream_t s)
+	{
+		if(dead) { snprintf(err, sizeof(err), "rank %d: the transport is dead (a deadline passed earlier)", rank); return PWN_ETIMEDOUT; }
+		stream = s; ops.clear(); return PWN_OK;
+	}
 	int send(const void *p, size_t n, int peer) { op o = { true, p, NULL, n, peer }; ops.push_back(o); return n <= slot_bytes ? PWN_OK : PWN_EINVAL; }
 	int recv(void *p, size_t n, int peer) { op o = { false, NULL, p, n, peer }; ops.push_back(o); return n <= slot_bytes ? PWN_OK : PWN_EINVAL; }
 	int wait_until(volatile unsigned long long *word, unsigned long long at_least)
 	{
-		// a peer that died must not hang the test: give up after two minutes
+		// a peer that died must not hang its neighbours: give up at the deadline (pwn_tiled_set_timeouts)
+		const double t0 = now_ms();
 		for(unsigned long long spins = 0; __atomic_load_n(word, __ATOMIC_ACQUIRE) < at_least; spins++)
 		{
-			if(spins > 200ull * 120ull * 50ull) { snprintf(err, sizeof(err), "shm transport: peer did not answer"); return PWN_EIO; }
-			if(spins > 2000) { struct timespec ts = { 0, 100 * 1000 }; nanosleep(&ts, NULL); }
+			if(spins > 2000)
+			{
+				if(now_ms() - t0 > (double)wait_ms)
+				{
+					dead = true;
+					snprintf(err, sizeof(err), "rank %d of %d: a peer did not answer within %d ms", rank, world, wait_ms);
+					return PWN_ETIMEDOUT;
+				}
+				struct timespec ts = { 0, 100 * 1000 }; nanosleep(&ts, NULL);
+			}
 		}
 		return PWN_OK;
 	}
@@ -261,7 +552,8 @@ struct pwn_tiled
 	// group that carried its gather (that is G(f+2)'s event or the drain group's)
 	hipEvent_t ev_t[NSLOT], ev_x[NSLOT], ev_b[NSLOT], ev_d[NSLOT];
 	hipEvent_t ev_k0[NSLOT], ev_k1[NSLOT], ev_k2[NSLOT], ev_k3[NSLOT];      // timing (PWN_OPT_FRAME_TIMING): around the trace, around the blur
-	hipEvent_t ev_g0[NSLOT], ev_g1[NSLOT], ev_g2[NSLOT];                    // ... on the comm stream: in front of the gather group, between the groups, behind the halo group
+	hipEvent_t ev_g0[NSLOT], ev_g1[NSLOT], ev_g2[NSLOT], ev_g3[NSLOT];      // ... on the comm stream: around the gather group (g0, g1), around the halo group (g2, g3)
+	hipStream_t fstream[NSLOT];         // the compute stream the slot's frame is on: cs[f & 1], or cs[0] for a counted frame (one set of counters)
 	hipEvent_t gathered_by[NSLOT];      // which of the above marks the slot's gather as done
 	// host sink: NSLOT whole frames in host memory shared by the ranks; this rank's copies on their own stream
 	uint8_t *host_base; void *host_registered;   // the frames; what this context registered with the device (or NULL)
@@ -276,6 +568,63 @@ struct pwn_tiled
 
 #define TPCHK(c, call) do { int rc_ = (call); if(rc_ != PWN_OK) { snprintf((c)->err, sizeof((c)->err), "%s transport: %s", \
 	(c)->tiled->tp->name(), (c)->tiled->tp->err); return rc_; } } while(0)
+
+static int init_timeout_ms(const pwn_ctx *c) { return c->tiled_init_ms > 0 ? c->tiled_init_ms : env_ms("PWN_TILED_INIT_TIMEOUT_MS", PWN_INIT_TIMEOUT_DEFAULT_MS); }
+static int wait_timeout_ms(const pwn_ctx *c) { return c->tiled_wait_ms > 0 ? c->tiled_wait_ms : env_ms("PWN_TILED_WAIT_TIMEOUT_MS", PWN_WAIT_TIMEOUT_DEFAULT_MS); }
+static bool rccl_mode_nonblocking(void)
+{
+	const char *e = getenv("PWN_TILED_RCCL_MODE");
+	return e != NULL && (strcmp(e, "nonblocking") == 0 || strcmp(e, "nb") == 0);
+}
+
+extern "C" int pwn_tiled_set_timeouts(pwn_ctx *c, int init_ms, int wait_ms)
+{
+	if(c == NULL) return PWN_EINVAL;
+	if(init_ms != 0) c->tiled_init_ms = init_ms > 0 ? init_ms : 0;
+	if(wait_ms != 0) c->tiled_wait_ms = wait_ms > 0 ? wait_ms : 0;
+	if(c->tiled != NULL)
+	{
+		if(c->tiled->tp != NULL) c->tiled->tp->wait_ms = wait_timeout_ms(c);
+		c->tiled->info.init_timeout_ms = init_timeout_ms(c); c->tiled->info.wait_timeout_ms = wait_timeout_ms(c);
+	}
+	return PWN_OK;
+}
+
+// What a first multi-GPU run wants on record before it starts (pwnhip.h).  No tiling needed.
+extern "C" int pwn_tiled_preflight(pwn_ctx *c, char *json, size_t n)
+{
+	if(c == NULL || json == NULL || n < 2) return PWN_EINVAL;
+	(void)hipSetDevice(c->device);
+	int count = 0;
+	if(hipGetDeviceCount(&count) != hipSuccess) count = 0;
+	char peers[512]; size_t pl = 0;
+	peers[0] = 0;
+	for(int d = 0; d < count && pl + 8 < sizeof(peers); d++)
+	{
+		int can = d == c->device ? 1 : 0;
+		if(d != c->device && hipDeviceCanAccessPeer(&can, c->device, d) != hipSuccess) { (void)hipGetLastError(); can = -1; }
+		pl += (size_t)snprintf(peers + pl, sizeof(peers) - pl, "%s%d", d ? "," : "", can);
+	}
+	char err[200]; err[0] = 0;
+	rccl_api *api = rccl_load(err, sizeof(err));
+	int ver = 0;
+	if(api != NULL && api->GetVersion != NULL) (void)api->GetVersion(&ver);
+	char pci[32]; pci[0] = 0;
+	if(hipDeviceGetPCIBusId(pci, (int)sizeof(pci), c->device) != hipSuccess) { (void)hipGetLastError(); pci[0] = 0; }
+	const char *ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+	const int len = snprintf(json, n,
+		"{\"device\": %d, \"pci\": \"%s\", \"devices_visible\": %d, \"can_access_peer\": [%s], "
+		"\"librccl\": %s%s%s, \"rccl_version\": %d, \"rccl_has_nonblocking_api\": %s, \"rccl_has_abort\": %s, "
+		"\"rccl_mode\": \"%s\", \"init_timeout_ms\": %d, \"wait_timeout_ms\": %d, \"HSA_ENABLE_IPC_MODE_LEGACY\": %s%s%s%s%s%s}",
+		c->device, pci, count, peers,
+		api ? "\"" : "", api ? api->path : "null", api ? "\"" : "", ver,
+		(api && api->CommInitRankConfig && api->CommGetAsyncError) ? "true" : "false", (api && api->CommAbort) ? "true" : "false",
+		rccl_mode_nonblocking() ? "nonblocking" : "blocking", init_timeout_ms(c), wait_timeout_ms(c),
+		ipc ? "\"" : "", ipc ? ipc : "null", ipc ? "\"" : "",
+		api ? "" : ", \"librccl_error\": \"", api ? "" : err, api ? "" : "\"");
+	if(len < 0) return PWN_EINVAL;
+	return len < (int)n ? len : (int)n - 1;
+}
 
 static int strip_rows(int h, int world)
 {
@@ -381,13 +730,14 @@ void pwn_tiled_destroy(pwn_ctx *c)
 	// (the device is idle: no copy of the tables is in use, and the events that said so -- ev_t, handed to the trace
 	// launches as pwn_ctx.trace_tables_event -- are destroyed below)
 	for(int i = 0; i < PWN_NBLOB; i++) c->tables_in_use[i] = false;
+	pwn_launch_history_clear(c);
 	delete t->tp;
 	for(int s = 0; s < NSLOT; s++)
 	{
 		(void)hipFree(t->pre[s]); (void)hipFree(t->out[s]); (void)hipFree(t->fin[s]); (void)hipFree(t->z[s]);
 		(void)hipFree(t->missw[s]); (void)hipFree(t->missv[s]);
 		hipEvent_t *evs[] = { &t->ev_t[s], &t->ev_x[s], &t->ev_b[s], &t->ev_d[s], &t->ev_k0[s], &t->ev_k1[s], &t->ev_k2[s], &t->ev_k3[s],
-			&t->ev_g0[s], &t->ev_g1[s], &t->ev_g2[s], &t->ev_h[s] };
+			&t->ev_g0[s], &t->ev_g1[s], &t->ev_g2[s], &t->ev_g3[s], &t->ev_h[s] };
 		for(size_t i = 0; i < sizeof(evs) / sizeof(evs[0]); i++) if(*evs[i]) (void)hipEventDestroy(*evs[i]);
 	}
 	(void)hipFree(t->cost_acc);
@@ -449,20 +799,29 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 		{
 			rccl_api *api = rccl_load(c->err, sizeof(c->err));
 			if(api == NULL) { rc = PWN_ENOTSUP; break; }
+			const bool nb = rccl_mode_nonblocking();
+			if(nb && (api->CommInitRankConfig == NULL || api->CommGetAsyncError == NULL))
+			{
+				snprintf(c->err, sizeof(c->err), "PWN_TILED_RCCL_MODE=nonblocking: this librccl (%s) has no ncclCommInitRankConfig / ncclCommGetAsyncError", api->path);
+				rc = PWN_ENOTSUP; break;
+			}
 			rccl_transport *rt = new(std::nothrow) rccl_transport();
 			if(rt == NULL) { rc = PWN_ENOMEM; break; }
-			rt->api = api;
+			rt->api = api; rt->nb = nb; rt->rank = rank; rt->world = world; rt->wait_ms = wait_timeout_ms(c);
 			t->tp = rt;
 			ncclUniqueId uid;
 			memcpy(&uid, id, sizeof(uid));
-			ncclResult_t r = api->CommInitRank(&rt->comm, world, uid, rank);
-			if(r != ncclSuccess) { snprintf(c->err, sizeof(c->err), "ncclCommInitRank: %s", api->GetErrorString(r)); rc = PWN_EHIP; break; }
+			// the communicator and one word to and from every other rank, under the bring-up deadline
+			rc = rccl_bringup_bounded(api, c->device, uid, world, rank, nb, init_timeout_ms(c), &rt->comm, c->err, sizeof(c->err));
+			if(rc != PWN_OK) { rt->dead = true; break; }
+			t->info.rccl_nonblocking = nb ? 1 : 0;
 		}
 		else if(transport == PWN_TRANSPORT_SHM)
 		{
 			shm_transport *st = new(std::nothrow) shm_transport();
 			if(st == NULL) { rc = PWN_ENOMEM; break; }
 			t->tp = st;
+			st->wait_ms = wait_timeout_ms(c);
 			char name[PWN_TILED_ID_BYTES];
 			memcpy(name, id, sizeof(name)); name[sizeof(name) - 1] = 0;
 			rc = st->open_region(name, rank, world, strip_bytes);
@@ -500,22 +859,28 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 			   hipEventCreate(&t->ev_k0[s]) != hipSuccess || hipEventCreate(&t->ev_k1[s]) != hipSuccess ||
 			   hipEventCreate(&t->ev_k2[s]) != hipSuccess || hipEventCreate(&t->ev_k3[s]) != hipSuccess ||
 			   hipEventCreate(&t->ev_g0[s]) != hipSuccess || hipEventCreate(&t->ev_g1[s]) != hipSuccess ||
-			   hipEventCreate(&t->ev_g2[s]) != hipSuccess) { rc = PWN_EHIP; break; }
+			   hipEventCreate(&t->ev_g2[s]) != hipSuccess || hipEventCreate(&t->ev_g3[s]) != hipSuccess) { rc = PWN_EHIP; break; }
 		}
 		if(rc != PWN_OK) break;
 		if(hipHostMalloc((void **)&t->h_missv, (size_t)NSLOT * ((size_t)world + 1) * 8, hipHostMallocDefault) != hipSuccess) { rc = PWN_ENOMEM; break; }
 		memset(t->h_missv, 0, (size_t)NSLOT * ((size_t)world + 1) * 8);
 		// one round trip through the transport before the first frame depends on it: every rank sends a
 		// word to its right-hand neighbour (to itself when alone) and checks what arrives from the left
+		// (the RCCL bring-up above has exchanged a word with EVERY rank already)
+		if(transport != PWN_TRANSPORT_RCCL)
 		{
 			const int to = (rank + 1) % world, from = (rank + world - 1) % world;
 			const uint32_t mine = 0x50574e00u + (uint32_t)rank, want = 0x50574e00u + (uint32_t)from;
 			uint32_t got = 0;
 			if(hipMemcpy(t->missw[0], &mine, 4, hipMemcpyHostToDevice) != hipSuccess) { rc = PWN_EHIP; break; }
-			if(t->tp->begin(t->comm) != PWN_OK || t->tp->send(t->missw[0], 4, to) != PWN_OK ||
-			   t->tp->recv(t->missv[0], 4, from) != PWN_OK || t->tp->end() != PWN_OK)
+			int trc = t->tp->begin(t->comm);
+			if(trc == PWN_OK) trc = t->tp->send(t->missw[0], 4, to);
+			if(trc == PWN_OK) trc = t->tp->recv(t->missv[0], 4, from);
+			if(trc == PWN_OK) trc = t->tp->end();
+			if(trc != PWN_OK)
 			{
-				snprintf(c->err, sizeof(c->err), "%s transport: %s", t->tp->name(), t->tp->err); rc = PWN_EHIP; break;
+				// (a peer that is not there: PWN_ETIMEDOUT after the wait deadline, with the rank in the text)
+				snprintf(c->err, sizeof(c->err), "%s transport: %s", t->tp->name(), t->tp->err); rc = trc == PWN_ETIMEDOUT ? trc : PWN_EHIP; break;
 			}
 			if(hipStreamSynchronize(t->comm) != hipSuccess || hipMemcpy(&got, t->missv[0], 4, hipMemcpyDeviceToHost) != hipSuccess ||
 			   hipMemset(t->missw[0], 0, 4) != hipSuccess || hipMemset(t->missv[0], 0, 4) != hipSuccess) { rc = PWN_EHIP; break; }
@@ -541,6 +906,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	t->info.rank = rank; t->info.world = world; t->info.y0 = t->cuts[rank]; t->info.y1 = t->cuts[rank + 1]; t->info.rows_per_rank = t->per;
 	t->info.halo_rows = t->halo; t->info.transport = transport;
 	t->info.max_rows = t->max_rows; t->info.grid_reserve = c->grid_reserve; t->info.two_streams = t->cs[1] != t->cs[0];
+	t->info.init_timeout_ms = init_timeout_ms(c); t->info.wait_timeout_ms = wait_timeout_ms(c);
 	return PWN_OK;
 }
 
@@ -635,6 +1001,7 @@ extern "C" int pwn_tiled_get_info(pwn_ctx *c, pwn_tiled_info *out)
 	t->info.halo_rows = t->halo;
 	t->info.y0 = t->cuts[t->rank]; t->info.y1 = t->cuts[t->rank + 1];
 	t->info.balance_every = t->balance_every;
+	t->info.dead = (t->tp != NULL && t->tp->dead) ? 1 : 0;
 	*out = t->info;
 	return PWN_OK;
 }
@@ -726,7 +1093,7 @@ static int copy_strip_to_host(pwn_ctx *c, pwn_tiled *t, int s)
 static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 {
 	const int s = (int)(k % NSLOT);
-	hipStream_t cs = t->cs[k & 1u];
+	hipStream_t cs = t->fstream[s];
 	int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
 	if(c->blur_passes)
 	{
@@ -765,12 +1132,22 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	if(c == NULL || cam == NULL || c->tiled == NULL) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
 	if(t->submitted - t->delivered >= NSLOT - 1) return PWN_EBUSY;
+	if(t->tp->dead) { snprintf(c->err, sizeof(c->err), "%s transport: dead (%s)", t->tp->name(), t->tp->err); return PWN_ETIMEDOUT; }
 	(void)hipSetDevice(c->device);
 	const double t_in = now_us();
 	const unsigned long long f = t->submitted;
 	const int s = (int)(f % NSLOT);
 	const size_t w4 = (size_t)c->w * 4;
-	hipStream_t cs = t->cs[f & 1u];
+	// A counted frame (PWN_OPT_COUNTERS, PWN_OPT_WAVE_LOG) goes on cs[0] whatever its parity: there is ONE set of
+	// counters and one wave log, which a launch clears at its start -- two counted grids side by side would clear
+	// each other's (and a wave log that grows would be freed under the other stream's kernel).  pwn_i_launch_trace
+	// orders a launch that leaves the alternating pattern behind the launch two before it (the ticket sets).
+	const bool counted = c->counters_on || c->wave_log_on;
+	hipStream_t cs = counted ? t->cs[0] : t->cs[f & 1u];
+	t->fstream[s] = cs;
+	// (a counted frame right behind an uncounted one on the OTHER stream: wait for that frame's trace, so that the
+	// counters and the wave log are this launch's alone)
+	if(counted && f > 0 && t->fstream[(f - 1) % NSLOT] != cs) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_t[(f - 1) % NSLOT], 0));
 	t->fhalo[s] = t->halo;
 	t->froot[s] = t->root_mode == PWN_TILED_ROOT_ROTATE ? (int)(f % (unsigned long long)t->world) : 0;
 	memcpy(t->fcuts[s], t->cuts, sizeof(t->cuts));
@@ -857,10 +1234,53 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 		TPCHK(c, t->tp->end());
 		t->info.groups++;
 	}
+	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g3[s], t->comm));       // (ev_x carries no time stamp)
 	HIPCHK(c, hipEventRecord(t->ev_x[s], t->comm));
 	t->submitted = f + 1;
 	t->enqueue_us[s] = (float)(now_us() - t_in);
 	return PWN_OK;
+}
+
+// Block until `ev` has happened -- but not for longer than the wait deadline, and not past an error the transport
+// reports meanwhile.  What a frame waits for may sit behind a kernel of the transport that itself waits for a peer: a
+// peer that never sends would hold hipEventSynchronize for ever.  On expiry the transport is aborted (its kernels
+// leave the device) and the tiling is dead.
+static int wait_event(pwn_ctx *c, pwn_tiled *t, hipEvent_t ev, const char *what, unsigned long long frame)
+{
+	hipError_t e = hipEventQuery(ev);
+	if(e == hipSuccess) return PWN_OK;
+	const double t0 = now_ms();
+	double look = t0 + 2.0;
+	for(unsigned spins = 0;; spins++)
+	{
+		e = hipEventQuery(ev);
+		if(e == hipSuccess) { (void)hipGetLastError(); return PWN_OK; }
+		if(e != hipErrorNotReady) { snprintf(c->err, sizeof(c->err), "rank %d: frame %llu, %s: %s", t->rank, frame, what, hipGetErrorString(e)); return PWN_EHIP; }
+		if(spins < 4000u) continue;              // the usual wait is a fraction of a millisecond: no clock, no sleep
+		const double now = now_ms();
+		if(now >= look)
+		{
+			look = now + 5.0;
+			const int rc = t->tp->alive();
+			if(rc != PWN_OK && !t->tp->dead)
+			{
+				t->tp->abort();
+				snprintf(c->err, sizeof(c->err), "%s transport: %s (frame %llu, waiting for %s); aborted", t->tp->name(), t->tp->err, frame, what);
+				return rc;
+			}
+		}
+		if(now - t0 > (double)t->tp->wait_ms)
+		{
+			t->tp->abort();
+			snprintf(c->err, sizeof(c->err), "rank %d of %d: frame %llu: %s not reached within %d ms (submitted %llu, blurred %llu, gathered %llu, "
+				"delivered %llu); %s transport aborted", t->rank, t->world, frame, what, t->tp->wait_ms, t->submitted, t->blurred, t->gathered,
+				t->delivered, t->tp->name());
+			snprintf(t->tp->err, sizeof(t->tp->err), "deadline passed at frame %llu (%s)", frame, what);
+			return PWN_ETIMEDOUT;
+		}
+		struct timespec ts = { 0, 20 * 1000 };
+		nanosleep(&ts, NULL);
+	}
 }
 
 extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
@@ -868,6 +1288,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	if(c == NULL || c->tiled == NULL) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
 	if(t->delivered >= t->submitted) return PWN_EINVAL;          // nothing in flight
+	if(t->tp->dead) { snprintf(c->err, sizeof(c->err), "%s transport: dead (%s)", t->tp->name(), t->tp->err); return PWN_ETIMEDOUT; }
 	(void)hipSetDevice(c->device);
 	const unsigned long long d = t->delivered;
 	const int s = (int)(d % NSLOT);
@@ -898,9 +1319,11 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		for(unsigned long long g = t->gathered; g <= d; g++) t->gathered_by[g % NSLOT] = t->ev_d[s];
 		t->gathered = d + 1;
 	}
-	HIPCHK(c, hipEventSynchronize(t->gathered_by[s]));
-	HIPCHK(c, hipEventSynchronize(t->ev_b[s]));               // (world 1, and rank 0's own strip)
-	if(t->host_base != NULL) HIPCHK(c, hipEventSynchronize(t->ev_h[s]));      // this rank's own strip is in the host frame
+	rc = wait_event(c, t, t->gathered_by[s], "the group that carries its strips and words", d);
+	if(rc != PWN_OK) return rc;
+	rc = wait_event(c, t, t->ev_b[s], "its blur (behind the halo rows of its neighbours)", d);               // (world 1, and rank 0's own strip)
+	if(rc != PWN_OK) return rc;
+	if(t->host_base != NULL) { rc = wait_event(c, t, t->ev_h[s], "the copy of its strip into the host frame", d); if(rc != PWN_OK) return rc; }      // this rank's own strip is in the host frame
 
 	// ---- the ranks' words of this frame (they came to pinned memory behind the group that carried them: fetch_words)
 	const uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1) * 2;
@@ -920,7 +1343,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		// On the comm stream, behind the groups of the newer frames that are already in it.
 		t->info.frames_redone++;
 		t->halo = 0; t->fhalo[s] = 0;
-		hipStream_t cs = t->cs[d & 1u];
+		hipStream_t cs = t->fstream[s];
 		int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
 		TPCHK(c, t->tp->begin(t->comm));
 		rc = add_allgather(c, t, s);
@@ -946,7 +1369,11 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		if(rc != PWN_OK) return rc;
 		TPCHK(c, t->tp->end());
 		t->info.groups += 2;
-		HIPCHK(c, hipStreamSynchronize(t->comm));
+		// (everything of the repeat is in front of this event on the comm stream: the whole strips, the blur behind them --
+		// the comm stream waited for ev_b -- the copy to the host, the gather)
+		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
+		rc = wait_event(c, t, t->ev_d[s], "its repeat with whole strips", d);
+		if(rc != PWN_OK) return rc;
 		HIPCHK(c, hipStreamSynchronize(cs));
 		if(t->host_base != NULL) HIPCHK(c, hipStreamSynchronize(t->copy));
 	}
@@ -993,7 +1420,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 			{
 				(void)hipEventElapsedTime(&out->blur_ms, t->ev_k2[s], t->ev_k3[s]);
 				(void)hipEventElapsedTime(&out->frame_ms, t->ev_k0[s], t->ev_k3[s]);      // trace .. blur: waiting for the halo rows in between
-				(void)hipEventElapsedTime(&out->halo_ms, t->ev_g2[s], t->ev_x[s]) ;
+				(void)hipEventElapsedTime(&out->halo_ms, t->ev_g2[s], t->ev_g3[s]);
 			}
 			if(t->timed_g2[s]) (void)hipEventElapsedTime(&out->gather_ms, t->ev_g0[s], t->ev_g1[s]);
 			if(hipGetLastError() != hipSuccess) { /* (an event without timing data: the figure stays 0) */ }

@@ -153,6 +153,13 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #include "trace_walk.inc"
 			// trace.h:250,677: out of steps
 			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
+#ifdef PWN_WALK_UNROLL2
+			// experiment (round 4): two cell steps per trip, so that the values a step hands to the next one (the cell word just
+			// fetched, the distance) need no register copy at the loop's back edge
+			if(ev != 0) break;
+#include "trace_walk.inc"
+			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
+#endif
 		} while(ev == 0);
 		// what the ray ended on is read back from the register: without this the compiler keeps
 		// "ev == EV_EXHAUSTED" as a lane mask that it updates in every iteration of the walk
@@ -470,8 +477,10 @@ pwn_trace_kernel(pwn_trace_params P)
 		// unit / units_x by the host's reciprocal (pwn_trace_params.ux_magic: exact for every unit < 2^31, pwn_api.cpp
 		// unit_div_magic): two instructions where the compiler's division takes thirteen; frames one unit wide divide
 		uint32_t k;
+		// (ux_shift < 0 only for units_x == 1, pwn_api.cpp unit_div_magic: then k = unit.  A real division here had its
+		// reciprocal hoisted to the top of the kernel and, in the 4-lane variant, parked in scratch memory)
 		if(P.ux_shift >= 0) k = __umulhi(unit, P.ux_magic) >> P.ux_shift;
-		else k = unit / units_x;
+		else k = unit;
 		const uint32_t ux = unit - k * units_x;
 		const uint32_t rows_u = ((uint32_t)(P.y1 - P.y0) + 3u) >> 2;
 		// ... of the FRAME: a strip of a row tiling starts at its rows nearest the frame's middle row (the strip of
@@ -489,7 +498,18 @@ pwn_trace_kernel(pwn_trace_params P)
 		}
 		const int half = (int)(ux & 1u);                  // left / right half of the 32-wide tile
 		const int cx0 = (int)(ux >> 1) * 32;              // the 32-pixel tile of screen.h:6-7 this wave is in
-		const int x = (int)ux * 16 + l16, y = P.y0 + (int)uy * 4 + (lane >> 4);
+		int x, y;
+		if constexpr(HAS_W)
+		{
+			// the lane's column and row inside the unit from a lane number made here (mbcnt behind an opaque zero): as
+			// loop invariants from the top of the kernel the 4-lane variant, which is out of registers, kept them in scratch
+			// memory -- 16 B per lane stored by every wave, two loads per unit (ScratchSize 16 -> 0, `make resources`)
+			uint32_t ln = 0u;
+			asm volatile("" : "+v"(ln));
+			ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, ln));
+			x = (int)ux * 16 + (int)(ln & 15u); y = P.y0 + (int)uy * 4 + (int)(ln >> 4);
+		}
+		else { x = (int)ux * 16 + l16; y = P.y0 + (int)uy * 4 + (lane >> 4); }
 
 		// screen.h:12-18, in the order the reference build evaluates it:
 		// rayl = (cx*rdx + rayb) + y*rdy, then one "+= rdx" per pixel of the
@@ -528,6 +548,8 @@ pwn_trace_kernel(pwn_trace_params P)
 		}
 #endif
 
+		unsigned long long u_begin = 0ull;
+		if(P.unit_cost != NULL) u_begin = __builtin_amdgcn_s_memrealtime();
 		if(x < P.w && y < P.y1)
 		{
 			// screen.h:19-21 (uint32 wrap-around)
@@ -540,6 +562,12 @@ pwn_trace_kernel(pwn_trace_params P)
 			const uint32_t o = __umul24((uint32_t)y, (uint32_t)P.w) + (uint32_t)x;      // w, h <= 32768 (pwn_init)
 			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
+		}
+		// PWN_OPT_WAVE_LOG: what this unit cost its wave (the add chain and the ticket arithmetic in front of it are the same for every unit)
+		if(P.unit_cost != NULL && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+		{
+			const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - u_begin) >> 2;
+			P.unit_cost[unit] = (uint16_t)(d > 65535ull ? 65535ull : d);
 		}
 #ifdef PWN_DRAW_PROBE
 		// experiment build (tools/r3/draw_probe.py): the draw AFTER the unit, and how long the wave waits for it

@@ -283,6 +283,20 @@ class Renderer:
     def tiled_shutdown(self):
         lib.pwn_tiled_shutdown(self._ctx)
 
+    def tiled_set_timeouts(self, init_s=None, wait_s=None):
+        """pwn_tiled_set_timeouts: how long pwn_tiled_init / pwn_tiled_wait may wait for the other ranks before they
+        return PWN_ETIMEDOUT (seconds; None keeps a value, a negative number restores the default)."""
+        ms = [0 if v is None else (-1 if v < 0 else max(1, int(v * 1000))) for v in (init_s, wait_s)]
+        self._chk(lib.pwn_tiled_set_timeouts(self._ctx, ms[0], ms[1]), "pwn_tiled_set_timeouts")
+
+    def tiled_preflight(self):
+        """pwn_tiled_preflight as a dict: visible devices, peer access from this context's device, the librccl that
+        dlopen resolved and its version, how the communicator will be driven, the deadlines."""
+        import json
+        buf = C.create_string_buffer(2048)
+        self._chk(lib.pwn_tiled_preflight(self._ctx, buf, len(buf)), "pwn_tiled_preflight")
+        return json.loads(buf.value.decode())
+
     def tiled_balance(self, every_frames):
         """Moving cuts: re-cut the strips every `every_frames` delivered frames from what they cost (0: leave them)."""
         self._chk(lib.pwn_tiled_balance(self._ctx, int(every_frames)), "pwn_tiled_balance")

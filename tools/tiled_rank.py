@@ -12,7 +12,12 @@ and every rank a line `info {...}` (pwn_tiled_info) and per frame `rows K Y0 Y1 
 what they cost).  TILED_ROTATE=1: pwn_tiled_gather_root(ROTATE), the `frame` lines then come from the frame's root, rank K mod
 WORLD.  TILED_BALANCE=k: pwn_tiled_balance(k) (moving cuts); TILED_CUTS_AT="K:c0,c1,..;K2:.." calls
 pwn_tiled_set_cuts in front of frame K.  TILED_HOSTSINK=1: frames are delivered into POSIX shared
-memory by every rank (pwn_tiled_host_sink); the other ranks then print `seen K fnv64 HASH` too."""
+memory by every rank (pwn_tiled_host_sink); the other ranks then print `seen K fnv64 HASH` too.
+Failure containment (tests/test_gpu_deadlines.py): TILED_TIMEOUTS="INIT_S,WAIT_S" -> pwn_tiled_set_timeouts;
+TILED_DIE_AT="K:RANK": that rank leaves the process (exit code 17) right before it would submit frame K.  A rank whose
+tiling call fails prints `error CODE after S s: MESSAGE`, then `info {...}` if there still is a tiling, and exits with 42.
+TILED_COUNTERS=1 / TILED_WAVELOG=1: the counting options on; every rank prints `stats K RAYS WAVES` per delivered frame.
+TILED_TIMING=1: every frame timed (PWN_OPT_FRAME_TIMING 1); `times K TRACE BLUR HALO GATHER` per delivered frame."""
 import json
 import os
 import sys
@@ -73,7 +78,35 @@ def main():
         # the frames' host memory: POSIX shared memory that every rank maps (created before the id file appears)
         with open(shm_path(idfile), "wb") as f:
             f.truncate(4 * w * h * 4)
-    r.tiled_init(rank, world, uid, transport, halo)
+    t_call = [time.time()]
+
+    def failed(e):
+        print("error %d after %.2f s: %s" % (e.code, time.time() - t_call[0], e), flush=True)
+        try:
+            print("info " + json.dumps(r.tiled_info()), flush=True)
+        except pwnfps_amd.PwnError:
+            pass
+        sys.stdout.flush()
+        os._exit(42)                        # (a helper thread may still sit inside RCCL: no interpreter shutdown)
+    if os.environ.get("TILED_TIMEOUTS"):
+        a, b = (float(v) for v in os.environ["TILED_TIMEOUTS"].split(","))
+        r.tiled_set_timeouts(a, b)
+    if os.environ.get("TILED_PREFLIGHT"):
+        print("preflight " + json.dumps(r.tiled_preflight()), flush=True)
+    try:
+        r.tiled_init(rank, world, uid, transport, halo)
+    except pwnfps_amd.PwnError as e:
+        failed(e)
+    if os.environ.get("TILED_COUNTERS"):
+        r.set_counters(True)
+    if os.environ.get("TILED_WAVELOG"):
+        r.set_wave_log(True)
+    if os.environ.get("TILED_TIMING"):
+        r.set_frame_timing(1)
+    die_at = None
+    if os.environ.get("TILED_DIE_AT"):
+        k, who = os.environ["TILED_DIE_AT"].split(":")
+        die_at = int(k) if int(who) == rank else None
     mm = None
     if hostsink:
         import mmap
@@ -91,10 +124,22 @@ def main():
         k, c = part.split(":")
         cuts_at[int(k)] = [int(v) for v in c.split(",")]
 
+    fr_rows = [0, 0]
+
     def deliver(k):
-        fr = r.tiled_wait(host=True)
+        t_call[0] = time.time()
+        try:
+            fr = r.tiled_wait(host=True)
+        except pwnfps_amd.PwnError as e:
+            failed(e)
         assert fr["seq"] == k + 1
+        fr_rows[0], fr_rows[1] = fr["y0"], fr["y1"]
         print("rows %d %d %d %d" % (k, fr["y0"], fr["y1"], fr["cost"]), flush=True)
+        if os.environ.get("TILED_COUNTERS") or os.environ.get("TILED_WAVELOG"):
+            st = r.stats()
+            print("stats %d %d %d" % (k, st["rays"], st["waves"]), flush=True)
+        if os.environ.get("TILED_TIMING"):
+            print("times %d %.6f %.6f %.6f %.6f" % (k, fr["trace_ms"], fr["blur_ms"], fr["halo_ms"], fr["gather_ms"]), flush=True)
         if (rank == 0 and hostsink) or (not hostsink and fr.get("sbuf") is not None):
             # (without a host sink: the frame's root has it -- rank 0, or rank k mod world with TILED_ROTATE=1)
             assert hostsink or fr["root"] == rank
@@ -107,11 +152,21 @@ def main():
         r.set_objects(sph)
         if k in cuts_at:
             r.tiled_set_cuts(cuts_at[k])
-        r.tiled_submit(cam, sec)
+        if die_at == k:
+            sys.stdout.flush()
+            os._exit(17)
+        t_call[0] = time.time()
+        try:
+            r.tiled_submit(cam, sec)
+        except pwnfps_amd.PwnError as e:
+            failed(e)
         if k >= 2:
             deliver(k - 2)
     for k in range(max(0, frames - 2), frames):
         deliver(k)
+    if os.environ.get("TILED_COUNTERS") or os.environ.get("TILED_WAVELOG"):
+        st = r.stats()                       # every frame delivered: the last launch's own counts
+        print("laststats %d %d %d %d" % (st["rays"], st["waves"], fr_rows[0], fr_rows[1]), flush=True)
     print("info " + json.dumps(r.tiled_info()), flush=True)
     print("cuts " + json.dumps([int(v) for v in r.tiled_get_cuts()[0]]), flush=True)
     r.tiled_shutdown()
