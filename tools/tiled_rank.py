@@ -17,7 +17,8 @@ Failure containment (tests/test_gpu_deadlines.py): TILED_TIMEOUTS="INIT_S,WAIT_S
 TILED_DIE_AT="K:RANK": that rank leaves the process (exit code 17) right before it would submit frame K.  A rank whose
 tiling call fails prints `error CODE after S s: MESSAGE`, then `info {...}` if there still is a tiling, and exits with 42.
 TILED_COUNTERS=1 / TILED_WAVELOG=1: the counting options on; every rank prints `stats K RAYS WAVES` per delivered frame.
-TILED_TIMING=1: every frame timed (PWN_OPT_FRAME_TIMING 1); `times K TRACE BLUR HALO GATHER` per delivered frame."""
+TILED_TIMING=1: every frame timed (PWN_OPT_FRAME_TIMING 1); `times K TRACE BLUR HALO GATHER` per delivered frame.
+Every rank ends with a line `host frames N in S s = MS ms per frame; pwn_tiled_submit US us per frame`."""
 import json
 import os
 import sys
@@ -125,6 +126,8 @@ def main():
         cuts_at[int(k)] = [int(v) for v in c.split(",")]
 
     fr_rows = [0, 0]
+    enq = []
+    t_run = time.time()
 
     def deliver(k):
         t_call[0] = time.time()
@@ -140,6 +143,7 @@ def main():
             print("stats %d %d %d" % (k, st["rays"], st["waves"]), flush=True)
         if os.environ.get("TILED_TIMING"):
             print("times %d %.6f %.6f %.6f %.6f" % (k, fr["trace_ms"], fr["blur_ms"], fr["halo_ms"], fr["gather_ms"]), flush=True)
+        enq.append(fr["enqueue_us"])
         if (rank == 0 and hostsink) or (not hostsink and fr.get("sbuf") is not None):
             # (without a host sink: the frame's root has it -- rank 0, or rank k mod world with TILED_ROTATE=1)
             assert hostsink or fr["root"] == rank
@@ -167,6 +171,9 @@ def main():
     if os.environ.get("TILED_COUNTERS") or os.environ.get("TILED_WAVELOG"):
         st = r.stats()                       # every frame delivered: the last launch's own counts
         print("laststats %d %d %d %d" % (st["rays"], st["waves"], fr_rows[0], fr_rows[1]), flush=True)
+    if enq:
+        print("host frames %d in %.4f s = %.4f ms per frame; pwn_tiled_submit %.1f us per frame (median %.1f)" % (
+            frames, time.time() - t_run, (time.time() - t_run) / frames * 1e3, float(np.mean(enq)), float(np.median(enq))), flush=True)
     print("info " + json.dumps(r.tiled_info()), flush=True)
     print("cuts " + json.dumps([int(v) for v in r.tiled_get_cuts()[0]]), flush=True)
     r.tiled_shutdown()
