@@ -400,6 +400,8 @@ def main():
                          "that leg with the kernels and their durations (2.7x) would be averaged into the resident loop's")
     args = ap.parse_args()
 
+    # (multi-process GPU work on this pool: the host driver only supports dmabuf IPC; already exported where the driver runs this)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import pwnfps_amd
@@ -947,6 +949,16 @@ def main():
         ok2, _ = bring_up(transport, halo=0, tag="sweep.whole_strips:")
         if ok2:
             point("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows")
+        if transport == "rccl":
+            # the other way of driving the communicator: non-blocking, every call polled against the deadline (a grouped launch is
+            # then handed to a thread of RCCL's and the host waits for it) -- what that costs the host per frame (enqueue_us)
+            barrier()
+            r.tiled_shutdown()
+            os.environ["PWN_TILED_RCCL_MODE"] = "nonblocking"          # (read by pwn_tiled_init; the same on every rank)
+            ok3, _ = bring_up(transport, tag="sweep.rccl_nonblocking:")
+            if ok3:
+                point("rccl_nonblocking", "PWN_TILED_RCCL_MODE=nonblocking: ncclCommInitRankConfig(blocking = 0), every call polled with ncclCommGetAsyncError")
+            del os.environ["PWN_TILED_RCCL_MODE"]
         # (the host-sink leg below sets the tiling up once more)
 
     if world == 1:

@@ -115,6 +115,15 @@ typedef struct pwn_stats
                                   frames with no room and with one workgroup per CU, the better kept for ~500 frames (half a second
                                   at least), then again (the answer depends on the scene: +3.5 % at 4K on level.txt, -3 % on a hall of
                                   mirrors); >= 0: that many, always.  Results never depend on it. */
+#define PWN_OPT_UNIT_ORDER 9   /* 1 (default; PWN_UNIT_ORDER=0 in the environment for a process): the trace kernel hands its 16 x 4-pixel units
+                                  out dearest first -- every unit's cost (the time its wave spent on it) is written by the launch, sorted per
+                                  work queue behind the frame's last kernel, and used by the next launch of the same rows on that compute
+                                  stream; the units handed out last are then the cheap ones and the launch's tail is short (a 4K
+                                  launch by itself: -5 %, the strips of an 8-way tiling: -15 ... -30 %, profiles/r4/).  0: arithmetic order,
+                                  rows from the frame's middle row outwards.  The first launch of a geometry uses the arithmetic order.  With the strip
+                                  forms the sort rides behind pwn_blur_rows_device[_bounded] on the caller's stream and serves that stream's
+                                  next pwn_trace_rows_device of the same rows.  Any order gives the same pixels.  The
+                                  reference's counterpart is OpenMP's static schedule over 32-row chunks (screen.h:63-64). */
 #define PWN_OPT_FRAME_TIMING 5 /* frames in flight: record HIP events around the trace and blur kernels of every N-th
                                   frame (pwn_frame.timed, .trace_ms ...); 1 = every frame (default), 0 = never.  An event
                                   between two kernels costs a few microseconds of pipeline */
@@ -128,6 +137,13 @@ typedef struct pwn_stats
 int pwn_init(pwn_ctx **out, int device, int width, int height);
 void pwn_destroy(pwn_ctx *ctx);
 int pwn_set_option(pwn_ctx *ctx, int option, int value);
+/* PWN_OPT_UNIT_ORDER as it stands: out[0] the option, out[1] trace launches so far that handed their units out in a sorted order,
+   out[2] sorts launched (one behind every frame whose trace wrote its units' costs), out[3] units the first compute stream's
+   current order covers (0: none yet). */
+int pwn_unit_order_state(pwn_ctx *ctx, unsigned long long out[4]);
+/* the sort by itself (tests): `units` costs in (host memory), the order out -- perm_out holds 64 * cap entries, cap = ceil(units / 64);
+   queue q's units, dearest first, are perm_out[q * cap .. q * cap + its length), the rest of its row is left 0xffffffff */
+int pwn_unit_order_probe(pwn_ctx *ctx, const uint16_t *cost, uint32_t units, uint32_t *perm_out);
 /* PWN_OPT_TRACE_ROOM as it stands: out[0] the option's value (-1 = measuring), out[1] the workgroups the next two-stream trace launch
    leaves free, out[2] how often the two settings were compared, out[3] how often the setting changed */
 int pwn_trace_room_state(pwn_ctx *ctx, int out[4]);

@@ -14,6 +14,7 @@ PWN_EBUSY, PWN_ENOTSUP, PWN_ETIMEDOUT = -8, -9, -10
 PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER, PWN_OPT_REFILL_LIMIT, PWN_OPT_FRAME_TIMING, PWN_OPT_WAVE_LOG = 1, 2, 3, 4, 5, 6
 PWN_OPT_FRAME_OVERLAP = 7
 PWN_OPT_TRACE_ROOM = 8
+PWN_OPT_UNIT_ORDER = 9
 PWN_SCHED_UNITS, PWN_SCHED_REFILL = 0, 1
 PWN_MAX_SLOTS = 4
 PWN_FRAME_SBUF, PWN_FRAME_ZBUF, PWN_FRAME_SURFACE = 1, 2, 4
@@ -96,6 +97,8 @@ ABI = [
     ("pwn_trace_rows_device", _i, [_vp, _vp, _f, _i, _i, _vp, _vp, _vp]),
     ("pwn_blur_rows_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("pwn_blur_rows_device_bounded", _i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    ("pwn_unit_order_state", _i, [_vp, _vp]),
+    ("pwn_unit_order_probe", _i, [_vp, _vp, C.c_uint32, _vp]),
     ("pwn_tiled_unique_id", _i, [_vp, _i]),
     ("pwn_tiled_init", _i, [_vp, _i, _i, _vp, _i, _i]),
     ("pwn_tiled_submit", _i, [_vp, _vp, _f]),

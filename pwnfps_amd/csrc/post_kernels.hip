@@ -274,6 +274,48 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	asm volatile("" : "+v"(vw), "+v"(vh));
 	uint32_t tap[4][4];
 	bool missed = false;
+	// Round 4: no "+ 1" per coordinate where it is not needed.  The one-up form exists for ONE input class, f >= 2^31 (above:
+	// v_cvt_i32_f32 saturates to INT_MAX where cvttss2si gives INT_MIN), and a coordinate is column / row + r * fstr * (depth - 1)
+	// with |r| <= 1 and fstr <= 66: while every depth of the wave's groups is below 10^6 in magnitude no coordinate comes near
+	// 2^31, the conversion needs no correction, and the clamp is [0, hi - 1] directly (NaN and -inf end at 0 both ways).  One
+	// wave-uniform test buys 32 additions per thread (4 % of the kernel's vector instructions).
+	const bool tame = fabsf(z[0]) < 1.0e6f && fabsf(z[1]) < 1.0e6f && fabsf(z[2]) < 1.0e6f && fabsf(z[3]) < 1.0e6f;
+	if(__builtin_expect(__ballot(!tame) == 0ull, 1))
+	{
+		const uint32_t w0 = (uint32_t)P.w;
+		const uintptr_t pre0 = (uintptr_t)P.pre;
+		int vw1 = P.w - 1, vh1 = P.h - 1;
+		asm volatile("" : "+v"(vw1), "+v"(vh1));
+		int lx = lx0, ly = ly0;
+		asm volatile("" : "+s"(lx), "+s"(ly));
+#pragma unroll
+		for(int i = 0; i < 4; i++)
+		{
+#pragma unroll
+			for(int j = 0; j < 4; j++)
+			{
+				// screen.h:101-106
+				const float fx = fcx[j] + (lcg2_fs(t2) * fstr) * z[j];
+				const float fy = fcy + (lcg2_fs(t2) * fstr) * z[j];
+				int x0c, y0c, cx_, cy_;
+				asm("v_cvt_i32_f32 %0, %1" : "=v"(cx_) : "v"(fx));
+				asm("v_cvt_i32_f32 %0, %1" : "=v"(cy_) : "v"(fy));
+				asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x0c) : "v"(cx_), "v"(vw1));
+				asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y0c) : "v"(cy_), "v"(vh1));
+				if(CHECK) missed |= (unsigned)(y0c - P.avail_y0) >= (unsigned)(P.avail_y1 - P.avail_y0);
+				const unsigned tx = (unsigned)(x0c - lx), ty = (unsigned)(y0c - ly);
+				const uint32_t *p = tile + (ty * BLUR_PITCH + tx);
+				if(!(tx < (unsigned)BLUR_LW && ty < (unsigned)BLUR_LH))
+				{
+					asm volatile("");
+					p = (const uint32_t *)(pre0 + ((uintptr_t)__umul24((unsigned)y0c, w0) + (uintptr_t)(unsigned)x0c) * 4u);
+				}
+				tap[i][j] = *p;
+			}
+		}
+	}
+	else
+	{
 #pragma unroll
 	for(int i = 0; i < 4; i++)
 	{
@@ -302,6 +344,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 			const uint32_t v = *p;
 			tap[i][j] = v;
 		}
+	}
 	}
 	uint4 o;
 	o.x = avg_u8x4(avg_u8x4(tap[0][0], tap[1][0]), avg_u8x4(tap[2][0], tap[3][0]));
@@ -381,6 +424,61 @@ extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stre
 		default: return hipErrorInvalidValue;
 	}
 #endif
+}
+
+// ------------------------------------------------------ the units' order ----
+// PWN_OPT_UNIT_ORDER: the hand-out order of the NEXT trace launch of this geometry from what every unit cost in the
+// one that just ran (pwn_trace_params.unit_cost: 40 ns per count, written by the wave that traced the unit).  Queue q
+// of the trace kernel holds the units a = q (mod 64); this kernel puts each queue's units in order of falling cost
+// and writes perm[q * cap + t] = the unit that ticket t of queue q stands for.  One 256-thread workgroup per queue,
+// a counting sort over 256 cost classes of 0.32 us (everything above 82 us in the dearest): a histogram in LDS, its
+// prefix sums, a scatter -- units of one class come out in whatever order their atomics land, which is as good as any
+// (a unit's cost is its wave's wall time, good to ~10 %).  (The first form, a bitonic sort of the whole queue in LDS,
+// took 80 us at 4K -- 66 passes of a barrier each -- against the ~20 us the order can win: profiles/r4/unit_order_ab.txt.)
+// Whatever the costs are, the output is a permutation of the queue's units, so the order can only change speed, never
+// a pixel.  Replaces: the static schedule of screen.h:63-64.
+__device__ __forceinline__ uint32_t order_class(uint32_t cost)
+{
+	const uint32_t b = cost >> 3;
+	return 255u - (b > 255u ? 255u : b);              // class 0 = dearest
+}
+
+__global__ void __launch_bounds__(256)
+pwn_order_kernel(const uint16_t *cost, uint32_t units, uint32_t cap, uint32_t *perm)
+{
+	__shared__ uint32_t hist[256], base[256];
+	const uint32_t q = blockIdx.x, t = threadIdx.x;
+	const uint32_t n = (units + PWN_QUEUES - 1u - q) / PWN_QUEUES;          // units of this queue: q, q + 64, ...
+	hist[t] = 0u;
+	__syncthreads();
+	for(uint32_t i = t; i < n; i += 256u) atomicAdd(&hist[order_class(cost[i * PWN_QUEUES + q])], 1u);
+	__syncthreads();
+	// exclusive prefix sums over the 256 classes (Hillis-Steele, eight rounds)
+	uint32_t v = hist[t];
+	base[t] = v;
+	__syncthreads();
+	for(uint32_t d = 1u; d < 256u; d <<= 1)
+	{
+		const uint32_t add = t >= d ? base[t - d] : 0u;
+		__syncthreads();
+		base[t] += add;
+		__syncthreads();
+	}
+	const uint32_t excl = base[t] - v;
+	__syncthreads();
+	base[t] = excl;
+	__syncthreads();
+	for(uint32_t i = t; i < n; i += 256u)
+	{
+		const uint32_t pos = atomicAdd(&base[order_class(cost[i * PWN_QUEUES + q])], 1u);
+		perm[q * cap + pos] = i * PWN_QUEUES + q;
+	}
+}
+
+extern "C" hipError_t pwn_launch_order(const uint16_t *cost, uint32_t units, uint32_t cap, uint32_t *perm, hipStream_t stream)
+{
+	hipLaunchKernelGGL(pwn_order_kernel, dim3(PWN_QUEUES), dim3(256), 0, stream, cost, units, cap, perm);
+	return hipGetLastError();
 }
 
 // -------------------------------------------------------------- upscale ----

@@ -90,6 +90,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->stream = NULL; c->copy_stream = NULL; c->stream2 = NULL; c->d_pre2 = NULL;
 	c->frame_overlap = 1; c->last_frame_done = NULL; c->last_frame_stream = NULL;
 	if(const char *e = getenv("PWN_FRAME_OVERLAP")) c->frame_overlap = atoi(e) != 0;
+	c->unit_order = 1;
+	if(const char *e = getenv("PWN_UNIT_ORDER")) c->unit_order = atoi(e) != 0;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));
 	c->frame_timing = 1; c->wave_log_on = 0; c->d_wave_log = NULL; c->wave_log_cap = 0;
@@ -204,7 +206,8 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 	if(c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	if(c->up_stream) (void)hipStreamDestroy(c->up_stream);
 	(void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z); (void)hipFree(c->d_pre2);
-	(void)hipFree(c->d_wave_log); (void)hipFree(c->d_unit_cost);
+	(void)hipFree(c->d_wave_log);
+	for(int i = 0; i < 4; i++) { (void)hipFree(c->order[i].d_cost); (void)hipFree(c->order[i].d_perm); }
 	(void)hipFree(c->d_skip); (void)hipFree(c->d_counters); (void)hipFree(c->d_tickets); (void)hipFree(c->d_scratch);
 	delete c;
 }
@@ -268,6 +271,7 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 		case PWN_OPT_WAVE_LOG: c->wave_log_on = value ? 1 : 0; return PWN_OK;
 		case PWN_OPT_FRAME_TIMING: if(value < 0) return PWN_EINVAL; c->frame_timing = value; return PWN_OK;
 		case PWN_OPT_REFILL_LIMIT: if(value < 1 || value > 64000) return PWN_EINVAL; c->refill_limit = value; return PWN_OK;
+		case PWN_OPT_UNIT_ORDER: if(value != 0 && value != 1) return PWN_EINVAL; c->unit_order = value; for(int i = 0; i < 4; i++) c->order[i].perm_valid = false; return PWN_OK;
 		case PWN_OPT_TRACE_ROOM: if(value < -1 || value > 4096) return PWN_EINVAL; memset(&c->room, 0, sizeof(c->room)); c->room.mode = value; return PWN_OK;
 		case PWN_OPT_FRAME_OVERLAP:
 			for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
@@ -616,6 +620,27 @@ static void frame_setup(int w, int h, const float cam[16], pwn_trace_params *P)
 	}
 }
 
+// the unit-order entry of a stream (pwn_internal.h); NULL: none to spare right now
+static pwn_ctx::unit_order_state *order_entry(pwn_ctx *c, hipStream_t stream, bool make)
+{
+	if(stream == c->stream) { c->order[0].key = stream; c->order[0].used = true; return &c->order[0]; }
+	if(c->stream2 != NULL && stream == c->stream2) { c->order[1].key = stream; c->order[1].used = true; return &c->order[1]; }
+	for(int i = 2; i < 4; i++) if(c->order[i].used && c->order[i].key == stream) { c->order[i].stamp = ++c->order_stamp; return &c->order[i]; }
+	if(!make) return NULL;
+	int pick = -1;
+	for(int i = 2; i < 4; i++) if(!c->order[i].used) { pick = i; break; }
+	if(pick < 0)
+	{
+		// both spare entries belong to other streams of the caller, whose kernels may still be using them: the older one is
+		// taken over once the device is idle (a host that rotates over many streams pays for it; two are free)
+		pick = c->order[2].stamp < c->order[3].stamp ? 2 : 3;
+		if(hipDeviceSynchronize() != hipSuccess) return NULL;
+	}
+	pwn_ctx::unit_order_state &e = c->order[pick];
+	e.key = stream; e.used = true; e.stamp = ++c->order_stamp; e.perm_valid = e.cost_fresh = false;
+	return &e;
+}
+
 // (the events of the launch history belong to frame slots / the row tiling: forget them where those go, with the
 // compute streams idle)
 void pwn_launch_history_clear(pwn_ctx *c)
@@ -732,24 +757,34 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 		}
 		HIPCHK(c, hipMemsetAsync(c->d_wave_log, 0, c->wave_log_cap * 16, stream));
 		P.wave_log = c->d_wave_log;
-		// ... and every unit's cost (unit kernel only), for tools/unit_order_sim.py
-		if(!refill)
-		{
-			const size_t units = (size_t)P.tiles_total;
-			if(units > c->unit_cost_cap)
-			{
-				if(c->d_unit_cost) { HIPCHK(c, hipDeviceSynchronize()); (void)hipFree(c->d_unit_cost); c->d_unit_cost = NULL; c->unit_cost_cap = 0; }
-				HIPCHK(c, hipMalloc((void **)&c->d_unit_cost, units * 2));
-				c->unit_cost_cap = units;
-			}
-			HIPCHK(c, hipMemsetAsync(c->d_unit_cost, 0, units * 2, stream));
-			P.unit_cost = c->d_unit_cost;
-			c->unit_cost_n = units;
-		}
 	}
-	// This launch clears the ticket set that the launch two before it drew from (above): it has to come after that one.
-	// On one stream and in the alternating pattern of two it does by itself; a launch that leaves the pattern waits.
-	if(c->launch_event[1] != NULL && c->launch_stream[1] != stream) HIPCHK(c, hipStreamWaitEvent(stream, c->launch_event[1], 0));
+	// PWN_OPT_UNIT_ORDER (and the wave log, for tools/unit_order_sim.py): this launch writes what every unit cost its wave,
+	// and hands its units out in the order sorted from the last launch of the same rows on this stream
+	pwn_ctx::unit_order_state *uop = (!refill && (c->unit_order || c->wave_log_on)) ? order_entry(c, stream, true) : order_entry(c, stream, false);
+	if(uop != NULL && !refill && (c->unit_order || c->wave_log_on))
+	{
+		pwn_ctx::unit_order_state &uo = *uop;
+		const size_t units = (size_t)P.tiles_total;
+		const uint32_t qcap = (uint32_t)((units + PWN_QUEUES - 1u) / PWN_QUEUES);
+		if(units > uo.cost_cap || (size_t)qcap * PWN_QUEUES > uo.perm_cap)
+		{
+			// (kernels that use the old buffers may still run, on either stream)
+			if(uo.d_cost || uo.d_perm) HIPCHK(c, hipDeviceSynchronize());
+			(void)hipFree(uo.d_cost); (void)hipFree(uo.d_perm);
+			uo.d_cost = NULL; uo.d_perm = NULL; uo.cost_cap = uo.perm_cap = 0; uo.perm_valid = uo.cost_fresh = false;
+			HIPCHK(c, hipMalloc((void **)&uo.d_cost, units * 2));
+			HIPCHK(c, hipMalloc((void **)&uo.d_perm, (size_t)qcap * PWN_QUEUES * 4));
+			uo.cost_cap = units; uo.perm_cap = (size_t)qcap * PWN_QUEUES;
+		}
+		P.unit_cost = uo.d_cost;
+		if(c->unit_order && uo.perm_valid && uo.perm_units == (uint32_t)units && uo.perm_y0 == y0 && uo.perm_y1 == y1)
+		{
+			P.perm = uo.d_perm; P.perm_cap = qcap;
+			c->order_used++;
+		}
+		uo.units = (uint32_t)units; uo.qcap = qcap; uo.y0 = y0; uo.y1 = y1; uo.cost_fresh = true;
+	}
+	else if(uop != NULL) uop->cost_fresh = false;
 	if(refill) HIPCHK(c, pwn_launch_trace_refill(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	else HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	c->ticket_set++;                     // only a launch that went out has cleared the other set
@@ -771,6 +806,48 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 		c->tables_wait[cur] = c->ev_tables[cur];
 	}
 	c->tables_in_use[cur] = true;
+	return PWN_OK;
+}
+
+// Behind the last kernel of a frame on `stream`: the costs its trace launch wrote become the hand-out order of the next
+// launch of the same rows on that stream.  ~10 us of 64 workgroups at 4K, which the caller puts where nobody waits for
+// it (behind the frame's "done" event / its copies to the host).
+int pwn_i_launch_order(pwn_ctx *c, hipStream_t stream)
+{
+	pwn_ctx::unit_order_state *uop = order_entry(c, stream, false);
+	if(uop == NULL) return PWN_OK;
+	pwn_ctx::unit_order_state &uo = *uop;
+	if(!c->unit_order || !uo.cost_fresh || uo.units < 4u * PWN_QUEUES) return PWN_OK;
+	uo.cost_fresh = false;
+	HIPCHK(c, pwn_launch_order(uo.d_cost, uo.units, uo.qcap, uo.d_perm, stream));
+	uo.perm_valid = true; uo.perm_units = uo.units; uo.perm_y0 = uo.y0; uo.perm_y1 = uo.y1;
+	c->order_sorts++;
+	return PWN_OK;
+}
+
+// the sort by itself, host arrays in and out (tests): perm_out has 64 * ceil(units / 64) entries, queue q's at [q * cap, q * cap + its length)
+extern "C" int pwn_unit_order_probe(pwn_ctx *c, const uint16_t *cost, uint32_t units, uint32_t *perm_out)
+{
+	if(c == NULL || cost == NULL || perm_out == NULL || units == 0u) return PWN_EINVAL;
+	const uint32_t cap = (units + PWN_QUEUES - 1u) / PWN_QUEUES;
+	(void)hipSetDevice(c->device);
+	uint16_t *d_cost = NULL; uint32_t *d_perm = NULL;
+	int rc = PWN_OK;
+	if(hipMalloc((void **)&d_cost, (size_t)units * 2) != hipSuccess || hipMalloc((void **)&d_perm, (size_t)cap * PWN_QUEUES * 4) != hipSuccess) rc = PWN_ENOMEM;
+	if(rc == PWN_OK && (hipMemcpy(d_cost, cost, (size_t)units * 2, hipMemcpyHostToDevice) != hipSuccess ||
+	   hipMemset(d_perm, 0xff, (size_t)cap * PWN_QUEUES * 4) != hipSuccess || hipDeviceSynchronize() != hipSuccess)) rc = PWN_EHIP;
+	if(rc == PWN_OK && pwn_launch_order(d_cost, units, cap, d_perm, c->stream) != hipSuccess) rc = PWN_EHIP;
+	if(rc == PWN_OK && (hipStreamSynchronize(c->stream) != hipSuccess ||
+	   hipMemcpy(perm_out, d_perm, (size_t)cap * PWN_QUEUES * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = PWN_EHIP;
+	(void)hipFree(d_cost); (void)hipFree(d_perm);
+	return rc;
+}
+
+extern "C" int pwn_unit_order_state(pwn_ctx *c, unsigned long long out[4])
+{
+	if(c == NULL || out == NULL) return PWN_EINVAL;
+	out[0] = (unsigned long long)c->unit_order; out[1] = c->order_used; out[2] = c->order_sorts;
+	out[3] = c->order[0].perm_valid ? c->order[0].perm_units : 0ull;
 	return PWN_OK;
 }
 
@@ -816,7 +893,10 @@ extern "C" int pwn_blur_rows_device(pwn_ctx *c, int y0, int y1, const void *d_pr
 {
 	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || y0 < 0 || y1 > c->h || y0 > y1 || d_pre == d_out) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
-	return pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream, 0, 0, NULL, NULL, NULL);
+	int rc = pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream, 0, 0, NULL, NULL, NULL);
+	// PWN_OPT_UNIT_ORDER: a strip's trace and blur on one stream of the caller's -- the order of that stream's next trace of the same rows
+	if(rc == PWN_OK) rc = pwn_i_launch_order(c, (hipStream_t)stream);
+	return rc;
 }
 
 extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const void *d_pre, const void *d_zbuf, void *d_out,
@@ -825,8 +905,10 @@ extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const vo
 	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || d_miss == NULL || y0 < 0 || y1 > c->h || y0 > y1 ||
 	   d_pre == d_out || avail_y0 > avail_y1) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
-	return pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream,
+	int rc = pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream,
 		avail_y0, avail_y1, (uint32_t *)d_miss, NULL, NULL);
+	if(rc == PWN_OK) rc = pwn_i_launch_order(c, (hipStream_t)stream);
+	return rc;
 }
 
 extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float sec, uint32_t *sbuf, float *zbuf)
@@ -856,7 +938,10 @@ extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float s
 	HIPCHK(c, hipMemcpyAsync(sbuf, cur, n * 4, hipMemcpyDeviceToHost, s));
 	if(zbuf != NULL) HIPCHK(c, hipMemcpyAsync(zbuf, c->d_z, n * 4, hipMemcpyDeviceToHost, s));
 	HIPCHK(c, hipEventRecord(c->ev[3], s));
-	HIPCHK(c, hipStreamSynchronize(s));
+	// (the units' order for the next call: behind the copies, and this call does not wait for it)
+	rc = pwn_i_launch_order(c, s);
+	if(rc != PWN_OK) return rc;
+	HIPCHK(c, hipEventSynchronize(c->ev[3]));
 	// keep the final frame addressable as d_out for pwn_screen_upscale(NULL,...)
 	if(cur != c->d_out) { c->d_pre = c->d_out; c->d_out = cur; }
 	(void)hipEventElapsedTime(&c->stats.trace_ms, c->ev[0], c->ev[1]);
@@ -999,11 +1084,14 @@ extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int 
 	HIPCHK(c, hipEventRecord(sl.ev_k[2], s));
 	c->last_frame_done = sl.ev_k[2]; c->last_frame_stream = s;
 	hipEvent_t last = sl.ev_k[2];
+	if(!(c->frame_flags & PWN_FRAME_SURFACE)) { rc = pwn_i_launch_order(c, s); if(rc != PWN_OK) return rc; }      // (behind the frame's "kernels done": nobody waits for it)
 	if(c->frame_flags & PWN_FRAME_SURFACE)
 	{
 		HIPCHK(c, pwn_launch_upscale(sl.d_out, sl.d_surface, c->w, c->h, c->frame_scale, c->frame_pitch / 4, s));
 		HIPCHK(c, hipEventRecord(sl.ev_k[3], s));
 		last = sl.ev_k[3];
+		rc = pwn_i_launch_order(c, s);
+		if(rc != PWN_OK) return rc;
 	}
 	if(c->frame_flags != 0)
 	{
@@ -1099,11 +1187,11 @@ extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 		c->stats.wave_time = sum; c->stats.waves = n; c->stats.kernel_span = n ? last - first : 0;
 		if(const char *path = getenv("PWN_DBG_WAVE_LOG"))        // tools/wave_log.py: the raw log
 			if(FILE *fp = fopen(path, "wb")) { fwrite(log.data(), 8, log.size(), fp); fclose(fp); }
-		if(const char *path = getenv("PWN_DBG_UNIT_COST"))       // tools/unit_order_sim.py: u16 per unit, 40 ns each
-			if(c->d_unit_cost != NULL && c->unit_cost_n > 0)
+		if(const char *path = getenv("PWN_DBG_UNIT_COST"))       // tools/unit_order_sim.py: u16 per unit (arithmetic numbering), 40 ns each
+			if(c->order[0].d_cost != NULL && c->order[0].units > 0)
 			{
-				std::vector<uint16_t> uc(c->unit_cost_n);
-				HIPCHK(c, hipMemcpy(uc.data(), c->d_unit_cost, uc.size() * 2, hipMemcpyDeviceToHost));
+				std::vector<uint16_t> uc(c->order[0].units);
+				HIPCHK(c, hipMemcpy(uc.data(), c->order[0].d_cost, uc.size() * 2, hipMemcpyDeviceToHost));
 				if(FILE *fp = fopen(path, "wb")) { fwrite(uc.data(), 2, uc.size(), fp); fclose(fp); }
 			}
 	}

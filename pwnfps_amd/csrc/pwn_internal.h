@@ -33,6 +33,7 @@ extern "C" int pwn_trace_tile_h(void);
 extern "C" int pwn_trace_tile_w(void);
 extern "C" unsigned pwn_trace_lds_extra(void);
 extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stream);
+extern "C" hipError_t pwn_launch_order(const uint16_t *cost, uint32_t units, uint32_t cap, uint32_t *perm, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upload(const void *h_pinned_src, void *d_dst, size_t bytes, hipStream_t stream);
 extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
@@ -124,7 +125,22 @@ struct pwn_ctx
 	uint2 *d_skip;                   // blur LCG skip-ahead, w/4 entries
 	unsigned long long *d_counters;
 	unsigned long long *d_wave_log; int wave_log_on; size_t wave_log_cap;   // PWN_OPT_WAVE_LOG; entries (16 B) allocated
-	uint16_t *d_unit_cost; size_t unit_cost_cap, unit_cost_n;               // ... and what every unit of the launch cost its wave (pwn_trace_params.unit_cost)
+	// PWN_OPT_UNIT_ORDER: per stream that trace launches go out on ([0] `stream`, [1] `stream2`, [2..3] a strip-form caller's own)
+	// what every unit of the last trace launch cost its wave (pwn_trace_params.unit_cost, indexed by the unit's number in
+	// arithmetic order) and, sorted from that behind the frame's blur (pwn_i_launch_order), the order the NEXT launch of the same
+	// rows on that stream hands its units out in.  Everything that touches one entry is ordered by ITS stream: the launch that
+	// writes the costs, the sort that reads them and writes the order, the next launch that reads the order.
+	struct unit_order_state
+	{
+		hipStream_t key; bool used; unsigned long long stamp;                 // the stream this entry belongs to
+		uint16_t *d_cost; uint32_t *d_perm; size_t cost_cap, perm_cap;        // allocated: u16 entries, u32 entries
+		uint32_t units, qcap; int y0, y1;                                     // what d_cost holds: of a launch over rows [y0, y1)
+		bool cost_fresh;                                                      // written by a launch, not sorted yet
+		uint32_t perm_units; int perm_y0, perm_y1; bool perm_valid;           // what d_perm orders
+	} order[4];
+	unsigned long long order_stamp;
+	int unit_order;                  // the option: 1 = units handed out by last launch's cost, 0 = arithmetic order
+	unsigned long long order_used, order_sorts;      // trace launches that ran in a sorted order; sorts launched (pwn_unit_order_state)
 	bool dbg_force_hasw; int dbg_blocks_per_cu;      // PWN_DBG_* hooks, read at pwn_init
 	int dbg_blur_th, dbg_blur_tw, dbg_blur_batch;                 // PWN_DBG_BLUR_TH: tile height of every blur launch (8 / 16 / 32), 0 = the launcher's choice
 	int grid_reserve;                // workgroups the persistent trace grid leaves free (row tiling over RCCL), else 0
@@ -170,5 +186,6 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream,
 	int avail_y0, int avail_y1, uint32_t *d_miss, uint32_t *d_cost_acc, uint32_t *d_cost_out);
 void pwn_launch_history_clear(pwn_ctx *c);      // the launch-order events are about to be destroyed (streams idle)
+int pwn_i_launch_order(pwn_ctx *c, hipStream_t stream);      // behind a frame's last kernel on `stream`: sort that stream's unit costs (no-op when there are none)
 void pwn_tiled_destroy(pwn_ctx *c);
 bool pwn_tiled_busy(pwn_ctx *c);        // frames of the row tiling in flight

@@ -1116,6 +1116,12 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k3[s], cs));
 	}
 	HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
+	// PWN_OPT_UNIT_ORDER: the strip's unit costs (written by the frame's trace, in front of this on the stream) sorted into
+	// the order of the stream's next trace of the same rows; behind ev_b, which is what the exchange waits for
+	{
+		const int rc = pwn_i_launch_order(c, cs);
+		if(rc != PWN_OK) return rc;
+	}
 	if(t->host_base != NULL) return copy_strip_to_host(c, t, s);
 	return PWN_OK;
 }

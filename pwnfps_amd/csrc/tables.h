@@ -148,7 +148,10 @@ struct pwn_trace_params
 	uint32_t *cost_word;                      // NULL, or a word this launch adds the sum of its waves' lifetimes to (100 MHz ticks): what
 	                                          // the rows cost, for the row tiling's moving cuts (pwn_tiled.cpp)
 	uint16_t *unit_cost;                      // NULL, or one entry per unit: how long the wave that traced it spent on it, in 40 ns (four ticks of the
-	                                          // 100 MHz clock, saturating); with PWN_OPT_WAVE_LOG, for tools/unit_order_sim.py
+	                                          // 100 MHz clock, saturating) -- what the NEXT launch of this geometry is ordered by (PWN_OPT_UNIT_ORDER,
+	                                          // post_kernels.hip pwn_order_kernel), and what tools/unit_order_sim.py replays
+	const uint32_t *perm;                     // NULL (units in arithmetic order: rows from the frame's middle outwards), or the hand-out order of
+	uint32_t perm_cap;                        // every queue: perm[q * perm_cap + ticket] = the unit that ticket of queue q stands for
 	uint32_t *clear_word;                     // NULL, or a word this launch sets to 0 (the row tiling's miss word of the frame:
 	                                          // the blur of the same frame, behind this launch on the stream, counts in it)
 };

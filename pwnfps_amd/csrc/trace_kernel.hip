@@ -450,7 +450,28 @@ pwn_trace_kernel(pwn_trace_params P)
 		//@R k_unit
 		RG(RG_UNIT);
 		misses = 0;
-		const uint32_t unit = ticket * PWN_QUEUES + q;
+		// Which unit a ticket stands for: ticket * 64 + q in arithmetic order, or -- PWN_OPT_UNIT_ORDER, the default -- what
+		// the table says: every queue's units sorted by what they cost in the last launch of this geometry, dearest first
+		// (pwn_order_kernel), so that the units handed out last are the cheap ones.  The reference's answer to uneven rows
+		// is OpenMP's static schedule (screen.h:63-64).  Never changes a pixel: any permutation of the units does.
+		// (the 4-lane variant is out of registers: loop-invariant lane values -- the lane number, "am I lane 0" -- end in
+		// scratch memory there unless they are made afresh per unit, from mbcnt behind an opaque zero)
+		uint32_t ln;
+		if constexpr(HAS_W)
+		{
+			ln = 0u;
+			asm volatile("" : "+v"(ln));
+			ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, ln));
+		}
+		else ln = (uint32_t)lane;
+		uint32_t unit = ticket * PWN_QUEUES + q;
+		// (a SCALAR load: the address is the same for the whole wave, and the scalar cache answers in a fraction of the
+		// microsecond a vector load takes here -- every unit waits for this word before it can do anything)
+		if(P.perm != NULL)
+		{
+			const uint32_t *pp = P.perm + (uint32_t)__builtin_amdgcn_readfirstlane((int)(q * P.perm_cap + ticket));
+			asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(unit) : "s"(pp) : "memory");
+		}
 		const bool draw = left == 0u;
 		// The next unit is asked for BEFORE this one is traced, which commits the wave to two units -- near the end of a
 		// launch that is the tail: the last ticket of a queue goes to a wave that still has a whole unit in front of it
@@ -462,7 +483,7 @@ pwn_trace_kernel(pwn_trace_params P)
 		// in step, 80 per counter), profiles/r3_strips/draw_probe.txt.
 		uint32_t next_raw = ticket + 1u;
 #ifndef PWN_DRAW_PROBE
-		if(draw && lane == 0) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n) + QBASE(q);
+		if(draw && ln == 0u) next_raw = atomicAdd(&P.tickets[q * PWN_QUEUE_STRIDE], draw_n) + QBASE(q);
 #endif
 		// rows from the middle outwards: the horizon band, where rays run longest,
 		// is started first and the cheap top and bottom edges make up the tail
@@ -494,18 +515,7 @@ pwn_trace_kernel(pwn_trace_params P)
 		}
 		const int half = (int)(ux & 1u);                  // left / right half of the 32-wide tile
 		const int cx0 = (int)(ux >> 1) * 32;              // the 32-pixel tile of screen.h:6-7 this wave is in
-		int x, y;
-		if constexpr(HAS_W)
-		{
-			// the lane's column and row inside the unit from a lane number made here (mbcnt behind an opaque zero): as
-			// loop invariants from the top of the kernel the 4-lane variant, which is out of registers, kept them in scratch
-			// memory -- 16 B per lane stored by every wave, two loads per unit (ScratchSize 16 -> 0, `make resources`)
-			uint32_t ln = 0u;
-			asm volatile("" : "+v"(ln));
-			ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, ln));
-			x = (int)ux * 16 + (int)(ln & 15u); y = P.y0 + (int)uy * 4 + (int)(ln >> 4);
-		}
-		else { x = (int)ux * 16 + l16; y = P.y0 + (int)uy * 4 + (lane >> 4); }
+		const int x = (int)ux * 16 + (HAS_W ? (int)(ln & 15u) : l16), y = P.y0 + (int)uy * 4 + (HAS_W ? (int)(ln >> 4) : (lane >> 4));
 
 		// screen.h:12-18, in the order the reference build evaluates it:
 		// rayl = (cx*rdx + rayb) + y*rdy, then one "+= rdx" per pixel of the
@@ -559,8 +569,8 @@ pwn_trace_kernel(pwn_trace_params P)
 			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
-		// PWN_OPT_WAVE_LOG: what this unit cost its wave (the add chain and the ticket arithmetic in front of it are the same for every unit)
-		if(P.unit_cost != NULL && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+		// what this unit cost its wave (the add chain and the ticket arithmetic in front of it are the same for every unit)
+		if(P.unit_cost != NULL && ln == 0u)
 		{
 			const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - u_begin) >> 2;
 			P.unit_cost[unit] = (uint16_t)(d > 65535ull ? 65535ull : d);

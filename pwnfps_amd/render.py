@@ -72,6 +72,24 @@ class Renderer:
         """frames in flight: successive frames alternate between two compute streams (default) or all run on one"""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_FRAME_OVERLAP, 1 if on else 0), "pwn_set_option")
 
+    def set_unit_order(self, on):
+        """PWN_OPT_UNIT_ORDER: the trace kernel's units handed out by what they cost in the last launch (True, the default) or
+        in arithmetic order (False).  Never changes a frame."""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_UNIT_ORDER, 1 if on else 0), "pwn_set_option")
+
+    def unit_order_state(self):
+        out = (C.c_uint64 * 4)()
+        self._chk(lib.pwn_unit_order_state(self._ctx, out), "pwn_unit_order_state")
+        return {"option": int(out[0]), "launches_in_sorted_order": int(out[1]), "sorts": int(out[2]), "units_ordered": int(out[3])}
+
+    def unit_order_probe(self, cost):
+        """pwn_unit_order_probe: the per-queue sort of `cost` (uint16 per unit) -> [64, cap] uint32, unused entries 0xffffffff"""
+        cost = np.ascontiguousarray(cost, np.uint16)
+        cap = (cost.size + 63) // 64
+        out = np.zeros((64, cap), np.uint32)
+        self._chk(lib.pwn_unit_order_probe(self._ctx, cost.ctypes.data, cost.size, out.ctypes.data), "pwn_unit_order_probe")
+        return out
+
     def set_trace_room(self, workgroups):
         """PWN_OPT_TRACE_ROOM: workgroups the persistent trace grid leaves free for the other stream's kernels while frames
         alternate between two streams; -1 (default) = the library measures which of 0 / one per CU is faster and keeps it"""
