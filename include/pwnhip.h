@@ -115,15 +115,16 @@ typedef struct pwn_stats
                                   frames with no room and with one workgroup per CU, the better kept for ~500 frames (half a second
                                   at least), then again (the answer depends on the scene: +3.5 % at 4K on level.txt, -3 % on a hall of
                                   mirrors); >= 0: that many, always.  Results never depend on it. */
-#define PWN_OPT_UNIT_ORDER 9   /* 1 (default; PWN_UNIT_ORDER=0 in the environment for a process): the trace kernel hands its 16 x 4-pixel units
-                                  out dearest first -- every unit's cost (the time its wave spent on it) is written by the launch, sorted per
-                                  work queue behind the frame's last kernel, and used by the next launch of the same rows on that compute
-                                  stream; the units handed out last are then the cheap ones and the launch's tail is short (a 4K
-                                  launch by itself: -5 %, the strips of an 8-way tiling: -15 ... -30 %, profiles/r4/).  0: arithmetic order,
-                                  rows from the frame's middle row outwards.  The first launch of a geometry uses the arithmetic order.  With the strip
-                                  forms the sort rides behind pwn_blur_rows_device[_bounded] on the caller's stream and serves that stream's
-                                  next pwn_trace_rows_device of the same rows.  Any order gives the same pixels.  The
-                                  reference's counterpart is OpenMP's static schedule over 32-row chunks (screen.h:63-64). */
+#define PWN_OPT_UNIT_ORDER 9   /* 0 (default): the trace kernel hands its 16 x 4-pixel units out in arithmetic order, rows from the frame's
+                                  middle row outwards.  1 (PWN_UNIT_ORDER=1 in the environment for a process): dearest first -- every unit's cost
+                                  (the time its wave spent on it) is written by the launch, put in order per work queue behind the frame's last
+                                  kernel (a counting sort, ~3 us), and used by the next launch of the same rows on that stream, so that the units
+                                  handed out last are the cheap ones.  Measured (profiles/r4/unit_order_ab.txt): a launch of a few units per wave
+                                  that runs alone gets shorter (720p -9 %, a middle strip of an 8-way 4K tiling -10 %), long launches and frames
+                                  on two streams get slower (4K +2 ... +4 %): sorted by cost, units of one kind share a SIMD.  Hence off.  The
+                                  first launch of a geometry uses the arithmetic order; with the strip forms the sort rides behind
+                                  pwn_blur_rows_device[_bounded] on the caller's stream.  Any order gives the same pixels.  The reference's
+                                  counterpart is OpenMP's static schedule over 32-row chunks (screen.h:63-64). */
 #define PWN_OPT_FRAME_TIMING 5 /* frames in flight: record HIP events around the trace and blur kernels of every N-th
                                   frame (pwn_frame.timed, .trace_ms ...); 1 = every frame (default), 0 = never.  An event
                                   between two kernels costs a few microseconds of pipeline */

@@ -90,7 +90,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->stream = NULL; c->copy_stream = NULL; c->stream2 = NULL; c->d_pre2 = NULL;
 	c->frame_overlap = 1; c->last_frame_done = NULL; c->last_frame_stream = NULL;
 	if(const char *e = getenv("PWN_FRAME_OVERLAP")) c->frame_overlap = atoi(e) != 0;
-	c->unit_order = 1;
+	c->unit_order = 0;             // (measured: a loss except on short launches that run alone, profiles/r4/unit_order_ab.txt)
 	if(const char *e = getenv("PWN_UNIT_ORDER")) c->unit_order = atoi(e) != 0;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));

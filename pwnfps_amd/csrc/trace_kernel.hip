@@ -450,7 +450,7 @@ pwn_trace_kernel(pwn_trace_params P)
 		//@R k_unit
 		RG(RG_UNIT);
 		misses = 0;
-		// Which unit a ticket stands for: ticket * 64 + q in arithmetic order, or -- PWN_OPT_UNIT_ORDER, the default -- what
+		// Which unit a ticket stands for: ticket * 64 + q in arithmetic order, or -- PWN_OPT_UNIT_ORDER, off by default -- what
 		// the table says: every queue's units sorted by what they cost in the last launch of this geometry, dearest first
 		// (pwn_order_kernel), so that the units handed out last are the cheap ones.  The reference's answer to uneven rows
 		// is OpenMP's static schedule (screen.h:63-64).  Never changes a pixel: any permutation of the units does.

@@ -73,8 +73,8 @@ class Renderer:
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_FRAME_OVERLAP, 1 if on else 0), "pwn_set_option")
 
     def set_unit_order(self, on):
-        """PWN_OPT_UNIT_ORDER: the trace kernel's units handed out by what they cost in the last launch (True, the default) or
-        in arithmetic order (False).  Never changes a frame."""
+        """PWN_OPT_UNIT_ORDER: the trace kernel's units handed out by what they cost in the last launch (True) or
+        in arithmetic order (False, the default).  Never changes a frame."""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_UNIT_ORDER, 1 if on else 0), "pwn_set_option")
 
     def unit_order_state(self):
