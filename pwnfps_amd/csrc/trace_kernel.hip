@@ -329,7 +329,10 @@ template<bool HAS_W> __device__ __forceinline__ void chain_rounds(Vec<HAS_W> &v,
 			: "+v"(v.x), "+v"(v.y), "+v"(v.z), "=&s"(saved) : "s"(rdx.x), "s"(rdx.y), "s"(rdx.z));
 }
 
-template<bool COUNT, bool HAS_W>
+// ORDER: the launch writes what every unit cost its wave and / or hands its units out by a table (PWN_OPT_UNIT_ORDER, the
+// wave log).  A template parameter, not a test of the two pointers: as dormant code -- two wave-uniform branches and a
+// clock read per unit -- it cost launches that do not use it 2.5-3 % (profiles/r4/unit_order_dormant_cost.txt).
+template<bool COUNT, bool HAS_W, bool ORDER>
 __global__ void __launch_bounds__(PWN_BLOCK, PWN_MIN_WAVES)
 pwn_trace_kernel(pwn_trace_params P)
 {
@@ -467,7 +470,7 @@ pwn_trace_kernel(pwn_trace_params P)
 		uint32_t unit = ticket * PWN_QUEUES + q;
 		// (a SCALAR load: the address is the same for the whole wave, and the scalar cache answers in a fraction of the
 		// microsecond a vector load takes here -- every unit waits for this word before it can do anything)
-		if(P.perm != NULL)
+		if(ORDER && P.perm != NULL)
 		{
 			const uint32_t *pp = P.perm + (uint32_t)__builtin_amdgcn_readfirstlane((int)(q * P.perm_cap + ticket));
 			asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(unit) : "s"(pp) : "memory");
@@ -555,7 +558,7 @@ pwn_trace_kernel(pwn_trace_params P)
 #endif
 
 		unsigned long long u_begin = 0ull;
-		if(P.unit_cost != NULL) u_begin = __builtin_amdgcn_s_memrealtime();
+		if(ORDER && P.unit_cost != NULL) u_begin = __builtin_amdgcn_s_memrealtime();
 		if(x < P.w && y < P.y1)
 		{
 			// screen.h:19-21 (uint32 wrap-around)
@@ -570,7 +573,7 @@ pwn_trace_kernel(pwn_trace_params P)
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
 		// what this unit cost its wave (the add chain and the ticket arithmetic in front of it are the same for every unit)
-		if(P.unit_cost != NULL && ln == 0u)
+		if(ORDER && P.unit_cost != NULL && ln == 0u)
 		{
 			const unsigned long long d = (__builtin_amdgcn_s_memrealtime() - u_begin) >> 2;
 			P.unit_cost[unit] = (uint16_t)(d > 65535ull ? 65535ull : d);
@@ -638,7 +641,7 @@ pwn_trace_kernel(pwn_trace_params P)
 	}
 }
 
-template<bool COUNT, bool HAS_W>
+template<bool COUNT, bool HAS_W, bool ORDER>
 static hipError_t launch_variant(const pwn_trace_params *P, int grid, size_t lds_bytes, hipStream_t stream)
 {
 	// the dynamic-LDS limit is a per-function attribute: raise it only when the blob grew
@@ -656,23 +659,30 @@ static hipError_t launch_variant(const pwn_trace_params *P, int grid, size_t lds
 			// the kernel addresses its tables from LDS address 0 (trace_common.h): that holds while it has no
 			// static LDS, which would be laid out in front of the dynamic allocation
 			hipFuncAttributes fa;
-			hipError_t e = hipFuncGetAttributes(&fa, (const void *)pwn_trace_kernel<COUNT, HAS_W>);
+			hipError_t e = hipFuncGetAttributes(&fa, (const void *)pwn_trace_kernel<COUNT, HAS_W, ORDER>);
 			if(e != hipSuccess) return e;
 			if(fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
-			e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W>,
+			e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W, ORDER>,
 				hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 			if(e != hipSuccess) return e;
 			lds_set = lds_bytes;
 		}
 	}
-	hipLaunchKernelGGL((pwn_trace_kernel<COUNT, HAS_W>), dim3(grid), dim3(PWN_BLOCK), lds_bytes, stream, *P);
+	hipLaunchKernelGGL((pwn_trace_kernel<COUNT, HAS_W, ORDER>), dim3(grid), dim3(PWN_BLOCK), lds_bytes, stream, *P);
 	return hipGetLastError();
+}
+
+template<bool ORDER>
+static hipError_t launch_ordered(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream)
+{
+	if(count) return P->has_w ? launch_variant<true, true, ORDER>(P, grid, lds_bytes, stream) : launch_variant<true, false, ORDER>(P, grid, lds_bytes, stream);
+	return P->has_w ? launch_variant<false, true, ORDER>(P, grid, lds_bytes, stream) : launch_variant<false, false, ORDER>(P, grid, lds_bytes, stream);
 }
 
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream)
 {
-	if(count) return P->has_w ? launch_variant<true, true>(P, grid, lds_bytes, stream) : launch_variant<true, false>(P, grid, lds_bytes, stream);
-	return P->has_w ? launch_variant<false, true>(P, grid, lds_bytes, stream) : launch_variant<false, false>(P, grid, lds_bytes, stream);
+	if(P->perm != NULL || P->unit_cost != NULL) return launch_ordered<true>(P, grid, lds_bytes, count, stream);
+	return launch_ordered<false>(P, grid, lds_bytes, count, stream);
 }
 
 // resident 256-thread workgroups per CU for this variant and LDS size
@@ -688,10 +698,10 @@ extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w)
 {
 	int n = 0;
 	hipError_t e;
-	if(count) e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, true>, PWN_BLOCK, lds_bytes)
-	                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, false>, PWN_BLOCK, lds_bytes);
-	else e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, true>, PWN_BLOCK, lds_bytes)
-	               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, false>, PWN_BLOCK, lds_bytes);
+	if(count) e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, true, false>, PWN_BLOCK, lds_bytes)
+	                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, false, false>, PWN_BLOCK, lds_bytes);
+	else e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, true, false>, PWN_BLOCK, lds_bytes)
+	               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, false, false>, PWN_BLOCK, lds_bytes);
 	if(e != hipSuccess || n < 1) n = 2;
 	return n;
 }

@@ -30,7 +30,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pwnfps_amd", "csrc")
-KERNEL = "_Z16pwn_trace_kernelILb0ELb0EEv16pwn_trace_params"
+KERNEL = "_Z16pwn_trace_kernelILb0ELb0ELb0EEv16pwn_trace_params"
 
 FULL = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_add_u32", "v_sub_u32",
         "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32", "v_bitop3_b32", "v_not_b32", "v_add_co_u32", "v_addc_co_u32",
