@@ -36,6 +36,8 @@
  * -M 1: the frames are delivered to the host by every rank (pwn_tiled_host_sink): one frame buffer in POSIX
  * shared memory, every rank copies its strip into it over its own PCIe link, nothing is gathered to rank 0.
  * -G 1: the gather's root rotates over the ranks (pwn_tiled_gather_root): frame f is assembled, and presented, on rank f mod WORLD.
+ * -X SECONDS / -Y SECONDS: how long the tiling's bring-up / a wait for a frame may wait for the other ranks (pwn_tiled_set_timeouts;
+ * defaults 120 / 60); a rank that does not answer ends the run with the library's message and exit status 2, not with a hang.
  * -q SLOTS (2..4) keeps that many frames in flight (pwn_submit_frame /
  * pwn_wait_frame): the frame and its upscaled surface arrive in the library's
  * pinned host buffers while the next frame's kernels run; frame f is presented
@@ -168,8 +170,12 @@ static uint64_t fnv64(const uint32_t *p, size_t n)
 	return h;
 }
 
+/* print-and-return, the reference's error model (level.h:35-37,110-115).  A deadline of the row tiling (a rank that does not
+   answer, pwn_tiled_set_timeouts) leaves the process at once: a helper thread of the bring-up may still sit inside RCCL, and
+   tearing the runtime down under it is not worth the risk */
 #define CHK(call) do { int rc_ = (call); if(rc_ != PWN_OK) { \
 	fprintf(stderr, "%s -> %s (%d): %s\n", #call, pwn_strerror(rc_), rc_, pwn_last_error(ctx)); \
+	if(rc_ == PWN_ETIMEDOUT) { fflush(NULL); _exit(2); } \
 	pwn_destroy(ctx); return 1; } } while(0)
 
 int main(int argc, char **argv)
@@ -177,6 +183,7 @@ int main(int argc, char **argv)
 	const char *level = NULL, *sphfile = NULL, *gamefile = NULL, *out = NULL, *luafile = NULL, *keyfile = NULL;
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
 	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL, window = 0, frames_given = 0, hostsink = 0;
+	float tiled_init_s = 0.0f, tiled_wait_s = 0.0f;
 	int rotate_root = 0;
 	int rank_given = 0, device_given = 0;
 	const char *idfile = NULL, *nonce = "";
@@ -213,6 +220,8 @@ int main(int argc, char **argv)
 			case 'M': hostsink = atoi(argv[++i]); break;
 			case 'G': rotate_root = atoi(argv[++i]); break;
 			case 'T': transport = strcmp(argv[++i], "shm") == 0 ? PWN_TRANSPORT_SHM : PWN_TRANSPORT_RCCL; break;
+			case 'X': tiled_init_s = (float)atof(argv[++i]); break;
+			case 'Y': tiled_wait_s = (float)atof(argv[++i]); break;
 			default: fprintf(stderr, "unknown option %s\n", argv[i]); return 2;
 		}
 	}
@@ -364,6 +373,7 @@ int main(int argc, char **argv)
 			}
 			if(!got) { fprintf(stderr, "rank %d: no group id of this launch in %s (a stale file of an earlier run? see -N)\n", rank, idfile); pwn_destroy(ctx); return 1; }
 		}
+		if(tiled_init_s > 0.0f || tiled_wait_s > 0.0f) CHK(pwn_tiled_set_timeouts(ctx, (int)(tiled_init_s * 1000.0f), (int)(tiled_wait_s * 1000.0f)));
 		CHK(pwn_tiled_init(ctx, rank, world, id, transport, halo));
 		void *host_frames = NULL;
 		const size_t host_bytes = (size_t)PWN_TILED_SLOTS * npix * 4;

@@ -220,6 +220,22 @@ def test_host_interactive_walk_every_frame_is_the_oracles(host_bin, mode, oracle
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["shm", "rccl"])
+def test_host_with_a_rank_that_never_comes_prints_and_returns(host_bin, transport, tmp_path):
+    """pwnhost -W 2 with only rank 0 started: the tiling's bring-up gives up after -X seconds (pwn_tiled_set_timeouts), the host
+    prints the library's message -- which rank, waiting for what -- and leaves with status 2.  print-and-return, like
+    level.h:35-37,110-115; never a hang."""
+    import time
+    t0 = time.time()
+    p = subprocess.run([host_bin, level_path("pwnfps_level"), "-w", "640", "-h", "360", "-n", "3", "-W", "2", "-R", "0",
+                        "-I", str(tmp_path / "id"), "-T", transport, "-X", "3", "-Y", "2"], capture_output=True, timeout=120)
+    assert p.returncode == 2, (p.returncode, p.stderr[-2000:])
+    err = p.stderr.decode()
+    assert "deadline" in err and "rank 0" in err, err
+    assert time.time() - t0 < 60
+
+
+@pytest.mark.gpu
 def test_host_missing_level_reports_eio(host_bin):
     p = subprocess.run([host_bin, "/nonexistent/level.txt"], capture_output=True, timeout=120)
     assert p.returncode == 1 and b"level file could not be read" in p.stderr
