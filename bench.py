@@ -373,6 +373,8 @@ def main():
     ap.add_argument("--min-time", type=float, default=3.0, help="repeat the K-step block until this many seconds were timed (each of the "
                     "resident and the d2h leg: the GPU is busy for >= 6 s of a default run)")
     ap.add_argument("--sweep-time", type=float, default=0.3, help="N > 1: seconds timed per leg of tiling.sweep (0 = no sweep)")
+    ap.add_argument("--sweep-nonblocking", action="store_true",
+                    help="N > 1 over RCCL: one more sweep leg with the communicator driven non-blocking (PWN_TILED_RCCL_MODE=nonblocking)")
     ap.add_argument("--bringup-timeout", type=float, default=150.0,
                     help="N > 1: seconds the bring-up may take (control plane, preflight, communicator, four frames through every leg of the "
                          "exchange; a fallback to the shared-memory transport starts the clock again); then rank 0 prints a diagnostic line "
@@ -895,8 +897,19 @@ def main():
         if args.post_timeout > 0:
             dog.arm(args.post_timeout, "the legs after the headline")
 
+    # ---- N > 1, first of the legs after the headline: the metric as SURVEY 8(d) words it (every frame delivered to the host).  In
+    # front of the sweep: should one of the sweep's legs not finish, this figure is in the line that the deadline prints.
+    tiling_up = world > 1
+    if world > 1 and not args.no_d2h:
+        leg_name[0] = "host_sink"
+        pcie = host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks,
+                             (lambda buf: oracle.fnv64(buf) == frame_hash) if (rank == 0 and oracle is not None and frame_hash is not None) else None,
+                             mark=board.mark)
+        tiling_up = False                 # (the leg leaves the tiling shut down)
     # ---- N > 1: the same run, other settings, a fraction of a second each: what a first multi-GPU run should look at
-    if world > 1 and args.sweep_time > 0:
+    if world > 1 and args.sweep_time > 0 and not tiling_up:
+        tiling_up, _ = bring_up(transport, tag="sweep:")
+    if world > 1 and args.sweep_time > 0 and tiling_up:
         sweep = {}
 
         def point(name, what):
@@ -949,7 +962,8 @@ def main():
         ok2, _ = bring_up(transport, halo=0, tag="sweep.whole_strips:")
         if ok2:
             point("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows")
-        if transport == "rccl":
+        if transport == "rccl" and args.sweep_nonblocking:
+            # (opt-in: an optional leg on the least-travelled path must not be able to cost a run its clean exit)
             # the other way of driving the communicator: non-blocking, every call polled against the deadline (a grouped launch is
             # then handed to a thread of RCCL's and the host waits for it) -- what that costs the host per frame (enqueue_us)
             barrier()
@@ -992,11 +1006,6 @@ def main():
     if world == 1 and not args.no_d2h:
         pcie = d2h_leg_one_gpu(r, args, w, h, cam, sec, spheres, blocking_best,
                                (lambda buf: oracle.fnv64(buf) == frame_hash) if (oracle is not None and frame_hash is not None) else None)
-    if world > 1 and not args.no_d2h:
-        pcie = host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks,
-                             (lambda buf: oracle.fnv64(buf) == frame_hash) if (rank == 0 and oracle is not None and frame_hash is not None) else None,
-                             mark=board.mark)
-
     dog.disarm()
     post["note"] = None
     if rank == 0:

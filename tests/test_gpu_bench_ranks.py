@@ -95,7 +95,8 @@ def test_bench_line_survives_a_leg_that_does_not_finish():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["frame_fnv64"] == "078fb94a5cd068f5"
     assert d["incomplete"] is True and "legs after the headline" in d["error"]
-    assert [s["rank"] for s in d["stage_reached"]] == [0, 1] and all(s["stage"].startswith("sweep.") for s in d["stage_reached"]), d["stage_reached"]
+    # (the host-delivered leg comes first after the headline, then the sweep: whichever the deadline caught them in)
+    assert [s["rank"] for s in d["stage_reached"]] == [0, 1] and all(s["stage"].startswith(("sweep", "host_sink", "headline_done")) for s in d["stage_reached"]), d["stage_reached"]
     assert "did not finish" in d["tiling"]["post_note"] and len(d["tiling"]["per_rank"]["trace_ms"]) == 2
 
 

@@ -95,6 +95,63 @@ def simulate(cost_of_ticket, nwaves, draw_ahead=True):
     return end, busy / max(nwaves, 1)
 
 
+def simulate_parked(cost_of_ticket, nwaves):
+    """The kernel's order with the ticket drawn ahead PARKED where the three sibling waves of the workgroup can take it (DESIGN.md
+    8, the round-3 review's item 7): a wave that runs dry takes a sibling's parked, not yet started unit instead of leaving; the
+    sibling, done with its current unit, finds its ticket gone and draws again.  Upper bound: stealing costs nothing here."""
+    pos = [0] * Q
+    qlen = [len(c) for c in cost_of_ticket]
+    for q in range(Q):
+        pos[q] = min(qlen[q], (nwaves + Q - 1 - q) // Q)
+
+    def draw(q):
+        for d in range(Q):
+            qq = (q + d) % Q
+            if pos[qq] < qlen[qq]:
+                t = pos[qq]
+                pos[qq] += 1
+                return qq, t
+        return None
+    cur_q = [i % Q for i in range(nwaves)]
+    parked = [None] * nwaves
+    heap = []
+    busy = 0.0
+    for i in range(nwaves):
+        q, t = i % Q, i // Q
+        first = (q, t) if t < qlen[q] else draw(q)
+        if first is None:
+            continue
+        parked[i] = draw(first[0])
+        c = cost_of_ticket[first[0]][first[1]]
+        busy += c
+        cur_q[i] = first[0]
+        heapq.heappush(heap, (c, i))
+    end = 0.0
+    while heap:
+        now, i = heapq.heappop(heap)
+        end = max(end, now)
+        nxt = parked[i]
+        parked[i] = None
+        if nxt is None:
+            nxt = draw(cur_q[i])
+        if nxt is None:
+            # dry: a sibling's parked ticket (workgroup = waves 4k .. 4k + 3)
+            g = i - (i & 3)
+            for sidx in range(g, min(g + 4, nwaves)):
+                if sidx != i and parked[sidx] is not None:
+                    nxt = parked[sidx]
+                    parked[sidx] = None
+                    break
+        if nxt is None:
+            continue
+        cur_q[i] = nxt[0]
+        parked[i] = draw(nxt[0])
+        c = cost_of_ticket[nxt[0]][nxt[1]]
+        busy += c
+        heapq.heappush(heap, (now + c, i))
+    return end, busy / max(nwaves, 1)
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     nwaves = 5120
@@ -122,6 +179,7 @@ def main():
     res = {}
     res["kernel (middle-out rows)"] = simulate(by_q, nwaves)
     res["kernel order, ticket drawn when the unit is done"] = simulate(by_q, nwaves, draw_ahead=False)
+    res["kernel order, the drawn-ahead ticket parked for siblings"] = simulate_parked(by_q, nwaves)
     res["lpt per queue"] = simulate([sorted(c, reverse=True) for c in by_q], nwaves)
     res["lpt per queue, drawn when done"] = simulate([sorted(c, reverse=True) for c in by_q], nwaves, draw_ahead=False)
     # rows by total cost, longest first: unit (k, ux) of the kernel's numbering sits in row middle_out(k); renumber the rows
