@@ -375,7 +375,7 @@ def main():
     ap.add_argument("--sweep-time", type=float, default=0.3, help="N > 1: seconds timed per leg of tiling.sweep (0 = no sweep)")
     ap.add_argument("--sweep-nonblocking", action="store_true",
                     help="N > 1 over RCCL: one more sweep leg with the communicator driven non-blocking (PWN_TILED_RCCL_MODE=nonblocking)")
-    ap.add_argument("--bringup-timeout", type=float, default=150.0,
+    ap.add_argument("--bringup-timeout", type=float, default=300.0,
                     help="N > 1: seconds the bring-up may take (control plane, preflight, communicator, four frames through every leg of the "
                          "exchange; a fallback to the shared-memory transport starts the clock again); then rank 0 prints a diagnostic line "
                          "(value null, the stage every rank reached) and every rank leaves with status 3")
@@ -513,7 +513,9 @@ def main():
         # ---- preflight: what every rank sees (devices, direct peer access from its own, the librccl dlopen resolved, its
         # version, how the communicator will be driven), marked on the board -- readable whatever happens next -- and
         # gathered for the line
-        lib_init_s = max(5.0, min(60.0, args.bringup_timeout * 0.4))
+        # (a first ncclCommInitRank of eight ranks on a cold node can take tens of seconds: a deadline that is too tight would send a
+        # healthy run to the shared-memory fallback; 120 s of 300 by default)
+        lib_init_s = max(5.0, min(120.0, args.bringup_timeout * 0.4))
         lib_wait_s = max(3.0, min(30.0, args.headline_timeout * 0.25))
         r.tiled_set_timeouts(lib_init_s, lib_wait_s)       # below the bench's own deadlines: an error the ranks can agree on comes first
         try:
