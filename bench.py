@@ -160,18 +160,18 @@ def nonfinite_scenes(pwnfps_amd):
 
 
 def model_over_measured(w, h, level, launch_ms):
-    """VALU issue time of one launch by the committed issue model (tools/issue_model.py -> profiles/r3_issue_model.json) over the
+    """VALU issue time of one launch by the committed issue model (tools/issue_model.py -> profiles/r4_issue_model.json) over the
     measured launch time.  NOT a roofline fraction: the model's costs per opcode class come from this repo's own
     microbenchmark, and a value near 1 says "this instruction stream has no stall slack", not "no faster kernel exists"
     (the architectural fractions are roofline.valu_issue_frac_of_peak / lane_slot_frac).  None when the model was not made
     for this frame."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r3_issue_model.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r4_issue_model.json")) as f:
             m = json.load(f)
         for c in m["cases"]:
             if (c["w"], c["h"], c["level"]) == (w, h, level) and launch_ms > 0:
                 return {"valu_issue_ms_model": c["valu_issue_ms"], "ratio": round(c["valu_issue_ms"] / launch_ms, 4),
-                        "model": "profiles/r3_issue_model.txt",
+                        "model": "profiles/r4_issue_model.txt",
                         "what": "the builder's cost model over the measured launch; > 1 only says the cost table over-predicts"}
     except (OSError, KeyError, ValueError):
         pass
@@ -823,7 +823,7 @@ def main():
                          "valu_issue_frac_of_peak": vf["valu_issue_frac_of_peak"] if vf else None,
                          "lane_slot_frac": vf["lane_slot_frac"] if vf else None,
                          "valu": vf,
-                         # ... and against the builder's own cost model (profiles/r3_issue_model.json: per-block instruction mix x
+                         # ... and against the builder's own cost model (profiles/r4_issue_model.json: per-block instruction mix x
                          # measured execution counts x issue cost per opcode class from this repo's microbenchmark) -- a ratio, not a
                          # roofline fraction (it was `issue_frac` until round 3)
                          "model_over_measured": model_over_measured(w, h, args.level, trace_ms) if world == 1 else None,

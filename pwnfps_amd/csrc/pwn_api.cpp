@@ -760,8 +760,11 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	}
 	// PWN_OPT_UNIT_ORDER (and the wave log, for tools/unit_order_sim.py): this launch writes what every unit cost its wave,
 	// and hands its units out in the order sorted from the last launch of the same rows on this stream
-	pwn_ctx::unit_order_state *uop = (!refill && (c->unit_order || c->wave_log_on)) ? order_entry(c, stream, true) : order_entry(c, stream, false);
-	if(uop != NULL && !refill && (c->unit_order || c->wave_log_on))
+	// (with the wave log only where the dump is asked for, PWN_DBG_UNIT_COST: the kernel variant that writes the costs is 2-3 % slower,
+	// and the wave log's span and residency are figures of the ordinary launch)
+	const bool want_cost = !refill && (c->unit_order || (c->wave_log_on && getenv("PWN_DBG_UNIT_COST") != NULL));
+	pwn_ctx::unit_order_state *uop = order_entry(c, stream, want_cost);
+	if(uop != NULL && want_cost)
 	{
 		pwn_ctx::unit_order_state &uo = *uop;
 		const size_t units = (size_t)P.tiles_total;

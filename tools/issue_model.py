@@ -8,13 +8,13 @@
               branch, LDS, vector memory, other (waitcnt, nop)
     dynamic   how often a wave64 runs each region with at least one lane: the counting variant's counters
               (pwn_stats.wave_steps, wave_paths, regions), taken on the GPU by tools/region_counts.py
-              -> profiles/r3_region_counts.json
+              -> profiles/r4_region_counts.json
     costs     ns of SIMD issue per wave-instruction, tools/ubench/valu_rate.hip (profiles/r3_valu_rate.txt): full-rate
               1 / 0.91, half-rate 1 / 0.545, quarter-rate 1 / 0.29 at 5 waves per SIMD with one opcode; 1 / 1.00, 1 / 0.57,
               1 / 0.293 saturated.  Scalar and branch instructions are counted, not priced: they issue beside the VALU
               instructions of other waves (the table shows what they would add if they did not)
 
-    python3 tools/issue_model.py [--counts profiles/r3_region_counts.json] [--out profiles/r3_issue_model]
+    python3 tools/issue_model.py [--counts profiles/r4_region_counts.json] [--out profiles/r4_issue_model]
 
 Prints the per-region table for the headline scene, the instruction totals against the PMC counters of the same
 launch (profiles/pmc_latest.csv: the check that the COUNTS are right, independent of any timing), and predicted
@@ -203,8 +203,8 @@ COUNT_OF = {        # region -> key of the counts
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--counts", default=os.path.join(ROOT, "profiles", "r3_region_counts.json"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r3_issue_model"))
+    ap.add_argument("--counts", default=os.path.join(ROOT, "profiles", "r4_region_counts.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4_issue_model"))
     ap.add_argument("--asm", default=None, help="an existing .s (else compiled here)")
     args = ap.parse_args()
 

@@ -26,7 +26,7 @@ for level, w, h in (("pwnfps_level", 3840, 2160), ("pwnfps_level", 1280, 720), (
         r.trace_screen_centred(cam, 0.0, want_z=False, sbuf=sb)
     r.set_wave_log(True)
     path = os.path.join(out, "%s_%dx%d.u16" % (level, w, h))
-    os.environ["PWN_DBG_UNIT_COST"] = path
+    os.environ["PWN_DBG_UNIT_COST"] = path          # (read by the launch -- the variant that writes the costs -- and by pwn_get_stats, which dumps them)
     r.trace_screen_centred(cam, 0.0, want_z=False, sbuf=sb)
     st = r.stats()
     del os.environ["PWN_DBG_UNIT_COST"]

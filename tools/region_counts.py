@@ -2,7 +2,7 @@
 """The dynamic part of the issue model (tools/issue_model.py), taken on the GPU: for a few scenes one COUNTED frame
 (how often a wave64 enters each region of the trace kernel) and, from uncounted frames of the timed build, the trace
 launch's duration between HIP events and its mean wave residency.
-    python3 tools/region_counts.py [out.json]        (default profiles/r3_region_counts.json)"""
+    python3 tools/region_counts.py [out.json]        (default profiles/r4_region_counts.json)"""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 import pwnfps_amd  # noqa: E402
 
 gold = os.path.join(ROOT, "tests", "golden")
-out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r3_region_counts.json")
+out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r4_region_counts.json")
 RG = ["segs", "setup_slow", "exhausted_w", "wall", "sphere", "floor", "sphrefl", "jitter", "comp1", "comp1_fog", "comp2", "comp2_fog",
       "help", "units", "sphtest", "sphupd", "else", "unit_half", "hc_r2", "hc_out", "portal_wall", "portal_go", "portal_odd", "portal_rot2", "waves"]
 
