@@ -121,8 +121,12 @@ class Watch:
             self.fired = True
         try:
             if self.board.rank == 0:
-                line = self.make_line(reason, self.board.snapshot())
-                self.out.write(json.dumps(line) + "\n")
+                stages = self.board.snapshot()
+                try:
+                    text = json.dumps(self.make_line(reason, stages))
+                except Exception as e:  # noqa: BLE001 -- (the main thread may be changing what the line is made of): the bare facts then
+                    text = json.dumps({"value": None, "incomplete": True, "error": reason, "line_error": repr(e), "stage_reached": stages})
+                self.out.write(text + "\n")
                 self.out.flush()
             else:
                 # rank 0 first: a launcher that ends the job at the first exit must find its line printed
