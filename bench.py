@@ -528,6 +528,16 @@ def main():
         preflight = [None] * world
         dist.all_gather_object(preflight, pre_mine)
         partial["line"] = {"tiling": {"preflight": preflight}}
+        # (what to read first when a run falls back to the shared-memory transport: a rank whose device cannot reach another rank's
+        # directly, ranks that resolved different librccl files)
+        try:
+            unreachable = [[q["rank"], d] for q in preflight for d, ok in enumerate(q.get("can_access_peer", [])) if ok != 1]
+            libs = sorted({str(q.get("librccl")) for q in preflight})
+            preflight_summary = {"every_device_reaches_every_other": not unreachable, "unreachable_rank_device_pairs": unreachable[:32],
+                                 "librccl_files": libs, "rccl_versions": sorted({q.get("rccl_version") for q in preflight})}
+        except Exception as e:                                       # noqa: BLE001
+            preflight_summary = {"error": str(e)}
+        partial["line"]["tiling"]["preflight_summary"] = preflight_summary
         # Every rank first checks that it can load the transport at all (a rank without librccl would leave the
         # others waiting inside ncclCommInitRank).  If one cannot, all ranks agree on the shared-memory test
         # transport instead -- the same kernels and messages, through the host -- and the line says so.
@@ -854,6 +864,7 @@ def main():
                                                     "max_rows", "balance_every", "grid_reserve", "two_streams", "recuts")}
             line["tiling"]["transport"] = transport
             line["tiling"]["preflight"] = preflight
+            line["tiling"]["preflight_summary"] = preflight_summary
             line["tiling"]["rccl_nonblocking"] = tinfo.get("rccl_nonblocking")
             line["tiling"]["deadlines_s"] = {"library_init": lib_init_s, "library_wait": lib_wait_s, "bring_up": args.bringup_timeout,
                                              "headline": args.headline_timeout, "post": args.post_timeout}

@@ -53,6 +53,7 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     for q in pf:
         assert q["devices_visible"] >= 1 and q["can_access_peer"][q["device"]] == 1 and q["rccl_version"] > 20000 and os.path.basename(q["librccl"]).startswith("librccl")
         assert q["rccl_mode"] == "blocking" and q["init_timeout_ms"] == int(t["deadlines_s"]["library_init"] * 1000)
+    assert t["preflight_summary"]["every_device_reaches_every_other"] is True and len(t["preflight_summary"]["librccl_files"]) == 1
     assert t["deadlines_s"]["bring_up"] == 300.0 and t["deadlines_s"]["library_init"] < t["deadlines_s"]["bring_up"]
     assert "incomplete" not in d and "stage_reached" not in d
     # every rank's own account of the headline leg, and the cuts (they move with what the strips cost)
