@@ -1,5 +1,5 @@
 # The randomised parity campaign that closes a round: generic and lattice scenes, the forced 4-lane variant, the
-# refill scheduler, large frames, and the frames in flight on two compute streams -- new seeds, 17 240 scenes + 420 frames + 14 tiled runs, ~17 GPU-minutes.
+# refill scheduler, large frames, and the frames in flight on two compute streams -- new seeds, 17 240 scenes + 420 frames + 14 tiled runs + 12 runs with a rank that leaves, ~18 GPU-minutes.
 #   gpurun -- bash tools/fuzz_campaign.sh [SEED0]   -> gpurun_out/fuzz2/*.txt, one summary line per leg on stdout
 #   (seeds SEED0 .. SEED0+7, default 9101)
 S=${1:-9101}
@@ -16,3 +16,4 @@ run bigl$((S+7)) python tools/fuzz_parity.py 120 $((S+7)) --lattice --size 1920x
 run frames$((S+8)) python tools/fuzz_frames.py 300 $((S+8)) 1280x720
 run frames4k$((S+9)) python tools/fuzz_frames.py 120 $((S+9)) 3840x2160
 run tiled$((S+10)) python tools/fuzz_tiled.py 14 $((S+10))
+run deadlines$((S+11)) python tools/fuzz_deadlines.py 12 $((S+11))
