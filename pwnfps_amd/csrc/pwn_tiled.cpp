@@ -554,6 +554,11 @@ struct pwn_tiled
 	hipEvent_t ev_k0[NSLOT], ev_k1[NSLOT], ev_k2[NSLOT], ev_k3[NSLOT];      // timing (PWN_OPT_FRAME_TIMING): around the trace, around the blur
 	hipEvent_t ev_g0[NSLOT], ev_g1[NSLOT], ev_g2[NSLOT], ev_g3[NSLOT];      // ... on the comm stream: around the gather group (g0, g1), around the halo group (g2, g3)
 	hipStream_t fstream[NSLOT];         // the compute stream the slot's frame is on: cs[f & 1], or cs[0] for a counted frame (one set of counters)
+	// PWN_TILED_SELF=1 with ONE rank over RCCL (measurement only: profiles/r4/rccl_self_exchange.txt): the rank sends itself what a rank
+	// of a real tiling sends -- H border rows behind every trace, its finished strip and its two words behind every blur, two sends and
+	// two receives to the same peer in each grouped launch -- into a scratch plane, so that RCCL's kernels, the room they find beside the
+	// persistent trace grid and the host's cost per grouped launch can be measured on a box with one GPU
+	bool self_exchange; uint32_t *self_buf;
 	hipEvent_t gathered_by[NSLOT];      // which of the above marks the slot's gather as done
 	// host sink: NSLOT whole frames in host memory shared by the ranks; this rank's copies on their own stream
 	uint8_t *host_base; void *host_registered;   // the frames; what this context registered with the device (or NULL)
@@ -740,7 +745,7 @@ void pwn_tiled_destroy(pwn_ctx *c)
 			&t->ev_g0[s], &t->ev_g1[s], &t->ev_g2[s], &t->ev_g3[s], &t->ev_h[s] };
 		for(size_t i = 0; i < sizeof(evs) / sizeof(evs[0]); i++) if(*evs[i]) (void)hipEventDestroy(*evs[i]);
 	}
-	(void)hipFree(t->cost_acc);
+	(void)hipFree(t->cost_acc); (void)hipFree(t->self_buf);
 	if(t->copy) (void)hipStreamDestroy(t->copy);
 	if(t->host_registered) (void)hipHostUnregister(t->host_registered);
 	if(t->h_missv) (void)hipHostFree(t->h_missv);
@@ -898,7 +903,12 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	// on 16 CUs, 1.25 % of the grid.  Not measurable without several GPUs; PWN_TILED_RESERVE=n overrides it
 	// (0 = fill every CU), pwn_tiled_set_reserve() changes it between frames: bench.py --gpus N sweeps it.
 	c->grid_reserve = 0;
-	if(world > 1 && transport == PWN_TRANSPORT_RCCL)
+	if(world == 1 && transport == PWN_TRANSPORT_RCCL && getenv("PWN_TILED_SELF") != NULL && atoi(getenv("PWN_TILED_SELF")) != 0)
+	{
+		if(hipMalloc((void **)&t->self_buf, n * 4 + 64) != hipSuccess) { pwn_tiled_destroy(c); return PWN_ENOMEM; }
+		t->self_exchange = true;
+	}
+	if((world > 1 || t->self_exchange) && transport == PWN_TRANSPORT_RCCL)
 	{
 		c->grid_reserve = 16;
 		if(const char *e = getenv("PWN_TILED_RESERVE")) { int v = atoi(e); if(v >= 0 && v <= 512) c->grid_reserve = v; }
@@ -1046,6 +1056,21 @@ static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 		t->info.bytes_sent += (unsigned long long)(y1 - y0) * w4;
 	}
 	return add_words(c, t, s);
+}
+
+// PWN_TILED_SELF: what a rank of a real tiling puts into the gather group, to itself
+static int add_self_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
+{
+	const int s = (int)(g % NSLOT);
+	const size_t w4 = (size_t)c->w * 4;
+	const uint32_t *mine = t->fin[s];          // (one rank is its own root: blur -- or, without one, the trace -- wrote straight into the assembled frame)
+	int y0, y1; rows_of(t, s, 0, &y0, &y1);
+	TPCHK(c, t->tp->send(mine + (size_t)y0 * c->w, (size_t)(y1 - y0) * w4, 0));
+	TPCHK(c, t->tp->recv(t->self_buf, (size_t)(y1 - y0) * w4, 0));
+	TPCHK(c, t->tp->send(t->missw[s], 8, 0));
+	TPCHK(c, t->tp->recv(t->missv[s], 8, 0));
+	t->info.bytes_sent += (unsigned long long)(y1 - y0) * w4 + 8; t->info.bytes_received += (unsigned long long)(y1 - y0) * w4 + 8;
+	return PWN_OK;
 }
 
 // behind a group that carried frame g's words: bring them (and this rank's own) to pinned host memory on the comm
@@ -1200,10 +1225,10 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 		}
 		const int gs = (int)((g_end - 1) % NSLOT);
 		if(t->timed[gs]) { HIPCHK(c, hipEventRecord(t->ev_g0[gs], t->comm)); }
-		if(t->world > 1)
+		if(t->world > 1 || t->self_exchange)
 		{
 			TPCHK(c, t->tp->begin(t->comm));
-			for(unsigned long long g = t->gathered; g < g_end; g++) { rc = add_gather(c, t, g); if(rc != PWN_OK) return rc; }
+			for(unsigned long long g = t->gathered; g < g_end; g++) { rc = t->self_exchange ? add_self_gather(c, t, g) : add_gather(c, t, g); if(rc != PWN_OK) return rc; }
 			TPCHK(c, t->tp->end());
 			t->info.groups++;
 		}
@@ -1217,6 +1242,19 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	// ---- then this frame's pre-blur rows, behind its trace
 	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g2[s], t->comm));
+	if(t->self_exchange && c->blur_passes)
+	{
+		// (to itself: the rows a middle rank exchanges with its two neighbours, out of this frame's pre-blur plane into the scratch plane)
+		const int H = (int)(0.002 * c->h * 24.0) + 2 < (y1 - y0) ? (int)(0.002 * c->h * 24.0) + 2 : (y1 - y0);
+		TPCHK(c, t->tp->begin(t->comm));
+		TPCHK(c, t->tp->send(t->pre[s] + (size_t)y0 * c->w, (size_t)H * w4, 0));
+		TPCHK(c, t->tp->recv(t->self_buf, (size_t)H * w4, 0));
+		TPCHK(c, t->tp->send(t->pre[s] + (size_t)(y1 - H) * c->w, (size_t)H * w4, 0));
+		TPCHK(c, t->tp->recv(t->self_buf + (size_t)H * c->w, (size_t)H * w4, 0));
+		TPCHK(c, t->tp->end());
+		t->info.groups++;
+		t->info.bytes_sent += 2ull * H * w4; t->info.bytes_received += 2ull * H * w4;
+	}
 	if(t->world > 1 && c->blur_passes)
 	{
 		TPCHK(c, t->tp->begin(t->comm));
@@ -1313,10 +1351,10 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
 			if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));
 		}
-		if(t->world > 1)
+		if(t->world > 1 || t->self_exchange)
 		{
 			TPCHK(c, t->tp->begin(t->comm));
-			for(unsigned long long g = t->gathered; g <= d; g++) { rc = add_gather(c, t, g); if(rc != PWN_OK) return rc; }
+			for(unsigned long long g = t->gathered; g <= d; g++) { rc = t->self_exchange ? add_self_gather(c, t, g) : add_gather(c, t, g); if(rc != PWN_OK) return rc; }
 			TPCHK(c, t->tp->end());
 			t->info.groups++;
 		}

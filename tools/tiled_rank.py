@@ -18,7 +18,9 @@ TILED_DIE_AT="K:RANK": that rank leaves the process (exit code 17) right before 
 tiling call fails prints `error CODE after S s: MESSAGE`, then `info {...}` if there still is a tiling, and exits with 42.
 TILED_COUNTERS=1 / TILED_WAVELOG=1: the counting options on; every rank prints `stats K RAYS WAVES` per delivered frame.
 TILED_TIMING=1: every frame timed (PWN_OPT_FRAME_TIMING 1); `times K TRACE BLUR HALO GATHER` per delivered frame.
-Every rank ends with a line `host frames N in S s = MS ms per frame; pwn_tiled_submit US us per frame`."""
+Every rank ends with a line `host frames N in S s = MS ms per frame; pwn_tiled_submit US us per frame` (+ the means of the
+timed kernels and exchanges); TILED_QUIET=1: only the last frame is hashed and printed, so that MS is the loop's own time.
+PWN_TILED_SELF=1 (read by the library, one rank over RCCL): the rank sends itself what a rank of a real tiling sends."""
 import json
 import os
 import sys
@@ -127,23 +129,32 @@ def main():
 
     fr_rows = [0, 0]
     enq = []
+    tms = {"trace_ms": [], "blur_ms": [], "halo_ms": [], "gather_ms": [], "frame_ms": []}
+    quiet = bool(os.environ.get("TILED_QUIET"))          # only the last frame is hashed and printed: the loop's own time per frame means something then
     t_run = time.time()
 
     def deliver(k):
         t_call[0] = time.time()
         try:
-            fr = r.tiled_wait(host=True)
+            fr = r.tiled_wait(host=(not quiet) or k + 1 >= frames)
         except pwnfps_amd.PwnError as e:
             failed(e)
         assert fr["seq"] == k + 1
         fr_rows[0], fr_rows[1] = fr["y0"], fr["y1"]
-        print("rows %d %d %d %d" % (k, fr["y0"], fr["y1"], fr["cost"]), flush=True)
+        if not quiet:
+            print("rows %d %d %d %d" % (k, fr["y0"], fr["y1"], fr["cost"]), flush=True)
         if os.environ.get("TILED_COUNTERS") or os.environ.get("TILED_WAVELOG"):
             st = r.stats()
             print("stats %d %d %d" % (k, st["rays"], st["waves"]), flush=True)
         if os.environ.get("TILED_TIMING"):
-            print("times %d %.6f %.6f %.6f %.6f" % (k, fr["trace_ms"], fr["blur_ms"], fr["halo_ms"], fr["gather_ms"]), flush=True)
+            if not quiet:
+                print("times %d %.6f %.6f %.6f %.6f" % (k, fr["trace_ms"], fr["blur_ms"], fr["halo_ms"], fr["gather_ms"]), flush=True)
+            for key in tms:
+                if fr[key] > 0:
+                    tms[key].append(fr[key])
         enq.append(fr["enqueue_us"])
+        if quiet and k + 1 < frames:
+            return
         if (rank == 0 and hostsink) or (not hostsink and fr.get("sbuf") is not None):
             # (without a host sink: the frame's root has it -- rank 0, or rank k mod world with TILED_ROTATE=1)
             assert hostsink or fr["root"] == rank
@@ -172,8 +183,9 @@ def main():
         st = r.stats()                       # every frame delivered: the last launch's own counts
         print("laststats %d %d %d %d" % (st["rays"], st["waves"], fr_rows[0], fr_rows[1]), flush=True)
     if enq:
-        print("host frames %d in %.4f s = %.4f ms per frame; pwn_tiled_submit %.1f us per frame (median %.1f)" % (
-            frames, time.time() - t_run, (time.time() - t_run) / frames * 1e3, float(np.mean(enq)), float(np.median(enq))), flush=True)
+        print("host frames %d in %.4f s = %.4f ms per frame; pwn_tiled_submit %.1f us per frame (median %.1f)%s" % (
+            frames, time.time() - t_run, (time.time() - t_run) / frames * 1e3, float(np.mean(enq)), float(np.median(enq)),
+            "".join("; %s %.4f" % (k, float(np.mean(v))) for k, v in tms.items() if v)), flush=True)
     print("info " + json.dumps(r.tiled_info()), flush=True)
     print("cuts " + json.dumps([int(v) for v in r.tiled_get_cuts()[0]]), flush=True)
     r.tiled_shutdown()
