@@ -9,9 +9,9 @@ reference's level.txt scene (its 14 game.lua spheres, camera at the spawn
 pose, sec_current = 0) at 3840x2160 with the post-process blur on, i.e. one
 level_prepare_render() + trace_screen_centred() (main.c:95,107; screen.h:31-124).  With N > 1 the frame is row-tiled
 behind the C ABI (pwn_tiled_*, pwnfps_amd/csrc/pwn_tiled.cpp): rank r traces rows
-[r*per, (r+1)*per), two grouped RCCL send/recv launches per frame carry the finished strips
-of the frame two back to rank 0 and this frame's pre-blur halo rows between neighbour
-strips, each rank blurs its strip; three frames are in flight.  Level/sphere
+[r*per, (r+1)*per), two grouped RCCL send/recv launches per frame carry the frame's pre-blur halo rows
+between neighbour strips and, behind the rank's blur of its strip, the finished strips to rank 0 -- all of it in order on the
+frame's own compute stream, frames alternating between two; three frames are in flight.  Level/sphere
 tables and all frame buffers are resident in HBM before the timed region; in the
 timed region of `value` the frame stays on the device (rank 0's for N > 1).  The rate with every frame handed over to the host (what
 trace_screen_centred does with sbuf, main.c:107) is measured in the same run
@@ -26,10 +26,11 @@ Prints ONE JSON line on rank 0.  After the timed region the last frame is
 hashed and compared with the golden hash of the compiled reference.
 
 N > 1: the line carries what it takes to read a first multi-GPU run from the driver's output alone --
-`tiling.per_rank` (every rank's trace / blur kernel times, the durations of the two grouped exchanges on the
-comm stream, host enqueue time per frame, rows and cost of its strip), the moving cuts, and `tiling.sweep`: short
+`tiling.per_rank` (every rank's trace / blur kernel times, the durations of the two grouped exchanges,
+host enqueue time per frame, rows and cost of its strip), the moving cuts, and `tiling.sweep`: short
 legs in the same run with the trace grid's room for RCCL at 0 / 16 / 64 workgroups, the gather spread over the
-ranks (`rotating_root`), equal strips, one compute stream, and whole strips instead of the bounded halo.  `transport` says at top level what carried the data; over
+ranks (`rotating_root`), equal strips, one compute stream, whole strips instead of the bounded halo, and the other
+choreography (`choreo_split`: the exchanges on a third stream).  `transport` says at top level what carried the data; over
 the shared-memory fallback the metric string says that the figure is NOT RCCL over xGMI.
 
 N > 1 cannot fail silently (pwnfps_amd/watch.py): every rank marks the stage it is in in the control plane's key-value
@@ -663,7 +664,7 @@ def main():
             for i in range(max(0, n - nres), n):
                 note(r.wait_frame(i % nres))
         else:
-            # N > 1: three frames in flight; the exchange of frame i carries the result of frame i-2
+            # N > 1: three frames in flight
             for i in range(n):
                 if not early or i == 0:
                     r.set_objects(spheres)
@@ -863,6 +864,8 @@ def main():
             line["tiling"] = {k: tinfo[k] for k in ("rows_per_rank", "halo_rows", "groups", "frames", "frames_redone", "bytes_sent", "bytes_received",
                                                     "max_rows", "balance_every", "grid_reserve", "two_streams", "recuts")}
             line["tiling"]["transport"] = transport
+            line["tiling"]["choreography"] = ("in-stream: trace, halo rows, blur, gather and words of a frame in order on the frame's own compute stream, frames "
+                                              "alternating between two (PWN_OPT_TILED_CHOREO; sweep.choreo_split = the other form)")
             line["tiling"]["preflight"] = preflight
             line["tiling"]["preflight_summary"] = preflight_summary
             line["tiling"]["rccl_nonblocking"] = tinfo.get("rccl_nonblocking")
@@ -975,6 +978,17 @@ def main():
         ok2, _ = bring_up(transport, halo=0, tag="sweep.whole_strips:")
         if ok2:
             point("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows")
+        # the choreography of rounds 2-3: the exchanges on a third stream, blur and gather one and two submits late
+        barrier()
+        r.tiled_shutdown()
+        r.set_tiled_choreo(True)
+        ok4, _ = bring_up(transport, tag="sweep.choreo_split:")
+        if ok4:
+            point("choreo_split", "PWN_OPT_TILED_CHOREO = split: the exchanges on a third stream tied to the kernels by events, blur f enqueued by submit f+1 "
+                                  "and its gather by submit f+2 (the headline: everything of a frame in order on the frame's own stream)")
+        barrier()
+        r.tiled_shutdown()
+        r.set_tiled_choreo(False)
         if transport == "rccl" and args.sweep_nonblocking:
             # (opt-in: an optional leg on the least-travelled path must not be able to cost a run its clean exit)
             # the other way of driving the communicator: non-blocking, every call polled against the deadline (a grouped launch is
@@ -986,7 +1000,6 @@ def main():
             if ok3:
                 point("rccl_nonblocking", "PWN_TILED_RCCL_MODE=nonblocking: ncclCommInitRankConfig(blocking = 0), every call polled with ncclCommGetAsyncError")
             del os.environ["PWN_TILED_RCCL_MODE"]
-        # (the host-sink leg below sets the tiling up once more)
 
     if world == 1:
         r.set_counters(True)

@@ -115,6 +115,16 @@ typedef struct pwn_stats
                                   frames with no room and with one workgroup per CU, the better kept for ~500 frames (half a second
                                   at least), then again (the answer depends on the scene: +3.5 % at 4K on level.txt, -3 % on a hall of
                                   mirrors); >= 0: that many, always.  Results never depend on it. */
+#define PWN_OPT_TILED_CHOREO 10 /* row tiling, read by pwn_tiled_init (PWN_EBUSY while a tiling exists; PWN_TILED_CHOREO=split in the environment
+                                  for a process).  PWN_TILED_CHOREO_INSTREAM (default): pwn_tiled_submit(f) enqueues everything of frame f --
+                                  trace, halo rows, blur, gather, words -- in order on the frame's own compute stream (frames alternate between
+                                  two); frame f's exchange overlaps the other stream's trace f+1 and no event crosses a queue.
+                                  PWN_TILED_CHOREO_SPLIT (rounds 2-3): the exchanges on a third stream tied to the kernels by four events per
+                                  frame, blur f enqueued by submit f+1 and its gather by submit f+2.  Same frames either way.  Measured on one
+                                  GPU (profiles/r4/host_bound.txt): split costs a rank 0.14-0.21 ms per frame whatever the frame's
+                                  size -- a strip of an 8-way tiled 4K frame needs 0.05 ms of kernels. */
+#define PWN_TILED_CHOREO_INSTREAM 0
+#define PWN_TILED_CHOREO_SPLIT    1
 #define PWN_OPT_UNIT_ORDER 9   /* 0 (default): the trace kernel hands its 16 x 4-pixel units out in arithmetic order, rows from the frame's
                                   middle row outwards.  1 (PWN_UNIT_ORDER=1 in the environment for a process): dearest first -- every unit's cost
                                   (the time its wave spent on it) is written by the launch, put in order per work queue behind the frame's last
@@ -300,13 +310,14 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
  *                        with such a tap is repeated with whole strips before it is delivered, and
  *                        whole strips are used from then on: delivered frames are always exact.
  *                        POSTPROC_BLUR 0 or 1.
- *   pwn_tiled_submit     enqueue one frame on every rank: trace own strip, blur the previous frame's
- *                        strip, two grouped exchanges (the finished strips of the frame two back to rank 0
- *                        with its miss words; then this frame's halo rows).  At most three frames in
- *                        flight (PWN_EBUSY): a frame then costs max(kernels, exchange), not their sum, and
- *                        waiting for frame f-2 right after submitting f does not wait for f's trace.
+ *   pwn_tiled_submit     enqueue one frame on every rank, in order on the frame's compute stream: trace own strip,
+ *                        one grouped exchange (the strip's border rows with the neighbour strips), blur the strip,
+ *                        a second grouped exchange (the finished strip to the frame's root, the rank's two words to
+ *                        every rank).  Frames alternate between two streams, so that a frame's exchange overlaps the
+ *                        next frame's trace: a frame then costs max(kernels, exchange), not their sum
+ *                        (PWN_OPT_TILED_CHOREO).  At most PWN_TILED_SLOTS - 1 = five frames in flight (PWN_EBUSY).
  *   pwn_tiled_wait       every rank: block until the oldest frame in flight is complete; on rank 0 (the frame's root)
- *                        out->d_sbuf is the full frame on the device (valid until three more frames
+ *                        out->d_sbuf is the full frame on the device (valid until five more frames
  *                        were submitted) and, with PWN_TILED_HOST, out->sbuf a pinned host copy.
  *   pwn_tiled_host_sink  optional, every rank, after pwn_tiled_init and before the first frame: frames are
  *                        delivered to the HOST instead (main.c:107-109 presents every frame there).  `base` is
@@ -351,7 +362,7 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
 #define PWN_TRANSPORT_RCCL 0
 #define PWN_TRANSPORT_SHM  1
 #define PWN_TILED_HOST     1
-#define PWN_TILED_SLOTS    4       /* frames a host sink holds (three in flight and the one being reused) */
+#define PWN_TILED_SLOTS    6       /* frames a host sink holds (at most five in flight and the one being reused) */
 #define PWN_TILED_MAX_WORLD 64
 #define PWN_TILED_ROOT_FIXED  0
 #define PWN_TILED_ROOT_ROTATE 1

@@ -15,6 +15,8 @@ PWN_OPT_BLUR_PASSES, PWN_OPT_COUNTERS, PWN_OPT_SCHEDULER, PWN_OPT_REFILL_LIMIT, 
 PWN_OPT_FRAME_OVERLAP = 7
 PWN_OPT_TRACE_ROOM = 8
 PWN_OPT_UNIT_ORDER = 9
+PWN_OPT_TILED_CHOREO = 10
+PWN_TILED_CHOREO_INSTREAM, PWN_TILED_CHOREO_SPLIT = 0, 1
 PWN_SCHED_UNITS, PWN_SCHED_REFILL = 0, 1
 PWN_MAX_SLOTS = 4
 PWN_FRAME_SBUF, PWN_FRAME_ZBUF, PWN_FRAME_SURFACE = 1, 2, 4
@@ -64,7 +66,7 @@ class TiledInfo(C.Structure):
 PWN_TILED_ID_BYTES = 128
 PWN_TRANSPORT_RCCL, PWN_TRANSPORT_SHM = 0, 1
 PWN_TILED_HOST = 1
-PWN_TILED_SLOTS = 4
+PWN_TILED_SLOTS = 6
 PWN_TILED_MAX_WORLD = 64
 
 # every symbol include/pwnhip.h declares: (name, restype, argtypes)

@@ -530,6 +530,20 @@ extern "C" hipError_t pwn_launch_upload(const void *h_pinned_src, void *d_dst, s
 	return hipGetLastError();
 }
 
+// The two words of every rank's strip (pwn_tiled.cpp: the miss word and the cost word) from where the exchange left them
+// to pinned host memory, by a kernel: two DMA copies of 8 bytes each cost the comm stream 20-50 us per frame, and the
+// host, which reads the words when it takes the frame, waited for them (profiles/r4/host_bound.txt).
+__global__ void pwn_words_kernel(const uint32_t *__restrict__ all, const uint32_t *__restrict__ own, uint32_t *h, int world)
+{
+	for(int i = threadIdx.x; i < 2 * world + 2; i += 64) h[i] = i < 2 * world ? all[i] : own[i - 2 * world];
+}
+
+extern "C" hipError_t pwn_launch_words(const uint32_t *d_all, const uint32_t *d_own, uint32_t *h_pinned_dst, int world, hipStream_t stream)
+{
+	hipLaunchKernelGGL(pwn_words_kernel, dim3(1), dim3(64), 0, stream, d_all, d_own, h_pinned_dst, world);
+	return hipGetLastError();
+}
+
 // --------------------------------------------------------------- probes ----
 // Device-side known-answer access to the arithmetic primitives (pwnhip.h
 // PWN_PROBE_*).  tabs = the rcp+rsqrt part of the blob (2 x 2048 u16).

@@ -92,6 +92,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	if(const char *e = getenv("PWN_FRAME_OVERLAP")) c->frame_overlap = atoi(e) != 0;
 	c->unit_order = 0;             // (measured: a loss except on short launches that run alone, profiles/r4/unit_order_ab.txt)
 	if(const char *e = getenv("PWN_UNIT_ORDER")) c->unit_order = atoi(e) != 0;
+	c->tiled_choreo = PWN_TILED_CHOREO_INSTREAM;
+	if(const char *e = getenv("PWN_TILED_CHOREO")) c->tiled_choreo = (strcmp(e, "split") == 0 || strcmp(e, "1") == 0) ? PWN_TILED_CHOREO_SPLIT : PWN_TILED_CHOREO_INSTREAM;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));
 	c->frame_timing = 1; c->wave_log_on = 0; c->d_wave_log = NULL; c->wave_log_cap = 0;
@@ -272,6 +274,10 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 		case PWN_OPT_FRAME_TIMING: if(value < 0) return PWN_EINVAL; c->frame_timing = value; return PWN_OK;
 		case PWN_OPT_REFILL_LIMIT: if(value < 1 || value > 64000) return PWN_EINVAL; c->refill_limit = value; return PWN_OK;
 		case PWN_OPT_UNIT_ORDER: if(value != 0 && value != 1) return PWN_EINVAL; c->unit_order = value; for(int i = 0; i < 4; i++) c->order[i].perm_valid = false; return PWN_OK;
+		case PWN_OPT_TILED_CHOREO:
+			if(value != PWN_TILED_CHOREO_INSTREAM && value != PWN_TILED_CHOREO_SPLIT) return PWN_EINVAL;
+			if(c->tiled != NULL) return PWN_EBUSY;
+			c->tiled_choreo = value; return PWN_OK;
 		case PWN_OPT_TRACE_ROOM: if(value < -1 || value > 4096) return PWN_EINVAL; memset(&c->room, 0, sizeof(c->room)); c->room.mode = value; return PWN_OK;
 		case PWN_OPT_FRAME_OVERLAP:
 			for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;

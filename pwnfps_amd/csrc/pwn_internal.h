@@ -36,6 +36,7 @@ extern "C" hipError_t pwn_launch_blur(const pwn_blur_params *P, hipStream_t stre
 extern "C" hipError_t pwn_launch_order(const uint16_t *cost, uint32_t units, uint32_t cap, uint32_t *perm, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upscale(const uint32_t *src, uint32_t *dst, int w, int h, int scale, int pitch, hipStream_t stream);
 extern "C" hipError_t pwn_launch_upload(const void *h_pinned_src, void *d_dst, size_t bytes, hipStream_t stream);
+extern "C" hipError_t pwn_launch_words(const uint32_t *d_all, const uint32_t *d_own, uint32_t *h_pinned_dst, int world, hipStream_t stream);
 extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out, int n, const uint16_t *tabs, hipStream_t stream);
 
 // LDS budget for the table blob: leave room so that at least two workgroups
@@ -139,6 +140,7 @@ struct pwn_ctx
 		uint32_t perm_units; int perm_y0, perm_y1; bool perm_valid;           // what d_perm orders
 	} order[4];
 	unsigned long long order_stamp;
+	int tiled_choreo;                // PWN_OPT_TILED_CHOREO, read by pwn_tiled_init
 	int unit_order;                  // the option: 1 = units handed out by last launch's cost, 0 = arithmetic order
 	unsigned long long order_used, order_sorts;      // trace launches that ran in a sorted order; sorts launched (pwn_unit_order_state)
 	bool dbg_force_hasw; int dbg_blocks_per_cu;      // PWN_DBG_* hooks, read at pwn_init

@@ -4,37 +4,34 @@
 // [r * rows_per, min((r + 1) * rows_per, h)), rows_per = ceil(h / world) rounded up to 8
 // (the reference parallelises the same two loops with OpenMP over rows, screen.h:63,77).
 // The trace pass needs no exchange.  The blur does: its taps reach 0.002*h*(depth-1) rows
-// (screen.h:100-102), unbounded in depth.  Per submitted frame f (slot s = f mod 4) a rank enqueues
+// (screen.h:100-102), unbounded in depth.  Per submitted frame f (slot s = f mod 6) a rank enqueues, IN ORDER ON THE
+// FRAME'S OWN COMPUTE STREAM (frames alternate between two):
 //
-//   compute stream   trace strip f -> pre[s], z[s]
-//   comm stream      TWO grouped exchanges, each a single RCCL launch:
-//                      G2(f-2), behind blur f-2 only: the FINISHED strip of frame f-2 to rank 0 (the gather) and its
-//                               miss word to every rank (see below)
-//                      G1(f), behind that trace: the H border rows of strip f to / from the neighbour strips,
-//                               straight out of / into the full-frame plane pre[s] (or, without a halo, every
-//                               strip to everybody: an all-gather by send / recv)
-//   compute stream   blur strip f-1 from pre rows [y0-H, y1+H) -> out, behind G1(f-1); taps outside those rows are
-//                    counted in the rank's miss word of that frame
+//   trace strip f -> pre[s], z[s]
+//   G1(f)   one grouped exchange, a single RCCL launch: the H border rows of strip f to / from the neighbour strips,
+//           straight out of / into the full-frame plane pre[s] (or, without a halo, every strip to everybody: an
+//           all-gather by send / recv)
+//   blur strip f from pre rows [y0-H, y1+H) -> out; taps outside those rows are counted in the rank's miss word
+//   G2(f)   the second grouped exchange: the FINISHED strip of frame f to the frame's root (the gather) and the rank's
+//           two words to every rank (see below)
+//   a kernel that stores every rank's words into pinned host memory, and the event pwn_tiled_wait waits for
 //
-// The blur of a frame is enqueued one submit late, BEHIND the next frame's trace, so the compute stream does not
-// sit waiting for the exchange: G1(f) is on the wire while trace f+1 and blur f-1 run, and a frame costs
-// max(kernels, exchange), not their sum.  The gather is a group of its own, in front of G1(f), so that it does not
-// wait for trace f: the host that collects frame f-2 after submitting f has it while trace f still runs and is back
-// with frame f+1's launches before the GPU is idle.  (As ONE group per frame -- the first form -- every delivery
-// waited for the newest trace and the host's enqueue time, 40-60 us per frame, was added to every frame: 108 -> 90
-// us per frame on one GPU with frames so small that nothing else counts.)  Frame f is complete on rank 0 when
-// G2(f) is (pwn_tiled_wait enqueues the outstanding blur and that group itself when no newer frames were
-// submitted); at most three frames are in flight, four buffer sets.
-// Every rank then holds every rank's miss word of frame f: if one is non-zero the bounded halo was
+// While one stream's frame is exchanged the other stream's frame is traced: a frame costs max(kernels, exchange), not
+// their sum, and no event crosses a queue.  (PWN_TILED_CHOREO_SPLIT, the form of rounds 2-3, is kept as an option: the
+// exchanges on a third stream tied to the kernels by four events per frame, blur f enqueued by submit f+1 behind the
+// next trace, G2(f) by submit f+2 in front of G1(f+2).  Measured on one GPU, round 4: those queue-to-queue waits cost a
+// rank 0.11-0.19 ms per frame whatever the frame's size -- a 64 x 32 frame, a strip of an 8-way tiled 4K frame whose
+// kernels take 0.05 ms -- against 0.044 / 0.059 ms in-stream, 0.088 with RCCL carrying a real rank's bytes to itself;
+// profiles/r4/host_bound.txt.)  At most five frames are in flight, six buffer sets.
+// Every rank holds every rank's miss word of a delivered frame f: if one is non-zero the bounded halo was
 // not enough for that frame and ALL ranks, having the same words, repeat its exchange with whole
 // strips, its blur and its gather before it is delivered, and use whole strips from then on.  A
-// delivered frame is always exact; the host synchronises only at delivery, two frames behind the
-// submissions.
+// delivered frame is always exact; the host synchronises only at delivery, behind its submissions.
 //
 // Host sink (pwn_tiled_host_sink): frames are delivered to ONE frame buffer in host memory that every rank has
 // mapped and registered.  There is then no gather: behind its blur every rank copies its strip into the frame on a
-// copy stream of its own (N PCIe links in parallel), and the second half of a group is one word per pair of ranks,
-// sent behind the sender's copy -- when a rank has received every other rank's word of frame f, every strip of f
+// copy stream of its own (N PCIe links in parallel), and G2 is one word per pair of ranks, sent behind the
+// sender's copy on that stream -- when a rank has received every other rank's word of frame f, every strip of f
 // is in host memory.  The word is the miss word, so the exactness protocol is unchanged.
 //
 // The transport is a small interface: RCCL (ncclSend / ncclRecv in a group, loaded with dlopen so
@@ -513,7 +510,7 @@ struct shm_transport : pwn_transport
 };
 
 // ---------------------------------------------------------------- state ----
-#define NSLOT 4          // buffer sets: three frames in flight and the one being reused
+#define NSLOT 6          // buffer sets: at most five frames in flight and the one being reused
 #define MAXW PWN_TILED_MAX_WORLD
 struct pwn_tiled
 {
@@ -559,6 +556,13 @@ struct pwn_tiled
 	// two receives to the same peer in each grouped launch -- into a scratch plane, so that RCCL's kernels, the room they find beside the
 	// persistent trace grid and the host's cost per grouped launch can be measured on a box with one GPU
 	bool self_exchange; uint32_t *self_buf;
+	// The choreography (PWN_OPT_TILED_CHOREO, fixed at pwn_tiled_init).  IN-STREAM (default): everything of frame f -- trace, halo rows,
+	// blur, gather, words -- is enqueued by pwn_tiled_submit(f) on the frame's own compute stream, in order; the exchange of frame f
+	// overlaps the other stream's trace f+1.  No event crosses a queue.  SPLIT (rounds 2-3): the exchanges on a third stream, tied
+	// to the kernels by four events per frame, blur f enqueued by submit f+1 and the gather of f by submit f+2.  Measured on one
+	// GPU (profiles/r4/host_bound.txt): the split form's queue-to-queue waits cost a rank 150-200 us per frame whatever the frame's
+	// size, three times what the kernels of a strip of an 8-way tiled 4K frame take.
+	bool instream;
 	hipEvent_t gathered_by[NSLOT];      // which of the above marks the slot's gather as done
 	// host sink: NSLOT whole frames in host memory shared by the ranks; this rank's copies on their own stream
 	uint8_t *host_base; void *host_registered;   // the frames; what this context registered with the device (or NULL)
@@ -620,11 +624,11 @@ extern "C" int pwn_tiled_preflight(pwn_ctx *c, char *json, size_t n)
 	const int len = snprintf(json, n,
 		"{\"device\": %d, \"pci\": \"%s\", \"devices_visible\": %d, \"can_access_peer\": [%s], "
 		"\"librccl\": %s%s%s, \"rccl_version\": %d, \"rccl_has_nonblocking_api\": %s, \"rccl_has_abort\": %s, "
-		"\"rccl_mode\": \"%s\", \"init_timeout_ms\": %d, \"wait_timeout_ms\": %d, \"HSA_ENABLE_IPC_MODE_LEGACY\": %s%s%s%s%s%s}",
+		"\"rccl_mode\": \"%s\", \"choreography\": \"%s\", \"init_timeout_ms\": %d, \"wait_timeout_ms\": %d, \"HSA_ENABLE_IPC_MODE_LEGACY\": %s%s%s%s%s%s}",
 		c->device, pci, count, peers,
 		api ? "\"" : "", api ? api->path : "null", api ? "\"" : "", ver,
 		(api && api->CommInitRankConfig && api->CommGetAsyncError) ? "true" : "false", (api && api->CommAbort) ? "true" : "false",
-		rccl_mode_nonblocking() ? "nonblocking" : "blocking", init_timeout_ms(c), wait_timeout_ms(c),
+		rccl_mode_nonblocking() ? "nonblocking" : "blocking", c->tiled_choreo == PWN_TILED_CHOREO_SPLIT ? "split" : "instream", init_timeout_ms(c), wait_timeout_ms(c),
 		ipc ? "\"" : "", ipc ? ipc : "null", ipc ? "\"" : "",
 		api ? "" : ", \"librccl_error\": \"", api ? "" : err, api ? "" : "\"");
 	if(len < 0) return PWN_EINVAL;
@@ -903,6 +907,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	// on 16 CUs, 1.25 % of the grid.  Not measurable without several GPUs; PWN_TILED_RESERVE=n overrides it
 	// (0 = fill every CU), pwn_tiled_set_reserve() changes it between frames: bench.py --gpus N sweeps it.
 	c->grid_reserve = 0;
+	t->instream = c->tiled_choreo != PWN_TILED_CHOREO_SPLIT;
 	if(world == 1 && transport == PWN_TRANSPORT_RCCL && getenv("PWN_TILED_SELF") != NULL && atoi(getenv("PWN_TILED_SELF")) != 0)
 	{
 		if(hipMalloc((void **)&t->self_buf, n * 4 + 64) != hipSuccess) { pwn_tiled_destroy(c); return PWN_ENOMEM; }
@@ -1074,13 +1079,13 @@ static int add_self_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 }
 
 // behind a group that carried frame g's words: bring them (and this rank's own) to pinned host memory on the comm
-// stream, so that pwn_tiled_wait reads them there instead of making two blocking copies per frame
-static int fetch_words(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
+// stream, so that pwn_tiled_wait reads them there instead of making two blocking copies per frame.  By a kernel that
+// stores into the pinned buffer (one launch instead of two asynchronous copies of 8 (x world) bytes).
+static int fetch_words(pwn_ctx *c, pwn_tiled *t, unsigned long long g, hipStream_t xs)
 {
 	const int s = (int)(g % NSLOT);
 	uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1) * 2;
-	HIPCHK(c, hipMemcpyAsync(h, t->missv[s], (size_t)t->world * 8, hipMemcpyDeviceToHost, t->comm));
-	HIPCHK(c, hipMemcpyAsync(h + 2 * t->world, t->missw[s], 8, hipMemcpyDeviceToHost, t->comm));
+	HIPCHK(c, pwn_launch_words(t->missv[s], t->missw[s], h, t->world, xs));
 	return PWN_OK;
 }
 
@@ -1122,7 +1127,7 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 	int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
 	if(c->blur_passes)
 	{
-		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));
+		if(!t->instream) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));          // (in-stream: the halo rows came in front of this on cs)
 		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k2[s], cs));
 		uint32_t *dst = (t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->out[s];
 		// the trace of this frame, in front of this launch on the stream, added up what the strip cost: the blur
@@ -1140,7 +1145,7 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 		if(rc != PWN_OK) return rc;
 		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k3[s], cs));
 	}
-	HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
+	if(!t->instream || t->host_base != NULL) HIPCHK(c, hipEventRecord(t->ev_b[s], cs));       // (in-stream: what follows the blur follows it on cs; only the copy to the host waits for it)
 	// PWN_OPT_UNIT_ORDER: the strip's unit costs (written by the frame's trace, in front of this on the stream) sorted into
 	// the order of the stream's next trace of the same rows; behind ev_b, which is what the exchange waits for
 	{
@@ -1151,102 +1156,17 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 	return PWN_OK;
 }
 
-static double now_us(void)
+// the pre-blur rows of the frame in slot s that the neighbours' blurs read (or, without a bounded halo, whole strips to
+// everybody), as one grouped launch on `xs`, behind the frame's trace
+static int exchange_halo(pwn_ctx *c, pwn_tiled *t, int s, hipStream_t xs, int y0, int y1)
 {
-	struct timespec ts;
-	clock_gettime(CLOCK_MONOTONIC, &ts);
-	return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
-}
-
-extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
-{
-	if(c == NULL || cam == NULL || c->tiled == NULL) return PWN_EINVAL;
-	pwn_tiled *t = c->tiled;
-	if(t->submitted - t->delivered >= NSLOT - 1) return PWN_EBUSY;
-	if(t->tp->dead) { snprintf(c->err, sizeof(c->err), "%s transport: dead (%s)", t->tp->name(), t->tp->err); return PWN_ETIMEDOUT; }
-	(void)hipSetDevice(c->device);
-	const double t_in = now_us();
-	const unsigned long long f = t->submitted;
-	const int s = (int)(f % NSLOT);
 	const size_t w4 = (size_t)c->w * 4;
-	// A counted frame (PWN_OPT_COUNTERS, PWN_OPT_WAVE_LOG) goes on cs[0] whatever its parity: there is ONE set of
-	// counters and one wave log, which a launch clears at its start -- two counted grids side by side would clear
-	// each other's (and a wave log that grows would be freed under the other stream's kernel).  pwn_i_launch_trace
-	// orders a launch that leaves the alternating pattern behind the launch two before it (the ticket sets).
-	const bool counted = c->counters_on || c->wave_log_on;
-	hipStream_t cs = counted ? t->cs[0] : t->cs[f & 1u];
-	t->fstream[s] = cs;
-	// (a counted frame right behind an uncounted one on the OTHER stream: wait for that frame's trace, so that the
-	// counters and the wave log are this launch's alone)
-	if(counted && f > 0 && t->fstream[(f - 1) % NSLOT] != cs) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_t[(f - 1) % NSLOT], 0));
-	t->fhalo[s] = t->halo;
-	t->froot[s] = t->root_mode == PWN_TILED_ROOT_ROTATE ? (int)(f % (unsigned long long)t->world) : 0;
-	memcpy(t->fcuts[s], t->cuts, sizeof(t->cuts));
-	const int y0 = t->cuts[t->rank], y1 = t->cuts[t->rank + 1];
-	// The slot's buffers were frame f-4's.  Its blur ran on this stream; its strips left in G(f-4) and in
-	// the group that carried its gather, and the frame was delivered (three in flight at most), which
-	// waited for that group on the host: nothing to wait for here.
-	uint32_t *plane = c->blur_passes ? t->pre[s] : ((t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->pre[s]);
-	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
-	t->timed_g2[s] = false;
-	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
-	c->trace_clear_word = t->missw[s];           // the frame's miss word is cleared by its trace launch (no memset between the kernels)
-	c->trace_cost_word = c->blur_passes ? t->cost_acc + 16 * (f & 1u) : NULL;      // (the blur moves it on: enqueue_blur)
-	c->trace_tables_event = t->ev_t[s];          // ... and ev_t, recorded right behind it, also tells when its tables are free again
-	c->launch_room = t->cs[1] != t->cs[0] ? pwn_room_for_launch(c) : 0;          // PWN_OPT_TRACE_ROOM
-	int rc = pwn_i_launch_trace(c, cam, sec, y0, y1, plane, t->z[s], cs);
-	if(rc != PWN_OK) { (void)hipEventRecord(t->ev_t[s], cs); return rc; }
-	t->fcost_mul[s] = c->cost_mul; t->fcost_div[s] = c->cost_div;
-	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
-	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
-
-	// ---- the blur of the frames before this one (normally just f-1), each on its frame's stream.  With one
-	// compute stream that puts the blur of f-1 BEHIND the trace of f, so that the stream does not sit waiting for
-	// the halo rows of f-1 while it could trace; with two, the other stream waits for them and this one traces.
-	for(; t->blurred < f; t->blurred++)
-	{
-		rc = enqueue_blur(c, t, t->blurred);
-		if(rc != PWN_OK) return rc;
-	}
-
-	// ---- on the comm stream, two grouped launches.  First the second half of the frames that are blurred and not
-	// gathered yet except the newest blur (its kernel was enqueued a moment ago: next time), i.e. normally of
-	// frame f-2: it waits for that frame's blur only, NOT for the trace enqueued above -- a host that waits for
-	// frame f-2 after this call gets it while trace f runs, and is back with frame f+1 before the GPU is idle.
-	// (As ONE group with the halo rows below, which need trace f, every delivery waited for the newest trace:
-	// the host's enqueue time, ~40-60 us per frame, was added to every frame instead of hidden.)
-	const unsigned long long g_end = f >= 1 ? f - 1 : 0;        // gather frames [gathered, g_end)
-	if(g_end > t->gathered)
-	{
-		for(unsigned long long g = t->gathered; g < g_end; g++)
-		{
-			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
-			if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));       // the word goes out behind the copy
-		}
-		const int gs = (int)((g_end - 1) % NSLOT);
-		if(t->timed[gs]) { HIPCHK(c, hipEventRecord(t->ev_g0[gs], t->comm)); }
-		if(t->world > 1 || t->self_exchange)
-		{
-			TPCHK(c, t->tp->begin(t->comm));
-			for(unsigned long long g = t->gathered; g < g_end; g++) { rc = t->self_exchange ? add_self_gather(c, t, g) : add_gather(c, t, g); if(rc != PWN_OK) return rc; }
-			TPCHK(c, t->tp->end());
-			t->info.groups++;
-		}
-		if(t->timed[gs]) { HIPCHK(c, hipEventRecord(t->ev_g1[gs], t->comm)); t->timed_g2[gs] = true; }
-		for(unsigned long long g = t->gathered; g < g_end; g++) { rc = fetch_words(c, t, g); if(rc != PWN_OK) return rc; }
-		hipEvent_t done = t->ev_d[(g_end - 1) % NSLOT];
-		HIPCHK(c, hipEventRecord(done, t->comm));
-		for(unsigned long long g = t->gathered; g < g_end; g++) t->gathered_by[g % NSLOT] = done;
-		t->gathered = g_end;
-	}
-	// ---- then this frame's pre-blur rows, behind its trace
-	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
-	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g2[s], t->comm));
+	int rc;
 	if(t->self_exchange && c->blur_passes)
 	{
 		// (to itself: the rows a middle rank exchanges with its two neighbours, out of this frame's pre-blur plane into the scratch plane)
 		const int H = (int)(0.002 * c->h * 24.0) + 2 < (y1 - y0) ? (int)(0.002 * c->h * 24.0) + 2 : (y1 - y0);
-		TPCHK(c, t->tp->begin(t->comm));
+		TPCHK(c, t->tp->begin(xs));
 		TPCHK(c, t->tp->send(t->pre[s] + (size_t)y0 * c->w, (size_t)H * w4, 0));
 		TPCHK(c, t->tp->recv(t->self_buf, (size_t)H * w4, 0));
 		TPCHK(c, t->tp->send(t->pre[s] + (size_t)(y1 - H) * c->w, (size_t)H * w4, 0));
@@ -1257,7 +1177,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	}
 	if(t->world > 1 && c->blur_passes)
 	{
-		TPCHK(c, t->tp->begin(t->comm));
+		TPCHK(c, t->tp->begin(xs));
 		if(t->halo)
 		{
 			const int H = t->halo;
@@ -1278,6 +1198,134 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 		TPCHK(c, t->tp->end());
 		t->info.groups++;
 	}
+	return PWN_OK;
+}
+
+static double now_us(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
+}
+
+extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
+{
+	if(c == NULL || cam == NULL || c->tiled == NULL) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	if(t->submitted - t->delivered >= NSLOT - 1) return PWN_EBUSY;
+	if(t->tp->dead) { snprintf(c->err, sizeof(c->err), "%s transport: dead (%s)", t->tp->name(), t->tp->err); return PWN_ETIMEDOUT; }
+	(void)hipSetDevice(c->device);
+	const double t_in = now_us();
+	const unsigned long long f = t->submitted;
+	const int s = (int)(f % NSLOT);
+	// A counted frame (PWN_OPT_COUNTERS, PWN_OPT_WAVE_LOG) goes on cs[0] whatever its parity: there is ONE set of
+	// counters and one wave log, which a launch clears at its start -- two counted grids side by side would clear
+	// each other's (and a wave log that grows would be freed under the other stream's kernel).  pwn_i_launch_trace
+	// orders a launch that leaves the alternating pattern behind the launch two before it (the ticket sets).
+	const bool counted = c->counters_on || c->wave_log_on;
+	hipStream_t cs = counted ? t->cs[0] : t->cs[f & 1u];
+	t->fstream[s] = cs;
+	// (a counted frame right behind an uncounted one on the OTHER stream: wait for that frame's trace, so that the
+	// counters and the wave log are this launch's alone)
+	if(counted && f > 0 && t->fstream[(f - 1) % NSLOT] != cs) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_t[(f - 1) % NSLOT], 0));
+	t->fhalo[s] = t->halo;
+	t->froot[s] = t->root_mode == PWN_TILED_ROOT_ROTATE ? (int)(f % (unsigned long long)t->world) : 0;
+	memcpy(t->fcuts[s], t->cuts, sizeof(t->cuts));
+	const int y0 = t->cuts[t->rank], y1 = t->cuts[t->rank + 1];
+	// The slot's buffers were frame f-NSLOT's.  Its blur ran on this stream (NSLOT is even); its strips left in
+	// G(f-NSLOT) and in the group that carried its gather, and the frame was delivered (NSLOT-1 in flight at most), which
+	// waited for that group on the host: nothing to wait for here.
+	uint32_t *plane = c->blur_passes ? t->pre[s] : ((t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->pre[s]);
+	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
+	t->timed_g2[s] = false;
+	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
+	c->trace_clear_word = t->missw[s];           // the frame's miss word is cleared by its trace launch (no memset between the kernels)
+	c->trace_cost_word = c->blur_passes ? t->cost_acc + 16 * (f & 1u) : NULL;      // (the blur moves it on: enqueue_blur)
+	c->trace_tables_event = t->ev_t[s];          // ... and ev_t, recorded right behind it, also tells when its tables are free again
+	c->launch_room = t->cs[1] != t->cs[0] ? pwn_room_for_launch(c) : 0;          // PWN_OPT_TRACE_ROOM
+	int rc = pwn_i_launch_trace(c, cam, sec, y0, y1, plane, t->z[s], cs);
+	if(rc != PWN_OK) { (void)hipEventRecord(t->ev_t[s], cs); return rc; }
+	t->fcost_mul[s] = c->cost_mul; t->fcost_div[s] = c->cost_div;
+	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
+	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
+
+	if(t->instream)
+	{
+		// ---- everything else of frame f behind its trace, on its stream: halo rows, blur, gather, words
+		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g2[s], cs));
+		rc = exchange_halo(c, t, s, cs, y0, y1);
+		if(rc != PWN_OK) return rc;
+		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g3[s], cs));
+		rc = enqueue_blur(c, t, f);
+		if(rc != PWN_OK) return rc;
+		t->blurred = f + 1;
+		// (host sink: the words go out behind this rank's copy to the host, on the copy's stream -- the compute stream does not
+		// wait for PCIe)
+		hipStream_t gs = t->host_base != NULL ? t->copy : cs;
+		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g0[s], gs));
+		if(t->world > 1 || t->self_exchange)
+		{
+			TPCHK(c, t->tp->begin(gs));
+			rc = t->self_exchange ? add_self_gather(c, t, f) : add_gather(c, t, f);
+			if(rc != PWN_OK) return rc;
+			TPCHK(c, t->tp->end());
+			t->info.groups++;
+		}
+		if(t->timed[s]) { HIPCHK(c, hipEventRecord(t->ev_g1[s], gs)); t->timed_g2[s] = true; }
+		rc = fetch_words(c, t, f, gs);
+		if(rc != PWN_OK) return rc;
+		HIPCHK(c, hipEventRecord(t->ev_d[s], gs));
+		t->gathered_by[s] = t->ev_d[s];
+		t->gathered = f + 1;
+		t->submitted = f + 1;
+		t->enqueue_us[s] = (float)(now_us() - t_in);
+		return PWN_OK;
+	}
+
+	// ---- the blur of the frames before this one (normally just f-1), each on its frame's stream.  With one
+	// compute stream that puts the blur of f-1 BEHIND the trace of f, so that the stream does not sit waiting for
+	// the halo rows of f-1 while it could trace; with two, the other stream waits for them and this one traces.
+	for(; t->blurred < f; t->blurred++)
+	{
+		rc = enqueue_blur(c, t, t->blurred);
+		if(rc != PWN_OK) return rc;
+	}
+
+	// ---- SPLIT form.  On the comm stream, two grouped launches.  First the second half of the frames that are blurred
+	// and not gathered yet except the newest blur (its kernel was enqueued a moment ago: next time), i.e. normally of
+	// frame f-2: it waits for that frame's blur only, NOT for the trace enqueued above.  (As ONE group with the halo
+	// rows below, which need trace f, every delivery waited for the newest trace, round 2.  Gathering the newest blur
+	// too, round 4, made the chain blur -> words -> halo event -> next blur the limit: 0.28 instead of 0.21 ms per
+	// strip-sized frame, profiles/r4/host_bound.txt.)
+	const unsigned long long g_end = f >= 1 ? f - 1 : 0;        // gather frames [gathered, g_end)
+	if(g_end > t->gathered)
+	{
+		for(unsigned long long g = t->gathered; g < g_end; g++)
+		{
+			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
+			if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));       // the word goes out behind the copy
+		}
+		const int gs = (int)((g_end - 1) % NSLOT);
+		if(t->timed[gs]) { HIPCHK(c, hipEventRecord(t->ev_g0[gs], t->comm)); }
+		if(t->world > 1 || t->self_exchange)
+		{
+			TPCHK(c, t->tp->begin(t->comm));
+			for(unsigned long long g = t->gathered; g < g_end; g++) { rc = t->self_exchange ? add_self_gather(c, t, g) : add_gather(c, t, g); if(rc != PWN_OK) return rc; }
+			TPCHK(c, t->tp->end());
+			t->info.groups++;
+		}
+		if(t->timed[gs]) { HIPCHK(c, hipEventRecord(t->ev_g1[gs], t->comm)); t->timed_g2[gs] = true; }
+		for(unsigned long long g = t->gathered; g < g_end; g++) { rc = fetch_words(c, t, g, t->comm); if(rc != PWN_OK) return rc; }
+		hipEvent_t done = t->ev_d[(g_end - 1) % NSLOT];
+		HIPCHK(c, hipEventRecord(done, t->comm));
+		for(unsigned long long g = t->gathered; g < g_end; g++) t->gathered_by[g % NSLOT] = done;
+		t->gathered = g_end;
+	}
+	// ---- then this frame's pre-blur rows, behind its trace
+	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
+	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g2[s], t->comm));
+	rc = exchange_halo(c, t, s, t->comm, y0, y1);
+	if(rc != PWN_OK) return rc;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g3[s], t->comm));       // (ev_x carries no time stamp)
 	HIPCHK(c, hipEventRecord(t->ev_x[s], t->comm));
 	t->submitted = f + 1;
@@ -1358,15 +1406,18 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 			TPCHK(c, t->tp->end());
 			t->info.groups++;
 		}
-		for(unsigned long long g = t->gathered; g <= d; g++) { rc = fetch_words(c, t, g); if(rc != PWN_OK) return rc; }
+		for(unsigned long long g = t->gathered; g <= d; g++) { rc = fetch_words(c, t, g, t->comm); if(rc != PWN_OK) return rc; }
 		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
 		for(unsigned long long g = t->gathered; g <= d; g++) t->gathered_by[g % NSLOT] = t->ev_d[s];
 		t->gathered = d + 1;
 	}
 	rc = wait_event(c, t, t->gathered_by[s], "the group that carries its strips and words", d);
 	if(rc != PWN_OK) return rc;
-	rc = wait_event(c, t, t->ev_b[s], "its blur (behind the halo rows of its neighbours)", d);               // (world 1, and rank 0's own strip)
-	if(rc != PWN_OK) return rc;
+	if(!t->instream || t->host_base != NULL)         // (in-stream the gather's event is behind the blur on the frame's stream)
+	{
+		rc = wait_event(c, t, t->ev_b[s], "its blur (behind the halo rows of its neighbours)", d);               // (world 1, and rank 0's own strip)
+		if(rc != PWN_OK) return rc;
+	}
 	if(t->host_base != NULL) { rc = wait_event(c, t, t->ev_h[s], "the copy of its strip into the host frame", d); if(rc != PWN_OK) return rc; }      // this rank's own strip is in the host frame
 
 	// ---- the ranks' words of this frame (they came to pinned memory behind the group that carried them: fetch_words)
@@ -1384,16 +1435,18 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	{
 		// Every rank sees the same words and comes here together: the frame's exchange again with
 		// whole strips (pre[s] and z[s] still hold this frame), blur, gather; whole strips from now on.
-		// On the comm stream, behind the groups of the newer frames that are already in it.
+		// Behind the groups of the newer frames that are already enqueued (split form: on the comm stream; in-stream: on
+		// this frame's stream, the transport keeping the order of its own launches).
 		t->info.frames_redone++;
 		t->halo = 0; t->fhalo[s] = 0;
 		hipStream_t cs = t->fstream[s];
+		hipStream_t xs = t->instream ? cs : t->comm;          // the stream of the exchanges (in-stream: waits on its own events cost nothing)
 		int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
-		TPCHK(c, t->tp->begin(t->comm));
+		TPCHK(c, t->tp->begin(xs));
 		rc = add_allgather(c, t, s);
 		if(rc != PWN_OK) return rc;
 		TPCHK(c, t->tp->end());
-		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
+		HIPCHK(c, hipEventRecord(t->ev_d[s], xs));
 		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_d[s], 0));
 		uint32_t *dst = (t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->out[s];
 		// (this stream's cost accumulator may hold the trace of frame d+2 by now: it is left alone, the frame's
@@ -1401,21 +1454,21 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL, NULL, NULL);
 		if(rc != PWN_OK) return rc;
 		HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
-		HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[s], 0));
+		HIPCHK(c, hipStreamWaitEvent(xs, t->ev_b[s], 0));
 		if(t->host_base != NULL)
 		{
 			rc = copy_strip_to_host(c, t, s);                     // the strip again, and the words behind it
 			if(rc != PWN_OK) return rc;
-			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[s], 0));
+			HIPCHK(c, hipStreamWaitEvent(xs, t->ev_h[s], 0));
 		}
-		TPCHK(c, t->tp->begin(t->comm));
+		TPCHK(c, t->tp->begin(xs));
 		rc = add_gather(c, t, d);
 		if(rc != PWN_OK) return rc;
 		TPCHK(c, t->tp->end());
 		t->info.groups += 2;
 		// (everything of the repeat is in front of this event on the comm stream: the whole strips, the blur behind them --
 		// the comm stream waited for ev_b -- the copy to the host, the gather)
-		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
+		HIPCHK(c, hipEventRecord(t->ev_d[s], xs));
 		rc = wait_event(c, t, t->ev_d[s], "its repeat with whole strips", d);
 		if(rc != PWN_OK) return rc;
 		HIPCHK(c, hipStreamSynchronize(cs));

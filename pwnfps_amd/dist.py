@@ -21,20 +21,20 @@ ceil(h/world) rounded up to 8 (the reference parallelises the same loops with Op
 then the cuts MOVE with what the strips cost (``recut``: every rank's cost word travels with the frame's miss
 word, every rank computes the same new cuts from the same numbers, a frame keeps the cuts it was traced with).  The
 trace pass needs no exchange.  The blur does: its taps reach 0.002*h*(depth-1) rows
-(screen.h:100-102), unbounded in depth.  Per submitted frame f (slot s = f mod 4):
+(screen.h:100-102), unbounded in depth.  Per submitted frame f (slot s = f mod NSLOT), in this order -- the C code's
+default choreography, PWN_TILED_CHOREO_INSTREAM, where all of it is enqueued on the frame's own compute stream:
 
     trace strip f -> pre[s], z[s]
-    blur strip f-1 from pre rows [y0-H, y1+H) -> out (behind the group that brought its halo rows);
-        taps outside those rows are counted in the rank's miss word of that frame
-    two grouped exchanges:
-        G2(f-2): the FINISHED strip of frame f-2 to rank 0 and its miss word to every rank (behind blur f-2 only)
-        G1(f):   the H border rows of strip f to / from the neighbour strips (or, without a halo,
-                 every strip to everybody), behind trace f
+    G1(f): the H border rows of strip f to / from the neighbour strips (or, without a halo, every strip to
+           everybody)
+    blur strip f from pre rows [y0-H, y1+H) -> out; taps outside those rows are counted in the rank's miss
+           word of that frame
+    G2(f): the FINISHED strip of frame f to the frame's root and its two words to every rank
 
-(In the C code the blur of a frame sits behind the next frame's trace on the compute stream so
-that the stream never waits for the exchange; here everything is synchronous and only the order
-matters.)  Frame f is complete on rank 0 when G2(f) is, which rides with submit f+2 (``wait`` enqueues the outstanding blur
-and that group itself when no newer frames were submitted); three frames in flight at
+(In the C code frames alternate between two streams, so that frame f's exchange overlaps the trace of f+1; here
+everything is synchronous and only the order matters.  The C code's other choreography, PWN_TILED_CHOREO_SPLIT,
+enqueues blur f with submit f+1 and G2(f) with submit f+2 on a third stream: the same groups in another order,
+the same frames.)  Frame f is complete on its root when G2(f) is; five frames in flight at
 most.  Every rank then holds every rank's miss word of frame f: if one is non-zero ALL ranks repeat
 that frame's exchange with whole strips, its blur and its gather before it is delivered, and use
 whole strips from then on.
@@ -49,7 +49,7 @@ import torch
 import torch.distributed as dist
 
 TAG_HALO, TAG_STRIP, TAG_GATHER, TAG_MISS = 1, 2, 3, 4
-NSLOT = 4          # buffer sets: three frames in flight and the one being reused
+NSLOT = 6          # buffer sets: at most five frames in flight and the one being reused
 
 
 def strip_rows(h, world):
@@ -310,7 +310,7 @@ class TiledFrames:
     # ---- pwn_tiled_submit ---------------------------------------------------------------------
     def submit(self, cam, sec=0.0):
         if self.submitted - self.delivered >= NSLOT - 1:
-            raise RuntimeError("three frames are in flight: wait() first (PWN_EBUSY)")
+            raise RuntimeError("%d frames are in flight: wait() first (PWN_EBUSY)" % (NSLOT - 1))
         f = self.submitted
         s = f % NSLOT
         self.fhalo[s] = self.halo
@@ -325,20 +325,7 @@ class TiledFrames:
         # frame's second word; a backend that measures nothing leaves it 0 and the cuts where they are)
         if cost is not None and self.blur_passes:
             self.missw[s][1] = int(cost) & 0x7fffffff
-        # the blur of the frames before this one (normally just f-1)
-        while self.blurred < f:
-            self._enqueue_blur(self.blurred)
-            self.blurred += 1
-        # two groups, like pwn_tiled_submit: first the gather of what is blurred except the newest blur (it does not
-        # depend on this frame's trace), then this frame's pre-blur rows
-        g_end = f - 1 if f >= 1 else 0
-        if g_end > self.gathered:
-            if self.world > 1:
-                self._begin()
-                for g in range(self.gathered, g_end):
-                    self._add_gather(g)
-                self._end()
-            self.gathered = g_end
+        # this frame's pre-blur rows to the neighbours, its blur, its gather: two groups, like pwn_tiled_submit
         if self.world > 1 and self.blur_passes:
             self._begin()
             if self.halo:
@@ -352,29 +339,25 @@ class TiledFrames:
             else:
                 self._add_allgather(s)
             self._end()
+        self._enqueue_blur(f)
+        self.blurred = f + 1
+        if self.world > 1:
+            self._begin()
+            self._add_gather(f)
+            self._end()
+        self.gathered = f + 1
         self.submitted = f + 1
 
     # ---- pwn_tiled_wait -------------------------------------------------------------------------
     def wait(self):
         """Oldest frame in flight, on every rank.  Returns (frame, redone): frame = the full frame
-        tensor on the frame's root (rank 0, or rank f mod world with rotate_root; valid until three more frames were
+        tensor on the frame's root (rank 0, or rank f mod world with rotate_root; valid until five more frames were
         submitted), None elsewhere; with a host
         sink the frame in the shared host memory, on every rank."""
         if self.delivered >= self.submitted:
             raise RuntimeError("nothing in flight")
         d = self.delivered
         s = d % NSLOT
-        # no newer frame has enqueued this one's blur / carried its gather: do both now
-        while self.blurred <= d:
-            self._enqueue_blur(self.blurred)
-            self.blurred += 1
-        if self.gathered <= d:
-            if self.world > 1:
-                self._begin()
-                for g in range(self.gathered, d + 1):
-                    self._add_gather(g)
-                self._end()
-            self.gathered = d + 1
         # the ranks' words of this frame
         words = self.missv[s].clone()
         words[2 * self.rank:2 * self.rank + 2] = self.missw[s]

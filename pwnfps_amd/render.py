@@ -72,6 +72,11 @@ class Renderer:
         """frames in flight: successive frames alternate between two compute streams (default) or all run on one"""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_FRAME_OVERLAP, 1 if on else 0), "pwn_set_option")
 
+    def set_tiled_choreo(self, split):
+        """PWN_OPT_TILED_CHOREO, before tiled_init: False (default) = everything of a frame in order on the frame's own compute stream;
+        True = the exchanges on a third stream, blur and gather one and two submits late (rounds 2-3).  Same frames."""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_TILED_CHOREO, 1 if split else 0), "pwn_set_option")
+
     def set_unit_order(self, on):
         """PWN_OPT_UNIT_ORDER: the trace kernel's units handed out by what they cost in the last launch (True) or
         in arithmetic order (False, the default).  Never changes a frame."""

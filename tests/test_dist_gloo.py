@@ -76,7 +76,7 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=Non
     try:
         import oracle
         import tiled_rank                      # the frame sequence of the GPU test of the C implementation
-        from pwnfps_amd.dist import TiledFrames, strip_range
+        from pwnfps_amd.dist import NSLOT, TiledFrames, strip_range
         key = "t0" if level == "pwnfps_level" else level
         base = load_spheres(key)
         be = OracleStripBackend(w, h, level_path(level), base)
@@ -84,7 +84,7 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=Non
         sink = None
         if sink_path is not None:
             # pwn_tiled_host_sink: one file mapped by every rank plays the shared host memory
-            sink = np.memmap(sink_path, dtype=np.uint32, mode="r+", shape=(4, h, w))
+            sink = np.memmap(sink_path, dtype=np.uint32, mode="r+", shape=(NSLOT, h, w))
         fr = TiledFrames(w, h, be, torch.device("cpu"), rank=rank, world=world, blur_passes=blur, halo_rows=halo, host_sink=sink,
                          balance_every=balance, rotate_root=rotate)
         assert (fr.y0, fr.y1) == strip_range(h, world, rank)
@@ -110,12 +110,15 @@ def _worker(rank, world, port, w, h, level, frames, blur, halo, q, sink_path=Non
             fr.submit(cam, sec)
             if k >= 2:
                 deliver(k - 2)
-        # at most three frames in flight
         cam, sec, sph = tiled_rank.scene(frames, base, spawn)
         be.o.set_spheres(sph)
         fr.submit(cam, sec)
+        # at most NSLOT - 1 frames in flight (the guard alone: this loop keeps three, like the hosts of rounds 2-3)
+        held = fr.delivered
+        fr.delivered = fr.submitted - (NSLOT - 1)
         with pytest.raises(RuntimeError, match="in flight"):
             fr.submit(cam, sec)
+        fr.delivered = held
         deliver(frames - 2)
         deliver(frames - 1)
         deliver(frames)
@@ -242,7 +245,7 @@ def test_host_sink_delivers_whole_frames_to_every_rank(world, blur, halo, tmp_pa
     mapped, a word per pair of ranks follows the copy, and a delivered frame is whole on EVERY rank."""
     w, h, frames = 320, 240, 5
     path = str(tmp_path / "frames.bin")
-    np.zeros((4, h, w), np.uint32).tofile(path)
+    np.zeros((6, h, w), np.uint32).tofile(path)          # pwnfps_amd.dist.NSLOT frames
     want = _want(w, h, "pwnfps_level", frames + 1, blur)
     res = _run(world, w, h, "pwnfps_level", frames, blur, halo, sink_path=path)
     redone = [g[1] for g in res[0][0]]
@@ -272,7 +275,7 @@ def test_moving_cuts_keep_every_frame_exact(world, halo, sink, tmp_path):
     path = None
     if sink:
         path = str(tmp_path / "frames.bin")
-        np.zeros((4, h, w), np.uint32).tofile(path)
+        np.zeros((6, h, w), np.uint32).tofile(path)          # pwnfps_amd.dist.NSLOT frames
     eq = equal_cuts(h, world)
     by_hand = {5: [0] + [c + 8 for c in eq[1:-2]] + [eq[-2], h]}            # (the last strip of the equal split is the short one)
     want = _want(w, h, "pwnfps_level", frames + 1, 1)

@@ -76,6 +76,32 @@ def oracle_hashes(w, h, level, frames, oracle_lib, blur=1):
     return want
 
 
+@pytest.mark.parametrize("world,hostsink,rotate", [(1, False, False), (3, False, False), (4, False, True), (3, True, False)])
+def test_split_choreography_gives_the_same_frames(world, hostsink, rotate, tmp_path, oracle_lib):
+    """PWN_OPT_TILED_CHOREO = split (bench.py's sweep leg `choreo_split`; the default of rounds 2-3): the exchanges on a
+    third stream, blur f enqueued by submit f+1 and its gather by submit f+2.  The same frames, groups and bytes as the
+    in-stream default, bounded halo, missed halo and whole strips."""
+    w, h, frames = 640, 360, 6
+    want = oracle_hashes(w, h, "pwnfps_level", frames, oracle_lib)
+    env = {"PWN_TILED_CHOREO": "split"}
+    if rotate:
+        env["TILED_ROTATE"] = "1"
+    for halo in (-1, 1):
+        by_rank, seen = [], []
+        hashes, infos = run_ranks(world, w, h, "pwnfps_level", frames, halo, tmp_path, hostsink=hostsink, seen=seen, extra_env=env, by_rank=by_rank)
+        if rotate:
+            got = {int(k): hh for per in by_rank for k, hh, _ in per}
+            assert [got[k] for k in range(frames)] == want, (world, halo)
+        else:
+            assert [x[1] for x in hashes] == want, (world, halo)
+        assert all(s_ == want for s_ in seen)
+        assert [i["frames"] for i in infos] == [frames] * world
+        if world > 1 and halo == 1:
+            assert len({i["frames_redone"] for i in infos}) == 1 and infos[0]["frames_redone"] >= 1 and all(i["halo_rows"] == 0 for i in infos)
+        if world > 1 and halo == -1:
+            assert all(i["frames_redone"] == 0 and i["groups"] == 2 * frames for i in infos)
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 4])
 def test_tiled_frames_are_the_oracles_frames(world, tmp_path, oracle_lib):
     w, h, frames = 640, 360, 6
@@ -95,7 +121,7 @@ def test_tiled_frames_are_the_oracles_frames(world, tmp_path, oracle_lib):
             assert all(i["halo_rows"] == 0 for i in infos)
         if world > 1 and halo == -1:
             assert all(i["halo_rows"] == int(0.002 * h * 24) + 2 for i in infos)
-            # two grouped launches per frame: its halo rows, and (two frames later, or when the run drains) its gather
+            # two grouped launches per frame: its halo rows in front of its blur, its gather behind
             assert all(i["groups"] == 2 * frames for i in infos)
 
 

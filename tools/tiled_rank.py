@@ -9,7 +9,7 @@ file.  Every frame has its own camera, sec_current and sphere set (tools/tiled_r
 frame that is delivered late or from the wrong buffers shows.  Rank 0 prints one line per frame:
     frame K fnv64 HASH redone R
 and every rank a line `info {...}` (pwn_tiled_info) and per frame `rows K Y0 Y1 COST` (the rows it traced of that frame and
-what they cost).  TILED_ROTATE=1: pwn_tiled_gather_root(ROTATE), the `frame` lines then come from the frame's root, rank K mod
+what they cost).  TILED_DEPTH=n: n frames in flight (default 3, at most PWN_TILED_SLOTS - 1).  TILED_ROTATE=1: pwn_tiled_gather_root(ROTATE), the `frame` lines then come from the frame's root, rank K mod
 WORLD.  TILED_BALANCE=k: pwn_tiled_balance(k) (moving cuts); TILED_CUTS_AT="K:c0,c1,..;K2:.." calls
 pwn_tiled_set_cuts in front of frame K.  TILED_HOSTSINK=1: frames are delivered into POSIX shared
 memory by every rank (pwn_tiled_host_sink); the other ranks then print `seen K fnv64 HASH` too.
@@ -80,7 +80,7 @@ def main():
     if hostsink and rank == 0:
         # the frames' host memory: POSIX shared memory that every rank maps (created before the id file appears)
         with open(shm_path(idfile), "wb") as f:
-            f.truncate(4 * w * h * 4)
+            f.truncate(pwnfps_amd._lib.PWN_TILED_SLOTS * w * h * 4)
     t_call = [time.time()]
 
     def failed(e):
@@ -114,7 +114,7 @@ def main():
     if hostsink:
         import mmap
         fd = os.open(shm_path(idfile), os.O_RDWR)
-        mm = mmap.mmap(fd, 4 * w * h * 4)
+        mm = mmap.mmap(fd, pwnfps_amd._lib.PWN_TILED_SLOTS * w * h * 4)
         os.close(fd)
         r.tiled_host_sink(mm)
 
@@ -162,6 +162,7 @@ def main():
         elif hostsink:
             # with a host sink every rank holds the whole frame when its wait returns
             print("seen %d fnv64 %s" % (k, oracle.fnv64(fr["sbuf"])), flush=True)
+    depth = min(max(int(os.environ.get("TILED_DEPTH", "3")), 1), pwnfps_amd._lib.PWN_TILED_SLOTS - 1)      # frames in flight
     for k in range(frames):
         cam, sec, sph = scene(0 if os.environ.get("TILED_SAME_SCENE") else k, base, spawn)
         r.set_objects(sph)
@@ -175,9 +176,9 @@ def main():
             r.tiled_submit(cam, sec)
         except pwnfps_amd.PwnError as e:
             failed(e)
-        if k >= 2:
-            deliver(k - 2)
-    for k in range(max(0, frames - 2), frames):
+        if k >= depth - 1:
+            deliver(k - (depth - 1))
+    for k in range(max(0, frames - (depth - 1)), frames):
         deliver(k)
     if os.environ.get("TILED_COUNTERS") or os.environ.get("TILED_WAVELOG"):
         st = r.stats()                       # every frame delivered: the last launch's own counts
