@@ -66,9 +66,10 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     assert len(t["cuts"]) == world + 1 and t["cuts"][0] == 0 and t["cuts"][-1] == size[1]
     assert t["balance_every"] == 8 and t["two_streams"] == 1 and t["max_rows"] >= t["rows_per_rank"] and t["grid_reserve"] == 0
     assert d["roofline"]["pixels_per_launch"] in [rows * size[0] for rows in pr["rows"]]
-    # the in-run sweep: room left for the transport's kernels, equal strips, one compute stream, whole strips
+    # the in-run sweep: room left for the transport's kernels, equal strips, one compute stream, whole strips, the other choreography
     sw = t["sweep"]
-    assert set(sw) - {"rank0_tall"} == {"reserve_0", "reserve_16", "reserve_64", "rotating_root", "equal_strips", "one_stream", "whole_strips"}
+    assert set(sw) - {"rank0_tall"} == {"reserve_0", "reserve_16", "reserve_64", "rotating_root", "equal_strips", "one_stream", "whole_strips", "choreo_split"}
+    assert t["choreography"].startswith("in-stream") and all(q["choreography"] == "instream" for q in pf)
     assert ("rank0_tall" in sw) == (world > 2)
     for name, pt in sw.items():
         assert pt["value"] > 0 and pt["ms_per_step"] > 0 and len(pt["trace_ms"]) == world and len(pt["rows"]) == world, name
