@@ -29,8 +29,8 @@ N > 1: the line carries what it takes to read a first multi-GPU run from the dri
 `tiling.per_rank` (every rank's trace / blur kernel times, the durations of the two grouped exchanges,
 host enqueue time per frame, rows and cost of its strip), the moving cuts, and `tiling.sweep`: short
 legs in the same run with the trace grid's room for RCCL at 0 / 16 / 64 workgroups, the gather spread over the
-ranks (`rotating_root`), equal strips, one compute stream, whole strips instead of the bounded halo, and the other
-choreography (`choreo_split`: the exchanges on a third stream).  `transport` says at top level what carried the data; over
+ranks (`rotating_root`), equal strips, one compute stream, whole strips instead of the bounded halo, the other
+choreography (`choreo_split`: the exchanges on a third stream), and three compute streams.  `transport` says at top level what carried the data; over
 the shared-memory fallback the metric string says that the figure is NOT RCCL over xGMI.
 
 N > 1 cannot fail silently (pwnfps_amd/watch.py): every rank marks the stage it is in in the control plane's key-value
@@ -989,6 +989,14 @@ def main():
         barrier()
         r.tiled_shutdown()
         r.set_tiled_choreo(False)
+        # frames rotating over three compute streams instead of alternating between two
+        r.set_tiled_streams(3)
+        ok5, _ = bring_up(transport, tag="sweep.three_streams:")
+        if ok5:
+            point("three_streams", "PWN_OPT_TILED_STREAMS = 3: frame f on compute stream f mod 3 (one GPU: a strip-sized frame 8 % faster, a whole 4K frame 8 % slower)")
+        barrier()
+        r.tiled_shutdown()
+        r.set_tiled_streams(2)
         if transport == "rccl" and args.sweep_nonblocking:
             # (opt-in: an optional leg on the least-travelled path must not be able to cost a run its clean exit)
             # the other way of driving the communicator: non-blocking, every call polled against the deadline (a grouped launch is

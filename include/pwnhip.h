@@ -125,6 +125,10 @@ typedef struct pwn_stats
                                   size -- a strip of an 8-way tiled 4K frame needs 0.05 ms of kernels. */
 #define PWN_TILED_CHOREO_INSTREAM 0
 #define PWN_TILED_CHOREO_SPLIT    1
+#define PWN_OPT_TILED_STREAMS 11 /* row tiling, in-stream choreography, read by pwn_tiled_init (PWN_EBUSY while a tiling exists; PWN_TILED_STREAMS=n
+                                  in the environment): 2 = frames alternate between the context's two compute streams, 3 = they rotate
+                                  over those and a third that the tiling creates -- two frames' exchanges and blurs then overlap a third
+                                  frame's trace.  Same frames.  Without PWN_OPT_FRAME_OVERLAP there is one stream whatever this says. */
 #define PWN_OPT_UNIT_ORDER 9   /* 0 (default): the trace kernel hands its 16 x 4-pixel units out in arithmetic order, rows from the frame's
                                   middle row outwards.  1 (PWN_UNIT_ORDER=1 in the environment for a process): dearest first -- every unit's cost
                                   (the time its wave spent on it) is written by the launch, put in order per work queue behind the frame's last
@@ -400,6 +404,8 @@ typedef struct pwn_tiled_info
 	                                                  the deadline (the default) */
 	int init_timeout_ms, wait_timeout_ms;          /* pwn_tiled_set_timeouts, as in force */
 	int dead;                                      /* 1: a deadline passed or the transport failed; the communicator is gone */
+	int compute_streams;                           /* 1, 2 or 3: frame f runs on compute stream f mod this (PWN_OPT_FRAME_OVERLAP, PWN_OPT_TILED_STREAMS) */
+	int choreography;                              /* PWN_TILED_CHOREO_* as fixed at pwn_tiled_init */
 } pwn_tiled_info;
 int pwn_tiled_unique_id(void *id128, int transport);
 int pwn_tiled_init(pwn_ctx *ctx, int rank, int world, const void *id128, int transport, int halo_rows);

@@ -80,7 +80,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		c->ev_upload[i] = NULL; c->upload_pending[i] = false;
 	}
 	for(int i = 0; i < PWN_NSTAGE; i++) { c->h_stage[i] = NULL; c->ev_stage[i] = NULL; c->stage_used[i] = false; }
-	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0;
+	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0; c->launch_rot = 2;
 	c->trace_clear_word = NULL; c->trace_cost_word = NULL; c->trace_tables_event = NULL; c->grid_reserve = 0;
 	memset(&c->room, 0, sizeof(c->room)); c->room.mode = -1; c->launch_room = 0;
 	c->cost_mul = c->cost_div = 1u; c->blur_cost_mul = c->blur_cost_div = 0u;
@@ -92,6 +92,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	if(const char *e = getenv("PWN_FRAME_OVERLAP")) c->frame_overlap = atoi(e) != 0;
 	c->unit_order = 0;             // (measured: a loss except on short launches that run alone, profiles/r4/unit_order_ab.txt)
 	if(const char *e = getenv("PWN_UNIT_ORDER")) c->unit_order = atoi(e) != 0;
+	c->tiled_streams = PWN_TILED_STREAMS_DEFAULT;
+	if(const char *e = getenv("PWN_TILED_STREAMS")) { const int v = atoi(e); if(v == 2 || v == 3) c->tiled_streams = v; }
 	c->tiled_choreo = PWN_TILED_CHOREO_INSTREAM;
 	if(const char *e = getenv("PWN_TILED_CHOREO")) c->tiled_choreo = (strcmp(e, "split") == 0 || strcmp(e, "1") == 0) ? PWN_TILED_CHOREO_SPLIT : PWN_TILED_CHOREO_INSTREAM;
 	memset(c->ev, 0, sizeof(c->ev));
@@ -278,6 +280,10 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 			if(value != PWN_TILED_CHOREO_INSTREAM && value != PWN_TILED_CHOREO_SPLIT) return PWN_EINVAL;
 			if(c->tiled != NULL) return PWN_EBUSY;
 			c->tiled_choreo = value; return PWN_OK;
+		case PWN_OPT_TILED_STREAMS:
+			if(value != 2 && value != 3) return PWN_EINVAL;
+			if(c->tiled != NULL) return PWN_EBUSY;
+			c->tiled_streams = value; return PWN_OK;
 		case PWN_OPT_TRACE_ROOM: if(value < -1 || value > 4096) return PWN_EINVAL; memset(&c->room, 0, sizeof(c->room)); c->room.mode = value; return PWN_OK;
 		case PWN_OPT_FRAME_OVERLAP:
 			for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
@@ -651,8 +657,20 @@ static pwn_ctx::unit_order_state *order_entry(pwn_ctx *c, hipStream_t stream, bo
 // compute streams idle)
 void pwn_launch_history_clear(pwn_ctx *c)
 {
-	c->launch_stream[0] = c->launch_stream[1] = NULL;
-	c->launch_event[0] = c->launch_event[1] = NULL;
+	for(int i = 0; i < 3; i++) { c->launch_stream[i] = NULL; c->launch_event[i] = NULL; }
+}
+
+// How many streams successive trace launches rotate over (pwn_tiled.cpp: 3 for a tiling on three compute streams, else 2).
+// The work-queue counters are used in turn, 2R sets: a change starts them afresh, with the device idle.
+int pwn_i_set_launch_rotation(pwn_ctx *c, int rot)
+{
+	if(rot != 2 && rot != 3) return PWN_EINVAL;
+	if(c->launch_rot == rot) return PWN_OK;
+	HIPCHK(c, hipDeviceSynchronize());
+	HIPCHK(c, hipMemset(c->d_tickets, 0, PWN_TICKET_SETS * PWN_QUEUES * PWN_QUEUE_STRIDE * sizeof(uint32_t)));
+	c->ticket_set = 0; c->launch_rot = rot;
+	pwn_launch_history_clear(c);
+	return PWN_OK;
 }
 
 int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y1,
@@ -692,12 +710,14 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	P.clear_word = clear_word;
 	P.cost_word = cost_word;
 	P.wave_log = NULL;
-	// the kernel's work queues: four sets; launch n counts in set n mod 4 and clears set (n + 2) mod 4, the one of
-	// the launch after the next.  Launches of a context are stream-ordered (include/pwnhip.h) -- on ONE stream, or
-	// alternating between the two compute streams of the frames in flight (pwn_submit_frame), where launch n + 2
-	// is behind launch n on its stream and launch n + 1 may run beside it with a set of its own.
-	P.tickets = c->d_tickets + (c->ticket_set % PWN_TICKET_SETS) * PWN_QUEUES * PWN_QUEUE_STRIDE;
-	P.tickets_next = c->d_tickets + ((c->ticket_set + 2u) % PWN_TICKET_SETS) * PWN_QUEUES * PWN_QUEUE_STRIDE;
+	// the kernel's work queues: 2R sets, R = launch_rot; launch n counts in set n mod 2R and clears set (n + R) mod 2R,
+	// the one of the launch R launches on.  Launches of a context are stream-ordered (include/pwnhip.h) -- on ONE stream,
+	// or rotating over the R = 2 compute streams of the frames in flight (pwn_submit_frame) or the R = 2 or 3 of a row
+	// tiling, where launch n + R is behind launch n on its stream and the launches between may run beside it with sets
+	// of their own.
+	const unsigned rot = (unsigned)c->launch_rot, nsets = 2u * rot;
+	P.tickets = c->d_tickets + (c->ticket_set % nsets) * PWN_QUEUES * PWN_QUEUE_STRIDE;
+	P.tickets_next = c->d_tickets + ((c->ticket_set + rot) % nsets) * PWN_QUEUES * PWN_QUEUE_STRIDE;
 	// ordinary cameras (rows x,y,z with w = 0, position w = 1: mat4_iden + rotations,
 	// main.c:61-64) never put anything but 0 / 1 into the w lanes; the kernel has a
 	// 3-lane specialisation for them that is arithmetically identical
@@ -794,9 +814,13 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 		uo.units = (uint32_t)units; uo.qcap = qcap; uo.y0 = y0; uo.y1 = y1; uo.cost_fresh = true;
 	}
 	else if(uop != NULL) uop->cost_fresh = false;
+	// This launch clears the ticket set that the launch R before it drew from (above): it has to come after that one.
+	// On one stream and in the rotation over R it does by itself; a launch that leaves the pattern waits.
+	if(c->launch_event[rot - 1] != NULL && c->launch_stream[rot - 1] != stream) HIPCHK(c, hipStreamWaitEvent(stream, c->launch_event[rot - 1], 0));
 	if(refill) HIPCHK(c, pwn_launch_trace_refill(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	else HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	c->ticket_set++;                     // only a launch that went out has cleared the other set
+	c->launch_stream[2] = c->launch_stream[1]; c->launch_event[2] = c->launch_event[1];
 	c->launch_stream[1] = c->launch_stream[0]; c->launch_event[1] = c->launch_event[0];
 	c->launch_stream[0] = stream; c->launch_event[0] = caller_event != NULL ? caller_event : c->ev_tables[cur];
 	if(caller_event != NULL)

@@ -48,7 +48,8 @@ extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out
                           // with three or four it runs at once, somewhere beside the trace grid: 0.3823 -> 0.3790 ms per 4K frame
 #endif
 #define PWN_NCOUNTERS 48     // device counters of the counting kernel variants: 16 (pwn_stats) + 24 regions + spare
-#define PWN_TICKET_SETS 4u  // launch n counts in set n mod 4 and clears set (n + 2) mod 4 (pwn_i_launch_trace)
+#define PWN_TILED_STREAMS_DEFAULT 2
+#define PWN_TICKET_SETS 6u  // launch n counts in set n mod 2R and clears set (n + R) mod 2R, R = pwn_ctx.launch_rot streams in rotation, 2 or 3 (pwn_i_launch_trace)
 #define PWN_NSTAGE 4      // pinned staging buffers for those uploads
 
 // one frame in flight (pwn_submit_frame / pwn_wait_frame)
@@ -141,6 +142,7 @@ struct pwn_ctx
 	} order[4];
 	unsigned long long order_stamp;
 	int tiled_choreo;                // PWN_OPT_TILED_CHOREO, read by pwn_tiled_init
+	int tiled_streams;               // PWN_OPT_TILED_STREAMS, read by pwn_tiled_init
 	int unit_order;                  // the option: 1 = units handed out by last launch's cost, 0 = arithmetic order
 	unsigned long long order_used, order_sorts;      // trace launches that ran in a sorted order; sorts launched (pwn_unit_order_state)
 	bool dbg_force_hasw; int dbg_blocks_per_cu;      // PWN_DBG_* hooks, read at pwn_init
@@ -175,7 +177,8 @@ struct pwn_ctx
 	// of launch n + 2 = the set launch n - 2 drew from, so it has to come after launch n - 2: true by itself on one
 	// stream and while frames alternate between two (n - 2 is then on n's stream), NOT when a launch leaves that pattern
 	// (a blocking call or a counted frame between alternating ones) -- pwn_i_launch_trace then waits for this event.
-	hipStream_t launch_stream[2]; hipEvent_t launch_event[2];     // [0] the last launch, [1] the one before
+	hipStream_t launch_stream[3]; hipEvent_t launch_event[3];     // [0] the last launch, [1] the one before, [2] the one before that
+	int launch_rot;                  // streams that successive trace launches rotate over: 2 (one stream, or two alternating), 3 (pwn_i_set_launch_rotation)
 
 	char err[256];
 };
@@ -188,6 +191,7 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const float *d_z, uint32_t *d_out, hipStream_t stream,
 	int avail_y0, int avail_y1, uint32_t *d_miss, uint32_t *d_cost_acc, uint32_t *d_cost_out);
 void pwn_launch_history_clear(pwn_ctx *c);      // the launch-order events are about to be destroyed (streams idle)
+int pwn_i_set_launch_rotation(pwn_ctx *c, int rot);
 int pwn_i_launch_order(pwn_ctx *c, hipStream_t stream);      // behind a frame's last kernel on `stream`: sort that stream's unit costs (no-op when there are none)
 void pwn_tiled_destroy(pwn_ctx *c);
 bool pwn_tiled_busy(pwn_ctx *c);        // frames of the row tiling in flight

@@ -537,8 +537,9 @@ struct pwn_tiled
 	// frame f+1 moves onto the CUs while frame f's runs out of units (a strip of an 8-way tiling of a 4K frame is
 	// three units per wave: the mean wave is resident for 2/3 of such a launch) and a stream that waits for its
 	// frame's halo rows does not hold up the other.  Without PWN_OPT_FRAME_OVERLAP both are the context's one stream.
-	hipStream_t cs[2];
-	uint32_t *cost_acc;                 // device, two words 64 B apart: what the trace launch in flight on cs[i] cost so far (tables.h cost_word)
+	hipStream_t cs[3]; int ncs;         // ncs = 1 (no PWN_OPT_FRAME_OVERLAP), 2, or 3 (PWN_OPT_TILED_STREAMS, in-stream only): frame f on cs[f % ncs]
+	hipStream_t cs3;                    // the third compute stream, the tiling's own
+	uint32_t *cost_acc;                 // device, a word per buffer set, 64 B apart: what the slot's trace launch cost so far (tables.h cost_word)
 	uint32_t *pre[NSLOT], *out[NSLOT], *fin[NSLOT]; float *z[NSLOT];     // full-frame planes per frame slot (fin: rank 0)
 	// the two words a rank says about a frame: [0] taps that left its halo (miss), [1] what its strip cost (the sum of
 	// its trace waves' lifetimes, 100 MHz ticks); missw = this rank's, missv = every rank's (world x 2)
@@ -755,9 +756,11 @@ void pwn_tiled_destroy(pwn_ctx *c)
 	if(t->h_missv) (void)hipHostFree(t->h_missv);
 	if(t->h_frame) (void)hipHostFree(t->h_frame);
 	if(t->comm) (void)hipStreamDestroy(t->comm);
+	if(t->cs3) (void)hipStreamDestroy(t->cs3);
 	delete t;
 	c->tiled = NULL;
 	c->grid_reserve = 0;
+	(void)pwn_i_set_launch_rotation(c, 2);
 }
 
 extern "C" void pwn_tiled_shutdown(pwn_ctx *c) { if(c != NULL) pwn_tiled_destroy(c); }
@@ -797,6 +800,8 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	t->balance_every = (world > 1 && shortest >= 16 && c->blur_passes == 1) ? 8 : 0;
 	if(const char *e = getenv("PWN_TILED_BALANCE")) { int v = atoi(e); if(v >= 0 && v <= 100000 && (v == 0 || t->balance_every > 0)) t->balance_every = v; }
 	t->cs[0] = c->stream; t->cs[1] = (c->frame_overlap && c->stream2 != NULL) ? c->stream2 : c->stream;
+	t->ncs = t->cs[1] != t->cs[0] ? 2 : 1;
+	t->instream = c->tiled_choreo != PWN_TILED_CHOREO_SPLIT;
 	c->tiled = t;
 
 	int rc = PWN_OK;
@@ -849,8 +854,23 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 				if(hipStreamCreateWithFlags(&t->comm, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
 			}
 		}
-		if(hipMalloc((void **)&t->cost_acc, 128) != hipSuccess) { rc = PWN_ENOMEM; break; }
-		if(hipMemset(t->cost_acc, 0, 128) != hipSuccess) { rc = PWN_EHIP; break; }
+		// a third compute stream (in-stream choreography): frame f on cs[f mod 3], so that two frames' exchanges and blurs
+		// overlap a third frame's trace.  On the hardware-queue pool of stream2 and comm (pwn_init)
+		if(t->instream && t->ncs == 2 && c->tiled_streams == 3)
+		{
+			int least = 0, greatest = 0;
+			(void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+			if(hipStreamCreateWithPriority(&t->cs3, hipStreamNonBlocking, greatest < 0 ? greatest : -1) != hipSuccess)
+			{
+				(void)hipGetLastError();
+				if(hipStreamCreateWithFlags(&t->cs3, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
+			}
+			t->cs[2] = t->cs3; t->ncs = 3;
+		}
+		rc = pwn_i_set_launch_rotation(c, t->ncs == 3 ? 3 : 2);
+		if(rc != PWN_OK) break;
+		if(hipMalloc((void **)&t->cost_acc, 64 * NSLOT) != hipSuccess) { rc = PWN_ENOMEM; break; }
+		if(hipMemset(t->cost_acc, 0, 64 * NSLOT) != hipSuccess) { rc = PWN_EHIP; break; }
 		for(int s = 0; s < NSLOT && rc == PWN_OK; s++)
 		{
 			if(hipMalloc((void **)&t->pre[s], n * 4) != hipSuccess || hipMalloc((void **)&t->out[s], n * 4) != hipSuccess ||
@@ -907,7 +927,6 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	// on 16 CUs, 1.25 % of the grid.  Not measurable without several GPUs; PWN_TILED_RESERVE=n overrides it
 	// (0 = fill every CU), pwn_tiled_set_reserve() changes it between frames: bench.py --gpus N sweeps it.
 	c->grid_reserve = 0;
-	t->instream = c->tiled_choreo != PWN_TILED_CHOREO_SPLIT;
 	if(world == 1 && transport == PWN_TRANSPORT_RCCL && getenv("PWN_TILED_SELF") != NULL && atoi(getenv("PWN_TILED_SELF")) != 0)
 	{
 		if(hipMalloc((void **)&t->self_buf, n * 4 + 64) != hipSuccess) { pwn_tiled_destroy(c); return PWN_ENOMEM; }
@@ -920,7 +939,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	}
 	t->info.rank = rank; t->info.world = world; t->info.y0 = t->cuts[rank]; t->info.y1 = t->cuts[rank + 1]; t->info.rows_per_rank = t->per;
 	t->info.halo_rows = t->halo; t->info.transport = transport;
-	t->info.max_rows = t->max_rows; t->info.grid_reserve = c->grid_reserve; t->info.two_streams = t->cs[1] != t->cs[0];
+	t->info.max_rows = t->max_rows; t->info.grid_reserve = c->grid_reserve; t->info.two_streams = t->ncs > 1; t->info.compute_streams = t->ncs; t->info.choreography = t->instream ? PWN_TILED_CHOREO_INSTREAM : PWN_TILED_CHOREO_SPLIT;
 	t->info.init_timeout_ms = init_timeout_ms(c); t->info.wait_timeout_ms = wait_timeout_ms(c);
 	return PWN_OK;
 }
@@ -1132,7 +1151,7 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 		uint32_t *dst = (t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->out[s];
 		// the trace of this frame, in front of this launch on the stream, added up what the strip cost: the blur
 		// moves that into the frame's second word and clears the accumulator for the stream's next trace
-		uint32_t *acc = t->cost_acc + 16 * (k & 1u);
+		uint32_t *acc = t->cost_acc + 16 * s;
 		int rc;
 		c->blur_cost_mul = t->fcost_mul[s]; c->blur_cost_div = t->fcost_div[s];
 		if(t->fhalo[s])
@@ -1223,11 +1242,12 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	// each other's (and a wave log that grows would be freed under the other stream's kernel).  pwn_i_launch_trace
 	// orders a launch that leaves the alternating pattern behind the launch two before it (the ticket sets).
 	const bool counted = c->counters_on || c->wave_log_on;
-	hipStream_t cs = counted ? t->cs[0] : t->cs[f & 1u];
+	hipStream_t cs = counted ? t->cs[0] : t->cs[f % (unsigned long long)t->ncs];
 	t->fstream[s] = cs;
-	// (a counted frame right behind an uncounted one on the OTHER stream: wait for that frame's trace, so that the
+	// (a counted frame right behind uncounted ones on the OTHER streams: wait for those frames' traces, so that the
 	// counters and the wave log are this launch's alone)
-	if(counted && f > 0 && t->fstream[(f - 1) % NSLOT] != cs) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_t[(f - 1) % NSLOT], 0));
+	for(int back = 1; counted && back < t->ncs && (unsigned long long)back <= f; back++)
+		if(t->fstream[(f - back) % NSLOT] != cs) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_t[(f - back) % NSLOT], 0));
 	t->fhalo[s] = t->halo;
 	t->froot[s] = t->root_mode == PWN_TILED_ROOT_ROTATE ? (int)(f % (unsigned long long)t->world) : 0;
 	memcpy(t->fcuts[s], t->cuts, sizeof(t->cuts));
@@ -1240,9 +1260,9 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	t->timed_g2[s] = false;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
 	c->trace_clear_word = t->missw[s];           // the frame's miss word is cleared by its trace launch (no memset between the kernels)
-	c->trace_cost_word = c->blur_passes ? t->cost_acc + 16 * (f & 1u) : NULL;      // (the blur moves it on: enqueue_blur)
+	c->trace_cost_word = c->blur_passes ? t->cost_acc + 16 * s : NULL;      // (the blur moves it on: enqueue_blur)
 	c->trace_tables_event = t->ev_t[s];          // ... and ev_t, recorded right behind it, also tells when its tables are free again
-	c->launch_room = t->cs[1] != t->cs[0] ? pwn_room_for_launch(c) : 0;          // PWN_OPT_TRACE_ROOM
+	c->launch_room = t->ncs > 1 ? pwn_room_for_launch(c) : 0;          // PWN_OPT_TRACE_ROOM
 	int rc = pwn_i_launch_trace(c, cam, sec, y0, y1, plane, t->z[s], cs);
 	if(rc != PWN_OK) { (void)hipEventRecord(t->ev_t[s], cs); return rc; }
 	t->fcost_mul[s] = c->cost_mul; t->fcost_div[s] = c->cost_div;
@@ -1499,7 +1519,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	}
 	t->delivered = d + 1;
 	t->info.frames++;
-	if(t->cs[1] != t->cs[0]) pwn_room_frame_done(c);
+	if(t->ncs > 1) pwn_room_frame_done(c);
 	if(out != NULL)
 	{
 		memset(out, 0, sizeof(*out));

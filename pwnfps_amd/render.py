@@ -77,6 +77,10 @@ class Renderer:
         True = the exchanges on a third stream, blur and gather one and two submits late (rounds 2-3).  Same frames."""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_TILED_CHOREO, 1 if split else 0), "pwn_set_option")
 
+    def set_tiled_streams(self, n):
+        """PWN_OPT_TILED_STREAMS, before tiled_init: compute streams the frames of an in-stream tiling rotate over, 2 or 3"""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_TILED_STREAMS, int(n)), "pwn_set_option")
+
     def set_unit_order(self, on):
         """PWN_OPT_UNIT_ORDER: the trace kernel's units handed out by what they cost in the last launch (True) or
         in arithmetic order (False, the default).  Never changes a frame."""
