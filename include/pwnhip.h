@@ -159,6 +159,11 @@ int pwn_unit_order_state(pwn_ctx *ctx, unsigned long long out[4]);
 /* the sort by itself (tests): `units` costs in (host memory), the order out -- perm_out holds 64 * cap entries, cap = ceil(units / 64);
    queue q's units, dearest first, are perm_out[q * cap .. q * cap + its length), the rest of its row is left 0xffffffff */
 int pwn_unit_order_probe(pwn_ctx *ctx, const uint16_t *cost, uint32_t units, uint32_t *perm_out);
+/* Trace launches of a context take their work-queue counters from sets used in turn, and launch n resets the set of launch n - R
+   (R = 2; 3 for a tiling on three compute streams): launches R apart have to be ordered.  On one stream, and with frames rotating over
+   R streams, they are by themselves; a launch that leaves the rotation (pwn_trace_screen_centred behind frames in flight, a counted
+   frame) is put behind the launch R before it with an event.  *out = how often that happened (tests). */
+int pwn_launch_order_waits(pwn_ctx *ctx, unsigned long long *out);
 /* PWN_OPT_TRACE_ROOM as it stands: out[0] the option's value (-1 = measuring), out[1] the workgroups the next two-stream trace launch
    leaves free, out[2] how often the two settings were compared, out[3] how often the setting changed */
 int pwn_trace_room_state(pwn_ctx *ctx, int out[4]);

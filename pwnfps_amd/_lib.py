@@ -101,6 +101,7 @@ ABI = [
     ("pwn_blur_rows_device", _i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     ("pwn_blur_rows_device_bounded", _i, [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     ("pwn_unit_order_state", _i, [_vp, _vp]),
+    ("pwn_launch_order_waits", _i, [_vp, _vp]),
     ("pwn_unit_order_probe", _i, [_vp, _vp, C.c_uint32, _vp]),
     ("pwn_tiled_unique_id", _i, [_vp, _i]),
     ("pwn_tiled_init", _i, [_vp, _i, _i, _vp, _i, _i]),

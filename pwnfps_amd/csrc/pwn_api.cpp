@@ -80,7 +80,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 		c->ev_upload[i] = NULL; c->upload_pending[i] = false;
 	}
 	for(int i = 0; i < PWN_NSTAGE; i++) { c->h_stage[i] = NULL; c->ev_stage[i] = NULL; c->stage_used[i] = false; }
-	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0; c->launch_rot = 2;
+	c->d_pre = c->d_out = NULL; c->d_z = NULL; c->d_skip = NULL; c->d_counters = NULL; c->d_tickets = NULL; c->ticket_set = 0; c->launch_rot = 2; c->launch_waits = 0;
 	c->trace_clear_word = NULL; c->trace_cost_word = NULL; c->trace_tables_event = NULL; c->grid_reserve = 0;
 	memset(&c->room, 0, sizeof(c->room)); c->room.mode = -1; c->launch_room = 0;
 	c->cost_mul = c->cost_div = 1u; c->blur_cost_mul = c->blur_cost_div = 0u;
@@ -816,7 +816,11 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	else if(uop != NULL) uop->cost_fresh = false;
 	// This launch clears the ticket set that the launch R before it drew from (above): it has to come after that one.
 	// On one stream and in the rotation over R it does by itself; a launch that leaves the pattern waits.
-	if(c->launch_event[rot - 1] != NULL && c->launch_stream[rot - 1] != stream) HIPCHK(c, hipStreamWaitEvent(stream, c->launch_event[rot - 1], 0));
+	if(c->launch_event[rot - 1] != NULL && c->launch_stream[rot - 1] != stream)
+	{
+		HIPCHK(c, hipStreamWaitEvent(stream, c->launch_event[rot - 1], 0));
+		c->launch_waits++;
+	}
 	if(refill) HIPCHK(c, pwn_launch_trace_refill(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	else HIPCHK(c, pwn_launch_trace(&P, grid, lds_bytes, c->counters_on != 0, stream));
 	c->ticket_set++;                     // only a launch that went out has cleared the other set
@@ -874,6 +878,13 @@ extern "C" int pwn_unit_order_probe(pwn_ctx *c, const uint16_t *cost, uint32_t u
 	   hipMemcpy(perm_out, d_perm, (size_t)cap * PWN_QUEUES * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = PWN_EHIP;
 	(void)hipFree(d_cost); (void)hipFree(d_perm);
 	return rc;
+}
+
+extern "C" int pwn_launch_order_waits(pwn_ctx *c, unsigned long long *out)
+{
+	if(c == NULL || out == NULL) return PWN_EINVAL;
+	*out = c->launch_waits;
+	return PWN_OK;
 }
 
 extern "C" int pwn_unit_order_state(pwn_ctx *c, unsigned long long out[4])

@@ -178,6 +178,7 @@ struct pwn_ctx
 	// stream and while frames alternate between two (n - 2 is then on n's stream), NOT when a launch leaves that pattern
 	// (a blocking call or a counted frame between alternating ones) -- pwn_i_launch_trace then waits for this event.
 	hipStream_t launch_stream[3]; hipEvent_t launch_event[3];     // [0] the last launch, [1] the one before, [2] the one before that
+	unsigned long long launch_waits; // launches that left the rotation and were put behind the launch R before them (pwn_launch_order_waits)
 	int launch_rot;                  // streams that successive trace launches rotate over: 2 (one stream, or two alternating), 3 (pwn_i_set_launch_rotation)
 
 	char err[256];

@@ -86,6 +86,12 @@ class Renderer:
         in arithmetic order (False, the default).  Never changes a frame."""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_UNIT_ORDER, 1 if on else 0), "pwn_set_option")
 
+    def launch_order_waits(self):
+        """trace launches so far that left the rotation over the compute streams and were ordered behind the launch R before them"""
+        out = C.c_uint64(0)
+        self._chk(lib.pwn_launch_order_waits(self._ctx, C.byref(out)), "pwn_launch_order_waits")
+        return int(out.value)
+
     def unit_order_state(self):
         out = (C.c_uint64 * 4)()
         self._chk(lib.pwn_unit_order_state(self._ctx, out), "pwn_unit_order_state")

@@ -142,3 +142,40 @@ def test_trace_room_never_changes_a_frame(oracle_lib, cases):
     sb, _ = r.trace_screen_centred(cam, c["sec"])
     assert oracle_lib.fnv64(sb) == c["post"]
     r.close()
+
+
+def test_a_launch_that_leaves_the_rotation_is_ordered_behind_the_launch_two_before_it(oracle_lib):
+    """trace launches take their work-queue counters from sets used in turn and launch n resets the set of launch
+    n - 2.  Frames in flight alternate between two streams, so launches two apart are on one stream; a blocking
+    pwn_trace_screen_centred behind two frames in flight is launch n on the first stream with launch n - 2 on the SECOND: it has to
+    wait for that frame's event (the wait was lost once in round 4 and nothing noticed: hence the count)."""
+    import pwnfps_amd
+    from oracle import Oracle
+    base = load_spheres("t0")
+    r = pwnfps_amd.Renderer(W, H)
+    r.level_load(level_path("pwnfps_level"))
+    r.frames_config(3, sbuf=True)
+    O = Oracle()
+    O.load_level(level_path("pwnfps_level"))
+    assert r.launch_order_waits() == 0
+    for f in range(5):                                      # frames 0 .. 4 on streams 0 1 0 1 0: the rotation itself needs no wait
+        if f >= 3:
+            r.wait_frame(f % 3)
+        cam, sec, sph = _scene(f, base)
+        r.set_objects(sph)
+        r.submit_frame(cam, sec, f % 3)
+    assert r.launch_order_waits() == 0
+    # launch 5 by the blocking form: on the first stream, like launch 4; launch 3 went out on the second
+    cam, sec, sph = _scene(5, base)
+    r.set_objects(sph)
+    sb = np.empty((H, W), np.uint32)
+    r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
+    assert r.launch_order_waits() == 1
+    O.set_spheres(sph)
+    assert oracle_lib.fnv64(sb) == oracle_lib.fnv64(O.render(W, H, cam, sec=sec, blur=1)[0])
+    for k in (3, 4):
+        fr = r.wait_frame(k % 3)
+        cam, sec, sph = _scene(k, base)
+        O.set_spheres(sph)
+        assert oracle_lib.fnv64(fr["sbuf"]) == oracle_lib.fnv64(O.render(W, H, cam, sec=sec, blur=1)[0])
+    r.close()
