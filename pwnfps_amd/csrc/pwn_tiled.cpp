@@ -1175,6 +1175,38 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 	return PWN_OK;
 }
 
+// G2 of the frames [from, to) as ONE grouped launch on `gs` (behind their blurs -- and copies to the host -- which the caller
+// has put in front on that stream, or which `gs` is made to wait for here), their words to pinned memory, the event
+// pwn_tiled_wait waits for
+static int gather_frames(pwn_ctx *c, pwn_tiled *t, unsigned long long from, unsigned long long to, hipStream_t gs)
+{
+	int rc;
+	const int ls = (int)((to - 1) % NSLOT);
+	for(unsigned long long g = from; g < to; g++)
+	{
+		const int s = (int)(g % NSLOT);
+		if(t->host_base != NULL)
+		{
+			if(gs != t->copy) HIPCHK(c, hipStreamWaitEvent(gs, t->ev_h[s], 0));       // the word goes out behind the copy (which is behind the blur)
+		}
+		else if(gs != t->fstream[s]) HIPCHK(c, hipStreamWaitEvent(gs, t->ev_b[s], 0));
+	}
+	if(t->timed[ls]) HIPCHK(c, hipEventRecord(t->ev_g0[ls], gs));
+	if(t->world > 1 || t->self_exchange)
+	{
+		TPCHK(c, t->tp->begin(gs));
+		for(unsigned long long g = from; g < to; g++) { rc = t->self_exchange ? add_self_gather(c, t, g) : add_gather(c, t, g); if(rc != PWN_OK) return rc; }
+		TPCHK(c, t->tp->end());
+		t->info.groups++;
+	}
+	if(t->timed[ls]) { HIPCHK(c, hipEventRecord(t->ev_g1[ls], gs)); t->timed_g2[ls] = true; }
+	for(unsigned long long g = from; g < to; g++) { rc = fetch_words(c, t, g, gs); if(rc != PWN_OK) return rc; }
+	HIPCHK(c, hipEventRecord(t->ev_d[ls], gs));
+	for(unsigned long long g = from; g < to; g++) t->gathered_by[g % NSLOT] = t->ev_d[ls];
+	t->gathered = to;
+	return PWN_OK;
+}
+
 // the pre-blur rows of the frame in slot s that the neighbours' blurs read (or, without a bounded halo, whole strips to
 // everybody), as one grouped launch on `xs`, behind the frame's trace
 static int exchange_halo(pwn_ctx *c, pwn_tiled *t, int s, hipStream_t xs, int y0, int y1)
@@ -1276,27 +1308,22 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 		rc = exchange_halo(c, t, s, cs, y0, y1);
 		if(rc != PWN_OK) return rc;
 		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g3[s], cs));
+		// Host sink: the words of a frame go out behind this rank's copy of its strip to the host, on the copy's stream (the
+		// compute stream does not wait for PCIe) -- and one submit late, IN FRONT of this frame's copy: the transport runs
+		// its launches in the order they were made, so G1(f+1) would otherwise wait for G2(f) and with it for copy f.
+		if(t->host_base != NULL && t->gathered < f)
+		{
+			rc = gather_frames(c, t, t->gathered, f, t->copy);
+			if(rc != PWN_OK) return rc;
+		}
 		rc = enqueue_blur(c, t, f);
 		if(rc != PWN_OK) return rc;
 		t->blurred = f + 1;
-		// (host sink: the words go out behind this rank's copy to the host, on the copy's stream -- the compute stream does not
-		// wait for PCIe)
-		hipStream_t gs = t->host_base != NULL ? t->copy : cs;
-		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g0[s], gs));
-		if(t->world > 1 || t->self_exchange)
+		if(t->host_base == NULL)
 		{
-			TPCHK(c, t->tp->begin(gs));
-			rc = t->self_exchange ? add_self_gather(c, t, f) : add_gather(c, t, f);
+			rc = gather_frames(c, t, f, f + 1, cs);
 			if(rc != PWN_OK) return rc;
-			TPCHK(c, t->tp->end());
-			t->info.groups++;
 		}
-		if(t->timed[s]) { HIPCHK(c, hipEventRecord(t->ev_g1[s], gs)); t->timed_g2[s] = true; }
-		rc = fetch_words(c, t, f, gs);
-		if(rc != PWN_OK) return rc;
-		HIPCHK(c, hipEventRecord(t->ev_d[s], gs));
-		t->gathered_by[s] = t->ev_d[s];
-		t->gathered = f + 1;
 		t->submitted = f + 1;
 		t->enqueue_us[s] = (float)(now_us() - t_in);
 		return PWN_OK;
@@ -1320,26 +1347,8 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	const unsigned long long g_end = f >= 1 ? f - 1 : 0;        // gather frames [gathered, g_end)
 	if(g_end > t->gathered)
 	{
-		for(unsigned long long g = t->gathered; g < g_end; g++)
-		{
-			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
-			if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));       // the word goes out behind the copy
-		}
-		const int gs = (int)((g_end - 1) % NSLOT);
-		if(t->timed[gs]) { HIPCHK(c, hipEventRecord(t->ev_g0[gs], t->comm)); }
-		if(t->world > 1 || t->self_exchange)
-		{
-			TPCHK(c, t->tp->begin(t->comm));
-			for(unsigned long long g = t->gathered; g < g_end; g++) { rc = t->self_exchange ? add_self_gather(c, t, g) : add_gather(c, t, g); if(rc != PWN_OK) return rc; }
-			TPCHK(c, t->tp->end());
-			t->info.groups++;
-		}
-		if(t->timed[gs]) { HIPCHK(c, hipEventRecord(t->ev_g1[gs], t->comm)); t->timed_g2[gs] = true; }
-		for(unsigned long long g = t->gathered; g < g_end; g++) { rc = fetch_words(c, t, g, t->comm); if(rc != PWN_OK) return rc; }
-		hipEvent_t done = t->ev_d[(g_end - 1) % NSLOT];
-		HIPCHK(c, hipEventRecord(done, t->comm));
-		for(unsigned long long g = t->gathered; g < g_end; g++) t->gathered_by[g % NSLOT] = done;
-		t->gathered = g_end;
+		rc = gather_frames(c, t, t->gathered, g_end, t->comm);
+		if(rc != PWN_OK) return rc;
 	}
 	// ---- then this frame's pre-blur rows, behind its trace
 	HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_t[s], 0));
@@ -1414,22 +1423,9 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	}
 	if(t->gathered <= d)
 	{
-		for(unsigned long long g = t->gathered; g <= d; g++)
-		{
-			HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_b[g % NSLOT], 0));
-			if(t->host_base != NULL) HIPCHK(c, hipStreamWaitEvent(t->comm, t->ev_h[g % NSLOT], 0));
-		}
-		if(t->world > 1 || t->self_exchange)
-		{
-			TPCHK(c, t->tp->begin(t->comm));
-			for(unsigned long long g = t->gathered; g <= d; g++) { rc = t->self_exchange ? add_self_gather(c, t, g) : add_gather(c, t, g); if(rc != PWN_OK) return rc; }
-			TPCHK(c, t->tp->end());
-			t->info.groups++;
-		}
-		for(unsigned long long g = t->gathered; g <= d; g++) { rc = fetch_words(c, t, g, t->comm); if(rc != PWN_OK) return rc; }
-		HIPCHK(c, hipEventRecord(t->ev_d[s], t->comm));
-		for(unsigned long long g = t->gathered; g <= d; g++) t->gathered_by[g % NSLOT] = t->ev_d[s];
-		t->gathered = d + 1;
+		// (in-stream, which leaves only a host sink's words for later: behind the copies, on their stream)
+		rc = gather_frames(c, t, t->gathered, d + 1, t->instream ? (t->host_base != NULL ? t->copy : t->fstream[s]) : t->comm);
+		if(rc != PWN_OK) return rc;
 	}
 	rc = wait_event(c, t, t->gathered_by[s], "the group that carries its strips and words", d);
 	if(rc != PWN_OK) return rc;

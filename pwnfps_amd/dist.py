@@ -42,7 +42,8 @@ whole strips from then on.
 Host sink (``pwn_tiled_host_sink``; here ``host_sink=`` an array of NSLOT frames in memory that every
 rank has mapped): there is no gather.  Behind its blur every rank copies its strip into the frame, and
 the second half of a group is one word per pair of ranks, sent after the sender's copy; a frame is
-delivered, on every rank, when every other rank's word of it has arrived.
+delivered, on every rank, when every other rank's word of it has arrived.  (The C code sends that word one submit
+late, on the copy's stream in front of the next frame's copy, so that no exchange waits for PCIe; the same groups.)
 """
 import numpy as np
 import torch
