@@ -611,6 +611,7 @@ def main():
 
     launch_ms = []
     last = {"f": None}
+    tiled_depth = [3]
     diag = {"trace_ms": [], "blur_ms": [], "halo_ms": [], "gather_ms": [], "frame_ms": [], "enqueue_us": [], "rows": 0, "cost": 0, "redone": 0}
 
     def diag_reset():
@@ -664,16 +665,17 @@ def main():
             for i in range(max(0, n - nres), n):
                 note(r.wait_frame(i % nres))
         else:
-            # N > 1: three frames in flight
+            # N > 1: tiled_depth[0] frames in flight (three; the sweep also tries five)
+            behind = tiled_depth[0] - 1
             for i in range(n):
                 if not early or i == 0:
                     r.set_objects(spheres)
                 r.tiled_submit(cam, sec)
                 if early and i + 1 < n:
                     r.set_objects(spheres)          # frame i+1's tables, before the wait below
-                if i >= 2:
+                if i >= behind:
                     note(r.tiled_wait())
-            for _ in range(min(n, 2)):
+            for _ in range(min(n, behind)):
                 note(r.tiled_wait())
 
     def block():
@@ -940,6 +942,10 @@ def main():
             r.tiled_set_reserve(rsv)
             point("reserve_%d" % rsv, "PWN_TILED_RESERVE = %d workgroups of the persistent trace grid left free for the transport's kernels" % rsv)
         r.tiled_set_reserve(reserve0)
+        # the host collecting frames four behind its submissions instead of two
+        tiled_depth[0] = 5
+        point("five_in_flight", "five frames in flight instead of three (PWN_TILED_SLOTS - 1): the host waits for frame f-4 after submitting f")
+        tiled_depth[0] = 3
         # the gather spread over the ranks: frame f assembled on rank f mod N (pwn_tiled_gather_root) -- no rank's links carry every
         # frame; what a consumer on every GPU would get
         try:
