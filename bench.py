@@ -871,6 +871,7 @@ def main():
             line["tiling"]["preflight"] = preflight
             line["tiling"]["preflight_summary"] = preflight_summary
             line["tiling"]["rccl_nonblocking"] = tinfo.get("rccl_nonblocking")
+            line["tiling"]["communicators"] = tinfo.get("communicators")
             line["tiling"]["deadlines_s"] = {"library_init": lib_init_s, "library_wait": lib_wait_s, "bring_up": args.bringup_timeout,
                                              "headline": args.headline_timeout, "post": args.post_timeout}
             if transport_note:
@@ -972,37 +973,31 @@ def main():
             except Exception as e:                                   # noqa: BLE001 -- (cuts outside the library's bounds: no point)
                 sweep["rank0_tall"] = {"error": str(e)}
         r.tiled_balance(bal)
-        barrier()
-        r.tiled_shutdown()
-        r.set_frame_overlap(False)
-        ok1, _ = bring_up(transport, tag="sweep.one_stream:")
-        if ok1:
-            point("one_stream", "PWN_OPT_FRAME_OVERLAP 0: every frame's kernels on ONE compute stream")
-        barrier()
-        r.tiled_shutdown()
-        r.set_frame_overlap(True)
-        ok2, _ = bring_up(transport, halo=0, tag="sweep.whole_strips:")
-        if ok2:
-            point("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows")
-        # the choreography of rounds 2-3: the exchanges on a third stream, blur and gather one and two submits late
-        barrier()
-        r.tiled_shutdown()
-        r.set_tiled_choreo(True)
-        ok4, _ = bring_up(transport, tag="sweep.choreo_split:")
-        if ok4:
-            point("choreo_split", "PWN_OPT_TILED_CHOREO = split: the exchanges on a third stream tied to the kernels by events, blur f enqueued by submit f+1 "
-                                  "and its gather by submit f+2 (the headline: everything of a frame in order on the frame's own stream)")
-        barrier()
-        r.tiled_shutdown()
-        r.set_tiled_choreo(False)
-        # frames rotating over three compute streams instead of alternating between two
-        r.set_tiled_streams(3)
-        ok5, _ = bring_up(transport, tag="sweep.three_streams:")
-        if ok5:
-            point("three_streams", "PWN_OPT_TILED_STREAMS = 3: frame f on compute stream f mod 3 (one GPU: a strip-sized frame 8 % faster, a whole 4K frame 8 % slower)")
-        barrier()
-        r.tiled_shutdown()
-        r.set_tiled_streams(2)
+        # ---- legs that set the tiling up again, the ones a first multi-GPU run learns most from first.  (The options are read by
+        # pwn_tiled_init and refuse to change while a tiling exists: each leg shuts the last one down, then sets its own.)
+        def again(name, what, comms=False, streams=2, split=False, overlap=True, halo=None, depth=3):
+            barrier()
+            r.tiled_shutdown()
+            r.set_tiled_comms(comms)
+            r.set_tiled_streams(streams)
+            r.set_tiled_choreo(split)
+            r.set_frame_overlap(overlap)
+            ok, _ = bring_up(transport, halo=halo, tag="sweep.%s:" % name)
+            if ok:
+                tiled_depth[0] = depth
+                point(name, what)
+                tiled_depth[0] = 3
+        if transport == "rccl":
+            # a communicator per compute stream: the streams' exchanges do not wait for each other (one communicator runs its
+            # launches in the order they were made); then that with three streams and four frames in flight -- on one GPU, a
+            # rank exchanging with itself, the fastest form measured
+            again("comm_per_stream", "PWN_OPT_TILED_COMMS = per stream: one RCCL communicator per compute stream instead of one for both", comms=True)
+            again("three_streams_comm_per_stream", "three compute streams, a communicator each, four frames in flight", comms=True, streams=3, depth=4)
+        again("three_streams", "PWN_OPT_TILED_STREAMS = 3: frame f on compute stream f mod 3 (one GPU: a strip-sized frame 8 % faster, a whole 4K frame 8 % slower)", streams=3)
+        again("choreo_split", "PWN_OPT_TILED_CHOREO = split (rounds 2-3): the exchanges on a third stream tied to the kernels by events, blur f enqueued by submit f+1 "
+                              "and its gather by submit f+2 (the headline: everything of a frame in order on the frame's own stream)", split=True)
+        again("one_stream", "PWN_OPT_FRAME_OVERLAP 0: every frame's kernels on ONE compute stream", overlap=False)
+        again("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows", halo=0)
         if transport == "rccl" and args.sweep_nonblocking:
             # (opt-in: an optional leg on the least-travelled path must not be able to cost a run its clean exit)
             # the other way of driving the communicator: non-blocking, every call polled against the deadline (a grouped launch is

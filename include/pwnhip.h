@@ -125,6 +125,15 @@ typedef struct pwn_stats
                                   size -- a strip of an 8-way tiled 4K frame needs 0.05 ms of kernels. */
 #define PWN_TILED_CHOREO_INSTREAM 0
 #define PWN_TILED_CHOREO_SPLIT    1
+#define PWN_OPT_TILED_COMMS 12   /* row tiling over RCCL, in-stream choreography, read by pwn_tiled_init (PWN_EBUSY while a tiling exists;
+                                  PWN_TILED_COMMS=perstream in the environment).  PWN_TILED_COMMS_ONE (default): one communicator for all
+                                  exchanges -- it runs its grouped launches in the order they were made, so frame f+1's halo rows start
+                                  behind frame f's gather although the two are on different streams.  PWN_TILED_COMMS_PER_STREAM: one
+                                  communicator per compute stream (each brought up like the first, under the deadline; its id travels from
+                                  rank 0 over the first): the streams' exchanges are independent.  Blocking mode only.  Never run between
+                                  GPUs (nor has anything else here); on one GPU, a rank's exchange with itself: DESIGN.md 6. */
+#define PWN_TILED_COMMS_ONE        1
+#define PWN_TILED_COMMS_PER_STREAM 2
 #define PWN_OPT_TILED_STREAMS 11 /* row tiling, in-stream choreography, read by pwn_tiled_init (PWN_EBUSY while a tiling exists; PWN_TILED_STREAMS=n
                                   in the environment): 2 = frames alternate between the context's two compute streams, 3 = they rotate
                                   over those and a third that the tiling creates -- two frames' exchanges and blurs then overlap a third
@@ -411,6 +420,7 @@ typedef struct pwn_tiled_info
 	int dead;                                      /* 1: a deadline passed or the transport failed; the communicator is gone */
 	int compute_streams;                           /* 1, 2 or 3: frame f runs on compute stream f mod this (PWN_OPT_FRAME_OVERLAP, PWN_OPT_TILED_STREAMS) */
 	int choreography;                              /* PWN_TILED_CHOREO_* as fixed at pwn_tiled_init */
+	int communicators;                             /* RCCL transport: communicators in use (PWN_OPT_TILED_COMMS); 0 over shared memory */
 } pwn_tiled_info;
 int pwn_tiled_unique_id(void *id128, int transport);
 int pwn_tiled_init(pwn_ctx *ctx, int rank, int world, const void *id128, int transport, int halo_rows);

@@ -17,6 +17,7 @@ PWN_OPT_TRACE_ROOM = 8
 PWN_OPT_UNIT_ORDER = 9
 PWN_OPT_TILED_CHOREO = 10
 PWN_OPT_TILED_STREAMS = 11
+PWN_OPT_TILED_COMMS = 12
 PWN_TILED_CHOREO_INSTREAM, PWN_TILED_CHOREO_SPLIT = 0, 1
 PWN_SCHED_UNITS, PWN_SCHED_REFILL = 0, 1
 PWN_MAX_SLOTS = 4
@@ -61,7 +62,7 @@ class TiledInfo(C.Structure):
                [(n, C.c_uint64) for n in ("frames", "frames_redone", "groups", "bytes_sent", "bytes_received", "bytes_to_host")] + \
                [(n, C.c_int) for n in ("host_sink", "max_rows", "balance_every", "grid_reserve", "two_streams")] + \
                [("recuts", C.c_uint64), ("gather_root", C.c_int), ("rccl_nonblocking", C.c_int),
-                ("init_timeout_ms", C.c_int), ("wait_timeout_ms", C.c_int), ("dead", C.c_int), ("compute_streams", C.c_int), ("choreography", C.c_int)]
+                ("init_timeout_ms", C.c_int), ("wait_timeout_ms", C.c_int), ("dead", C.c_int), ("compute_streams", C.c_int), ("choreography", C.c_int), ("communicators", C.c_int)]
 
 
 PWN_TILED_ID_BYTES = 128

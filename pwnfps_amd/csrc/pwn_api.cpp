@@ -92,6 +92,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	if(const char *e = getenv("PWN_FRAME_OVERLAP")) c->frame_overlap = atoi(e) != 0;
 	c->unit_order = 0;             // (measured: a loss except on short launches that run alone, profiles/r4/unit_order_ab.txt)
 	if(const char *e = getenv("PWN_UNIT_ORDER")) c->unit_order = atoi(e) != 0;
+	c->tiled_comms = PWN_TILED_COMMS_ONE;
+	if(const char *e = getenv("PWN_TILED_COMMS")) c->tiled_comms = (strcmp(e, "perstream") == 0 || strcmp(e, "2") == 0) ? PWN_TILED_COMMS_PER_STREAM : PWN_TILED_COMMS_ONE;
 	c->tiled_streams = PWN_TILED_STREAMS_DEFAULT;
 	if(const char *e = getenv("PWN_TILED_STREAMS")) { const int v = atoi(e); if(v == 2 || v == 3) c->tiled_streams = v; }
 	c->tiled_choreo = PWN_TILED_CHOREO_INSTREAM;
@@ -280,6 +282,10 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 			if(value != PWN_TILED_CHOREO_INSTREAM && value != PWN_TILED_CHOREO_SPLIT) return PWN_EINVAL;
 			if(c->tiled != NULL) return PWN_EBUSY;
 			c->tiled_choreo = value; return PWN_OK;
+		case PWN_OPT_TILED_COMMS:
+			if(value != PWN_TILED_COMMS_ONE && value != PWN_TILED_COMMS_PER_STREAM) return PWN_EINVAL;
+			if(c->tiled != NULL) return PWN_EBUSY;
+			c->tiled_comms = value; return PWN_OK;
 		case PWN_OPT_TILED_STREAMS:
 			if(value != 2 && value != 3) return PWN_EINVAL;
 			if(c->tiled != NULL) return PWN_EBUSY;

@@ -143,6 +143,7 @@ struct pwn_ctx
 	unsigned long long order_stamp;
 	int tiled_choreo;                // PWN_OPT_TILED_CHOREO, read by pwn_tiled_init
 	int tiled_streams;               // PWN_OPT_TILED_STREAMS, read by pwn_tiled_init
+	int tiled_comms;                 // PWN_OPT_TILED_COMMS, read by pwn_tiled_init
 	int unit_order;                  // the option: 1 = units handed out by last launch's cost, 0 = arithmetic order
 	unsigned long long order_used, order_sorts;      // trace launches that ran in a sorted order; sorts launched (pwn_unit_order_state)
 	bool dbg_force_hasw; int dbg_blocks_per_cu;      // PWN_DBG_* hooks, read at pwn_init

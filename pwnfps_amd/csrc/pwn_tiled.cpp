@@ -158,12 +158,16 @@ static rccl_api *rccl_load(char *err, size_t errlen)
 // On expiry, either way: ncclCommAbort, PWN_ETIMEDOUT, the transport is dead.
 struct rccl_transport : pwn_transport
 {
+	// `comm` is the communicator of the group in hand: comms[0], or -- PWN_OPT_TILED_COMMS -- the one bound to the group's
+	// stream (a communicator runs its launches in the order they were made, whatever their streams: with one per compute
+	// stream a frame's halo rows do not wait for the other stream's gather)
 	rccl_api *api; ncclComm_t comm; hipStream_t stream; bool nb; int rank, world;
-	rccl_transport() : api(NULL), comm(NULL), stream(NULL), nb(false), rank(0), world(1) { err[0] = 0; }
-	~rccl_transport() { if(comm && !dead) (void)api->CommDestroy(comm); }
+	ncclComm_t comms[3]; hipStream_t keys[3]; int ncomm;
+	rccl_transport() : api(NULL), comm(NULL), stream(NULL), nb(false), rank(0), world(1), ncomm(0) { err[0] = 0; for(int i = 0; i < 3; i++) { comms[i] = NULL; keys[i] = NULL; } }
+	~rccl_transport() { for(int i = 0; i < ncomm; i++) if(comms[i] && !dead) (void)api->CommDestroy(comms[i]); }
 	void abort()
 	{
-		if(!dead && comm && api->CommAbort) (void)api->CommAbort(comm);
+		for(int i = 0; i < ncomm; i++) if(!dead && comms[i] && api->CommAbort) (void)api->CommAbort(comms[i]);
 		dead = true;
 	}
 	// nonblocking: the call that returned ncclInProgress is complete when the communicator's state is ncclSuccess again
@@ -196,7 +200,9 @@ struct rccl_transport : pwn_transport
 	int begin(hipStream_t s)
 	{
 		if(dead) { snprintf(err, sizeof(err), "rank %d: the communicator is gone (aborted earlier)", rank); return PWN_ETIMEDOUT; }
-		stream = s; return chk(api->GroupStart(), "ncclGroupStart", true);
+		stream = s; comm = comms[0];
+		for(int i = 1; i < ncomm; i++) if(keys[i] == s) comm = comms[i];
+		return chk(api->GroupStart(), "ncclGroupStart", true);
 	}
 	int send(const void *p, size_t n, int peer) { return chk(api->Send(p, n, ncclUint8, peer, comm, stream), "ncclSend", false); }
 	int recv(void *p, size_t n, int peer) { return chk(api->Recv(p, n, ncclUint8, peer, comm, stream), "ncclRecv", false); }
@@ -205,11 +211,15 @@ struct rccl_transport : pwn_transport
 	{
 		if(dead) return PWN_ETIMEDOUT;
 		if(api->CommGetAsyncError == NULL) return PWN_OK;
-		ncclResult_t st = ncclSuccess;
-		if(api->CommGetAsyncError(comm, &st) != ncclSuccess) return PWN_OK;
-		if(st == ncclSuccess || st == ncclInProgress) return PWN_OK;
-		snprintf(err, sizeof(err), "rank %d: the communicator reports %s", rank, api->GetErrorString(st));
-		return PWN_EHIP;
+		for(int i = 0; i < ncomm; i++)
+		{
+			ncclResult_t st = ncclSuccess;
+			if(api->CommGetAsyncError(comms[i], &st) != ncclSuccess) continue;
+			if(st == ncclSuccess || st == ncclInProgress) continue;
+			snprintf(err, sizeof(err), "rank %d: communicator %d reports %s", rank, i, api->GetErrorString(st));
+			return PWN_EHIP;
+		}
+		return PWN_OK;
 	}
 	const char *name() const { return "rccl"; }
 };
@@ -394,6 +404,40 @@ static int rccl_bringup_bounded(rccl_api *api, int device, const ncclUniqueId &u
 	}
 	*out = st->comm.load();
 	return PWN_OK;
+}
+
+// A further communicator of the same ranks needs an id of its own: rank 0 makes it and sends it to every rank over the
+// communicator that is up (every pair is connected: the bring-up's first exchange).  Bounded by `ms`.
+static int rccl_share_id(rccl_api *api, ncclComm_t cm, int world, int rank, ncclUniqueId *id, int ms, char *err, size_t errlen)
+{
+	if(rank == 0 && api->GetUniqueId(id) != ncclSuccess) { snprintf(err, errlen, "ncclGetUniqueId failed"); return PWN_EHIP; }
+	if(world == 1) return PWN_OK;
+	hipStream_t s = NULL; unsigned char *d = NULL;
+	int rc = PWN_OK;
+	do
+	{
+		if(hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&d, sizeof(ncclUniqueId)) != hipSuccess) { rc = PWN_EHIP; break; }
+		if(rank == 0 && hipMemcpy(d, id, sizeof(ncclUniqueId), hipMemcpyHostToDevice) != hipSuccess) { rc = PWN_EHIP; break; }
+		ncclResult_t r = api->GroupStart();
+		for(int k = 1; k < world && r == ncclSuccess && rank == 0; k++) r = api->Send(d, sizeof(ncclUniqueId), ncclUint8, k, cm, s);
+		if(r == ncclSuccess && rank != 0) r = api->Recv(d, sizeof(ncclUniqueId), ncclUint8, 0, cm, s);
+		const ncclResult_t e = api->GroupEnd();
+		if(r != ncclSuccess || e != ncclSuccess) { snprintf(err, errlen, "rank %d: sending a further communicator's id: %s", rank, api->GetErrorString(r != ncclSuccess ? r : e)); rc = PWN_EHIP; break; }
+		const double t0 = now_ms();
+		for(;;)
+		{
+			const hipError_t q = hipStreamQuery(s);
+			if(q == hipSuccess) break;
+			if(q != hipErrorNotReady) { rc = PWN_EHIP; break; }
+			if(now_ms() - t0 > (double)ms) { snprintf(err, errlen, "rank %d of %d: a further communicator's id did not arrive within %d ms", rank, world, ms); rc = PWN_ETIMEDOUT; break; }
+			struct timespec ts = { 0, 100 * 1000 }; nanosleep(&ts, NULL);
+		}
+		if(rc != PWN_OK) break;
+		if(rank != 0 && hipMemcpy(id, d, sizeof(ncclUniqueId), hipMemcpyDeviceToHost) != hipSuccess) rc = PWN_EHIP;
+	} while(0);
+	if(rc == PWN_EHIP && err[0] == 0) snprintf(err, errlen, "rank %d: a HIP call failed while sending a further communicator's id", rank);
+	if(rc != PWN_ETIMEDOUT) { if(d) (void)hipFree(d); if(s) (void)hipStreamDestroy(s); }      // (on expiry the stream still holds the launch: left to the abort)
+	return rc;
 }
 
 // ---- shared memory through the host (tests: several ranks on ONE GPU).  One mailbox per
@@ -828,6 +872,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 			// the communicator and one word to and from every other rank, under the bring-up deadline
 			rc = rccl_bringup_bounded(api, c->device, uid, world, rank, nb, init_timeout_ms(c), &rt->comm, c->err, sizeof(c->err));
 			if(rc != PWN_OK) { rt->dead = true; break; }
+			rt->comms[0] = rt->comm; rt->keys[0] = t->cs[0]; rt->ncomm = 1;
 			t->info.rccl_nonblocking = nb ? 1 : 0;
 		}
 		else if(transport == PWN_TRANSPORT_SHM)
@@ -866,6 +911,26 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 				if(hipStreamCreateWithFlags(&t->cs3, hipStreamNonBlocking) != hipSuccess) { rc = PWN_EHIP; break; }
 			}
 			t->cs[2] = t->cs3; t->ncs = 3;
+		}
+		// PWN_OPT_TILED_COMMS: a communicator per compute stream (in-stream choreography, blocking mode).  Each comes up like the
+		// first -- ncclCommInitRank and a word with every peer under the bring-up deadline -- with an id that rank 0 sends round
+		// over the first.
+		if(transport == PWN_TRANSPORT_RCCL && t->instream && t->ncs > 1 && c->tiled_comms == PWN_TILED_COMMS_PER_STREAM && !rccl_mode_nonblocking())
+		{
+			rccl_transport *rt = (rccl_transport *)t->tp;
+			for(int k = 1; k < t->ncs && rc == PWN_OK; k++)
+			{
+				ncclUniqueId id2;
+				memset(&id2, 0, sizeof(id2));
+				c->err[0] = 0;
+				rc = rccl_share_id(rt->api, rt->comms[0], world, rank, &id2, init_timeout_ms(c), c->err, sizeof(c->err));
+				if(rc != PWN_OK) break;
+				ncclComm_t cm = NULL;
+				rc = rccl_bringup_bounded(rt->api, c->device, id2, world, rank, false, init_timeout_ms(c), &cm, c->err, sizeof(c->err));
+				if(rc != PWN_OK) break;
+				rt->comms[k] = cm; rt->keys[k] = t->cs[k]; rt->ncomm = k + 1;
+			}
+			if(rc != PWN_OK) { rt->abort(); break; }
 		}
 		rc = pwn_i_set_launch_rotation(c, t->ncs == 3 ? 3 : 2);
 		if(rc != PWN_OK) break;
@@ -940,6 +1005,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	t->info.rank = rank; t->info.world = world; t->info.y0 = t->cuts[rank]; t->info.y1 = t->cuts[rank + 1]; t->info.rows_per_rank = t->per;
 	t->info.halo_rows = t->halo; t->info.transport = transport;
 	t->info.max_rows = t->max_rows; t->info.grid_reserve = c->grid_reserve; t->info.two_streams = t->ncs > 1; t->info.compute_streams = t->ncs; t->info.choreography = t->instream ? PWN_TILED_CHOREO_INSTREAM : PWN_TILED_CHOREO_SPLIT;
+	t->info.communicators = transport == PWN_TRANSPORT_RCCL ? ((rccl_transport *)t->tp)->ncomm : 0;
 	t->info.init_timeout_ms = init_timeout_ms(c); t->info.wait_timeout_ms = wait_timeout_ms(c);
 	return PWN_OK;
 }

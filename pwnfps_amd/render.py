@@ -77,6 +77,10 @@ class Renderer:
         True = the exchanges on a third stream, blur and gather one and two submits late (rounds 2-3).  Same frames."""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_TILED_CHOREO, 1 if split else 0), "pwn_set_option")
 
+    def set_tiled_comms(self, per_stream):
+        """PWN_OPT_TILED_COMMS, before tiled_init: False (default) = one RCCL communicator; True = one per compute stream"""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_TILED_COMMS, 2 if per_stream else 1), "pwn_set_option")
+
     def set_tiled_streams(self, n):
         """PWN_OPT_TILED_STREAMS, before tiled_init: compute streams the frames of an in-stream tiling rotate over, 2 or 3"""
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_TILED_STREAMS, int(n)), "pwn_set_option")

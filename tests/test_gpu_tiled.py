@@ -190,6 +190,24 @@ def test_tiled_over_rccl_with_one_rank(tmp_path, oracle_lib):
     assert infos[0]["transport"] == 0 and infos[0]["world"] == 1
 
 
+@pytest.mark.parametrize("comms,streams,depth", [("one", 2, 3), ("perstream", 2, 3), ("perstream", 3, 4), ("one", 3, 5)])
+def test_one_rank_exchanging_with_itself_over_rccl(comms, streams, depth, tmp_path, oracle_lib):
+    """PWN_TILED_SELF=1 (measurement mode): the rank sends itself what a rank of a real tiling sends -- border rows
+    behind every trace, its finished strip and its words behind every blur -- in the library's two grouped launches per frame,
+    on the frames' own compute streams.  With one communicator for all streams, and with one per stream (PWN_OPT_TILED_COMMS:
+    every further communicator is brought up like the first, its id travelling over the first); two and three compute streams;
+    three to five frames in flight.  The frames are the oracle's."""
+    w, h, frames = 640, 360, 12
+    want = oracle_hashes(w, h, "pwnfps_level", frames, oracle_lib)
+    env = {"PWN_TILED_SELF": "1", "PWN_TILED_COMMS": comms, "PWN_TILED_STREAMS": str(streams), "TILED_DEPTH": str(depth)}
+    hashes, infos = run_ranks(1, w, h, "pwnfps_level", frames, -1, tmp_path, transport="rccl", extra_env=env)
+    assert [x[1] for x in hashes] == want
+    i = infos[0]
+    assert i["transport"] == 0 and i["world"] == 1 and i["compute_streams"] == streams and i["choreography"] == 0
+    assert i["communicators"] == (streams if comms == "perstream" else 1)
+    assert i["groups"] == 2 * frames and i["bytes_sent"] == i["bytes_received"] > frames * h * w * 4
+
+
 @pytest.mark.parametrize("name", ["level_spawn_3840x2160", "synth256_cam0_7680x4320"])
 def test_eight_strip_geometry_single_process(name, oracle_lib, cases):
     """The per-rank kernels of an 8-GPU run at the BASELINE sizes, one process: every strip of the 8-way
