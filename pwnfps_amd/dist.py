@@ -4,7 +4,8 @@ operations.
 
 The product path is the C one: ``Renderer.tiled_init / tiled_submit / tiled_wait``
 (``include/pwnhip.h``, RCCL inside the library); ``bench.py --gpus N`` and ``host/pwnhost -W N``
-use it.  This module is the same state machine, statement for statement, with
+use it.  This module is the same state machine in the C code's default order (what goes into which group, which
+buffers a frame owns, what every rank decides from the words), with
 
 * the transport = one ``batch_isend_irecv`` per grouped exchange (gloo on CPU, nccl = RCCL on
   GPUs), and
