@@ -425,7 +425,13 @@ def main():
     transport = os.environ.get("PWN_BENCH_TRANSPORT", "rccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    line_out = sys.stdout
     if world > 1:
+        # stdout carries the JSON line and nothing else: from here on whatever libraries write to descriptor 1 (gloo announces its
+        # connections there) goes to stderr, and the line is written to a copy of the original descriptor
+        sys.stdout.flush()
+        line_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         # control plane (the group id, barriers, the max over ranks): gloo.  The data path is the
         # library's own RCCL communicator (ncclSend / ncclRecv over xGMI), not torch's.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -450,7 +456,7 @@ def main():
         line.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, incomplete=True, error=reason,
                     stage_reached=stages)
         return line
-    dog = watch.Watch(board, diagnostic_line)
+    dog = watch.Watch(board, diagnostic_line, out=line_out)
     _RUN.update(dog=dog, board=board, world=world, rank=rank)
     if world > 1:
         dog.catch_sigterm()
@@ -1044,7 +1050,7 @@ def main():
     dog.disarm()
     post["note"] = None
     if rank == 0:
-        print(json.dumps(build_line()), flush=True)
+        print(json.dumps(build_line()), file=line_out, flush=True)
 
     if world > 1:
         barrier()

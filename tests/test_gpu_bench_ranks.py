@@ -37,6 +37,8 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    # ONE line on stdout and nothing else (gloo announces its connections on descriptor 1: bench.py sends that to stderr)
+    assert [l for l in p.stdout.splitlines() if l.strip()] == lines, p.stdout[:600]
     d = json.loads(lines[0])
     assert d["n_gpus"] == world and d["steps"] == 6 and d["value"] > 0
     assert d["frame_fnv64"] == golden
