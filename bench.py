@@ -793,7 +793,7 @@ def main():
             slow = int(np.argmax(tm))
             strip_pix = ranks["rows"][slow] * w
             trace_ms = tm[slow]
-            par = "rows/%d with moving cuts, two grouped %s send/recv launches per frame (%s; the gather of the strips of the frame two back), 3 frames in flight on %s" % (
+            par = "rows/%d with moving cuts, two grouped %s send/recv launches per frame in order on the frame's own stream (%s in front of the blur; the gather of the finished strips behind it), 3 frames in flight on %s" % (
                 world, transport.upper(), ("%d halo rows per neighbour" % tinfo["halo_rows"]) if tinfo["halo_rows"] else "whole pre-blur strips to every rank",
                 "two compute streams" if tinfo["two_streams"] else "one compute stream")
         achieved = TRACE_BYTES_PER_PIXEL * strip_pix / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
@@ -884,9 +884,8 @@ def main():
                 line["tiling"]["transport_note"] = transport_note
             line["tiling"]["cuts"] = cuts_now
             # every rank's own account of the headline leg: kernel times of the timed frames (HIP events; with two compute
-            # streams a trace shares the chip with the neighbour frames' kernels), the two grouped exchanges on the comm
-            # stream (halo = this frame's border rows, gather = the finished strips of the frame two back + the ranks'
-            # words), host time inside pwn_tiled_submit per frame, the rows of its strip and what they cost
+            # streams a trace shares the chip with the neighbour frames' kernels), the two grouped exchanges (halo = this
+            # frame's border rows, gather = its finished strips + the ranks' words), host time inside pwn_tiled_submit per frame, the rows of its strip and what they cost
             line["tiling"]["per_rank"] = ranks
             if sweep is not None:
                 line["tiling"]["sweep"] = sweep

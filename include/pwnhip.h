@@ -393,8 +393,8 @@ typedef struct pwn_tiled_frame
 	int timed;                   /* PWN_OPT_FRAME_TIMING sampled this frame: */
 	float trace_ms, frame_ms;    /*   this rank's trace kernel; its trace .. blur incl. waiting for the exchange */
 	float blur_ms;               /*   its blur kernel */
-	float halo_ms, gather_ms;    /*   the two grouped exchanges on the comm stream: this frame's halo rows (G1); the gather that
-	                                  carried this frame's strips and words (G2; 0 when pwn_tiled_wait had to launch it itself) */
+	float halo_ms, gather_ms;    /*   the two grouped exchanges: this frame's halo rows (G1); the gather that carried this frame's
+	                                  strips and words (G2; split choreography: 0 when pwn_tiled_wait had to launch it itself) */
 	float enqueue_us;            /* host time inside pwn_tiled_submit for this frame (every frame) */
 	int y0, y1;                  /* the rows this rank traced of this frame (the cuts move: pwn_tiled_balance) */
 	uint32_t cost;               /* what they cost: sum of the trace waves' lifetimes, ticks of the GPU's 100 MHz clock */
