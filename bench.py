@@ -980,7 +980,7 @@ def main():
         r.tiled_balance(bal)
         # ---- legs that set the tiling up again, the ones a first multi-GPU run learns most from first.  (The options are read by
         # pwn_tiled_init and refuse to change while a tiling exists: each leg shuts the last one down, then sets its own.)
-        def again(name, what, comms=False, streams=2, split=False, overlap=True, halo=None, depth=3):
+        def again(name, what, comms=False, streams=2, split=False, overlap=True, halo=None, depth=3, rotate=False):
             barrier()
             r.tiled_shutdown()
             r.set_tiled_comms(comms)
@@ -989,15 +989,21 @@ def main():
             r.set_frame_overlap(overlap)
             ok, _ = bring_up(transport, halo=halo, tag="sweep.%s:" % name)
             if ok:
+                if rotate:
+                    r.tiled_gather_root(True)                        # (gone with the tiling at the next leg's shutdown)
                 tiled_depth[0] = depth
-                point(name, what)
-                tiled_depth[0] = 3
+                try:
+                    point(name, what)
+                finally:
+                    tiled_depth[0] = 3
         if transport == "rccl":
             # a communicator per compute stream: the streams' exchanges do not wait for each other (one communicator runs its
             # launches in the order they were made); then that with three streams and four frames in flight -- on one GPU, a
             # rank exchanging with itself, the fastest form measured
             again("comm_per_stream", "PWN_OPT_TILED_COMMS = per stream: one RCCL communicator per compute stream instead of one for both", comms=True)
             again("three_streams_comm_per_stream", "three compute streams, a communicator each, four frames in flight", comms=True, streams=3, depth=4)
+            again("three_streams_comm_per_stream_rotating_root", "the same with frame f gathered on rank f mod N: no rank's links carry every frame and the "
+                  "streams' exchanges are independent -- the form with the most overlap", comms=True, streams=3, depth=4, rotate=True)
         again("three_streams", "PWN_OPT_TILED_STREAMS = 3: frame f on compute stream f mod 3 (one GPU: a strip-sized frame 8 % faster, a whole 4K frame 8 % slower)", streams=3)
         again("choreo_split", "PWN_OPT_TILED_CHOREO = split (rounds 2-3): the exchanges on a third stream tied to the kernels by events, blur f enqueued by submit f+1 "
                               "and its gather by submit f+2 (the headline: everything of a frame in order on the frame's own stream)", split=True)
