@@ -29,6 +29,8 @@ def free_port():
 def test_bench_with_ranks_on_one_device(world, size, golden):
     env = dict(os.environ)
     env.update(PWN_BENCH_ONE_DEVICE="1", PWN_BENCH_TRANSPORT="shm", MASTER_ADDR="127.0.0.1")
+    if world == 3:
+        env.update(PWN_BENCH_ALL_LEGS="1")          # the sweep legs that only an RCCL run has, so that their lines have run somewhere
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--min-time", "0.2", "--sweep-time", "0.05",
@@ -70,7 +72,9 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     assert d["roofline"]["pixels_per_launch"] in [rows * size[0] for rows in pr["rows"]]
     # the in-run sweep: room left for the transport's kernels, equal strips, one compute stream, whole strips, the other choreography
     sw = t["sweep"]
-    assert set(sw) - {"rank0_tall"} == {"reserve_0", "reserve_16", "reserve_64", "rotating_root", "equal_strips", "one_stream", "whole_strips", "choreo_split", "three_streams", "five_in_flight"}
+    rccl_legs = {"comm_per_stream", "three_streams_comm_per_stream", "three_streams_comm_per_stream_rotating_root"}
+    assert set(sw) - {"rank0_tall"} - rccl_legs == {"reserve_0", "reserve_16", "reserve_64", "rotating_root", "equal_strips", "one_stream", "whole_strips", "choreo_split", "three_streams", "five_in_flight"}
+    assert (set(sw) & rccl_legs) == (rccl_legs if world == 3 else set())
     assert t["choreography"].startswith("in-stream") and all(q["choreography"] == "instream" for q in pf)
     assert ("rank0_tall" in sw) == (world > 2)
     for name, pt in sw.items():
