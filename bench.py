@@ -374,6 +374,8 @@ def main():
     ap.add_argument("--min-time", type=float, default=3.0, help="repeat the K-step block until this many seconds were timed (each of the "
                     "resident and the d2h leg: the GPU is busy for >= 6 s of a default run)")
     ap.add_argument("--sweep-time", type=float, default=0.3, help="N > 1: seconds timed per leg of tiling.sweep (0 = no sweep)")
+    ap.add_argument("--sweep-budget", type=float, default=100.0,
+                    help="N > 1: seconds the sweep legs that set the tiling up again may take together; the legs left over are marked skipped")
     ap.add_argument("--sweep-nonblocking", action="store_true",
                     help="N > 1 over RCCL: one more sweep leg with the communicator driven non-blocking (PWN_TILED_RCCL_MODE=nonblocking)")
     ap.add_argument("--bringup-timeout", type=float, default=300.0,
@@ -980,7 +982,14 @@ def main():
         r.tiled_balance(bal)
         # ---- legs that set the tiling up again, the ones a first multi-GPU run learns most from first.  (The options are read by
         # pwn_tiled_init and refuse to change while a tiling exists: each leg shuts the last one down, then sets its own.)
+        t_sweep = time.perf_counter()
+
         def again(name, what, comms=False, streams=2, split=False, overlap=True, halo=None, depth=3, rotate=False):
+            # every one of these legs makes its communicator(s) anew: together they stay inside --sweep-budget seconds (every rank
+            # takes the same decision: the slowest rank's clock)
+            if max_over_ranks(time.perf_counter() - t_sweep) > args.sweep_budget:
+                sweep[name] = {"skipped": "--sweep-budget %.0f s used up by the legs in front" % args.sweep_budget}
+                return
             barrier()
             r.tiled_shutdown()
             r.set_tiled_comms(comms)

@@ -108,6 +108,24 @@ def test_bench_line_survives_a_leg_that_does_not_finish():
     assert "did not finish" in d["tiling"]["post_note"] and len(d["tiling"]["per_rank"]["trace_ms"]) == 2
 
 
+def test_sweep_legs_that_set_the_tiling_up_again_stay_inside_their_budget():
+    """--sweep-budget: the legs that make their communicators anew are skipped, on every rank alike, once the ones in front have used
+    the budget up -- the line is complete and the run leaves with status 0."""
+    env = dict(os.environ)
+    env.update(PWN_BENCH_ONE_DEVICE="1", PWN_BENCH_TRANSPORT="shm", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--min-time", "0.1", "--sweep-time", "0.05",
+           "--sweep-budget", "0", "--no-d2h", "--time-every", "2", "--width", "1280", "--height", "720"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    sw = d["tiling"]["sweep"]
+    assert "incomplete" not in d and d["value"] > 0 and sw["reserve_16"]["value"] > 0 and sw["five_in_flight"]["value"] > 0
+    for name in ("three_streams", "choreo_split", "one_stream", "whole_strips"):
+        assert "skipped" in sw[name] and "value" not in sw[name], (name, sw[name])
+
+
 @pytest.mark.parametrize("stage", ["preflight", "tiled_init", "first_frames", "headline"])
 def test_a_rank_that_leaves_during_the_bring_up_costs_a_diagnostic_line_not_a_hang(stage):
     """The round-3 review's first item.  Rank 1 of 3 leaves the process at `stage` (PWN_BENCH_DIE_AT).  Whatever the others are
