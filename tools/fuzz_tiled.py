@@ -71,6 +71,8 @@ for run in range(runs):
     env["PWN_TILED_CHOREO"] = "split" if split else "instream"
     depth = int(rng.integers(1, 6))                           # frames in flight, 1 .. PWN_TILED_SLOTS - 1
     env["TILED_DEPTH"] = str(depth)
+    streams = int(rng.integers(2, 4))                         # PWN_OPT_TILED_STREAMS (in-stream only: the split form keeps two)
+    env["PWN_TILED_STREAMS"] = str(streams)
     with tempfile.TemporaryDirectory() as td:
         idfile = os.path.join(td, "id_%d" % run)
         procs = [subprocess.Popen([sys.executable, RANK, str(r), str(world), idfile, "shm", str(w), str(h), level, str(frames), str(halo)],
@@ -109,6 +111,6 @@ for run in range(runs):
         print("MISMATCH run %d: world %d %dx%d %s halo %d sink %d %s: frames %s, other ranks' views %d" % (run, world, w, h, level, halo, hostsink, "split" if split else "in-stream", mism[:8], seen_bad))
     else:
         print("run %d ok: world %d %dx%d %s halo %d sink %d rotating root %d %s, %d frames, %d cuts by hand, the cuts moved %s times, %s frames repeated" % (
-            run, world, w, h, level, halo, hostsink, int(rotate), ("split" if split else "in-stream") + ", %d in flight" % depth, frames, len(cuts_at), info.get("recuts"), info.get("frames_redone")), flush=True)
+            run, world, w, h, level, halo, hostsink, int(rotate), ("split" if split else "in-stream on %d streams" % streams) + ", %d in flight" % depth, frames, len(cuts_at), info.get("recuts"), info.get("frames_redone")), flush=True)
 print("fuzz_tiled: %d runs, %d frames, %d bad runs (seed %d)" % (runs, frames_done, bad, seed))
 sys.exit(1 if bad else 0)
