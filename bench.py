@@ -1010,6 +1010,8 @@ def main():
             # launches in the order they were made); then that with three streams and four frames in flight -- on one GPU, a
             # rank exchanging with itself, the fastest form measured
             again("comm_per_stream", "PWN_OPT_TILED_COMMS = per stream: one RCCL communicator per compute stream instead of one for both", comms=True)
+            again("comm_per_stream_rotating_root", "a communicator per stream and frame f gathered on rank f mod N: successive frames' gathers run in "
+                  "opposite directions over a link and, on communicators of their own, at the same time", comms=True, rotate=True)
             again("three_streams_comm_per_stream", "three compute streams, a communicator each, four frames in flight", comms=True, streams=3, depth=4)
             again("three_streams_comm_per_stream_rotating_root", "the same with frame f gathered on rank f mod N: no rank's links carry every frame and the "
                   "streams' exchanges are independent -- the form with the most overlap", comms=True, streams=3, depth=4, rotate=True)

@@ -72,7 +72,7 @@ def test_bench_with_ranks_on_one_device(world, size, golden):
     assert d["roofline"]["pixels_per_launch"] in [rows * size[0] for rows in pr["rows"]]
     # the in-run sweep: room left for the transport's kernels, equal strips, one compute stream, whole strips, the other choreography
     sw = t["sweep"]
-    rccl_legs = {"comm_per_stream", "three_streams_comm_per_stream", "three_streams_comm_per_stream_rotating_root"}
+    rccl_legs = {"comm_per_stream", "comm_per_stream_rotating_root", "three_streams_comm_per_stream", "three_streams_comm_per_stream_rotating_root"}
     assert set(sw) - {"rank0_tall"} - rccl_legs == {"reserve_0", "reserve_16", "reserve_64", "rotating_root", "equal_strips", "one_stream", "whole_strips", "choreo_split", "three_streams", "five_in_flight"}
     assert (set(sw) & rccl_legs) == (rccl_legs if world == 3 else set())
     assert t["choreography"].startswith("in-stream") and all(q["choreography"] == "instream" for q in pf)
