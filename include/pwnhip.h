@@ -148,6 +148,18 @@ typedef struct pwn_stats
                                   first launch of a geometry uses the arithmetic order; with the strip forms the sort rides behind
                                   pwn_blur_rows_device[_bounded] on the caller's stream.  Any order gives the same pixels.  The reference's
                                   counterpart is OpenMP's static schedule over 32-row chunks (screen.h:63-64). */
+#define PWN_OPT_CALL_STRIPS 13 /* the blocking call, pwn_trace_screen_centred (the one call an unchanged reference loop makes per frame,
+                                  main.c:107): handing a 4K frame to the host over PCIe takes twice as long as its kernels, so the call
+                                  works in row strips -- strip k is traced while strip k - 1 is blurred from the rows traced so far and
+                                  strip k - 2 travels to sbuf / zbuf on the copy stream.  A tap of the blur that lands below the rows
+                                  traced so far (taps reach 0.002*h*|depth-1| rows, screen.h:100-102) is counted; such a frame's blur is
+                                  repeated over the whole frame before the call returns, and the next calls run in one piece for a
+                                  while: the frame delivered is always the exact one.  -1 (default): strips for frames of 3 Mpixels
+                                  and more into registered buffers (pwn_host_register), of 6 Mpixels and more into others, with
+                                  POSTPROC_BLUR 0 or 1, not for counted or wave-logged frames; 0: one launch per pass,
+                                  then the copies (what pwn_stats.trace_ms / blur_ms time as single launches); 2..32: that many
+                                  strips whatever the size.  With strips pwn_stats.trace_ms runs from the first strip's trace to the
+                                  end of the last one's (the blurs between them included), blur_ms is the tail behind it. */
 #define PWN_OPT_FRAME_TIMING 5 /* frames in flight: record HIP events around the trace and blur kernels of every N-th
                                   frame (pwn_frame.timed, .trace_ms ...); 1 = every frame (default), 0 = never.  An event
                                   between two kernels costs a few microseconds of pipeline */
@@ -233,6 +245,22 @@ int pwn_get_objects(pwn_ctx *ctx, pwn_sphere *out, int cap);
  */
 int pwn_trace_screen_centred(pwn_ctx *ctx, const float cam[16], float sec_current,
 	uint32_t *sbuf, float *zbuf);
+/*
+ * The host's frame buffers are malloc'ed once and live as long as the process (main.c:395-400).  Made known to the
+ * device once (hipHostRegister), the copies of the blocking call into them are plain DMA that runs beside the kernels
+ * of the frame's later strips and never holds the calling thread; into memory that is not registered every strip's
+ * copy is staged by the runtime and blocks the caller while it runs (the call then keeps two strips of kernels
+ * enqueued ahead of the copy it waits in).  Same pixels either way.
+ *   pwn_host_register    [base, base + bytes): once, right after the malloc; PWN_EBUSY when PWN_HOST_REGS_MAX (16)
+ *                        ranges are registered, PWN_EHIP when the runtime refuses (the range stays usable, unregistered)
+ *   pwn_host_unregister  before the memory is freed -- a registered range that is freed and handed out again by
+ *                        malloc is still the OLD pages to the device; pwn_destroy unregisters what is left
+ * *_state: out[0] the option, out[1] strips of the last blocking call (1 = it ran in one piece), out[2] blocking calls
+ * that ran in strips, out[3] how many of those had their blur repeated over the whole frame.
+ */
+int pwn_host_register(pwn_ctx *ctx, void *base, size_t bytes);
+int pwn_host_unregister(pwn_ctx *ctx, void *base);
+int pwn_call_strips_state(pwn_ctx *ctx, unsigned long long out[4]);
 
 /*
  * Frames in flight.  The reference presents every frame on the host

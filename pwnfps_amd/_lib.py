@@ -18,6 +18,7 @@ PWN_OPT_UNIT_ORDER = 9
 PWN_OPT_TILED_CHOREO = 10
 PWN_OPT_TILED_STREAMS = 11
 PWN_OPT_TILED_COMMS = 12
+PWN_OPT_CALL_STRIPS = 13
 PWN_TILED_CHOREO_INSTREAM, PWN_TILED_CHOREO_SPLIT = 0, 1
 PWN_SCHED_UNITS, PWN_SCHED_REFILL = 0, 1
 PWN_MAX_SLOTS = 4
@@ -93,6 +94,9 @@ ABI = [
     ("pwn_prepare_render", _i, [_vp]),
     ("pwn_get_objects", _i, [_vp, _vp, _i]),
     ("pwn_trace_screen_centred", _i, [_vp, _vp, _f, _vp, _vp]),
+    ("pwn_host_register", _i, [_vp, _vp, C.c_size_t]),
+    ("pwn_host_unregister", _i, [_vp, _vp]),
+    ("pwn_call_strips_state", _i, [_vp, _vp]),
     ("pwn_frames_config", _i, [_vp, _i, _i, _i, _i]),
     ("pwn_submit_frame", _i, [_vp, _vp, _f, _i]),
     ("pwn_wait_frame", _i, [_vp, _i, C.POINTER(Frame)]),

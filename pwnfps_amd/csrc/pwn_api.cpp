@@ -87,7 +87,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	if(const char *e = getenv("PWN_TRACE_ROOM")) if(*e) c->room.mode = atoi(e) < 0 ? -1 : atoi(e);      // (the option's default for every context of a process)
 	c->d_scratch = NULL; c->scratch_cap = 0;
 	for(int i = 0; i < 8; i++) { c->occ_lds[i] = 0; c->occ_blocks[i] = 0; }
-	c->stream = NULL; c->copy_stream = NULL; c->stream2 = NULL; c->d_pre2 = NULL;
+	c->stream = NULL; c->copy_stream = NULL; c->copy_stream2 = NULL; c->stream2 = NULL; c->d_pre2 = NULL;
 	c->frame_overlap = 1; c->last_frame_done = NULL; c->last_frame_stream = NULL;
 	if(const char *e = getenv("PWN_FRAME_OVERLAP")) c->frame_overlap = atoi(e) != 0;
 	c->unit_order = 0;             // (measured: a loss except on short launches that run alone, profiles/r4/unit_order_ab.txt)
@@ -100,6 +100,10 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	if(const char *e = getenv("PWN_TILED_CHOREO")) c->tiled_choreo = (strcmp(e, "split") == 0 || strcmp(e, "1") == 0) ? PWN_TILED_CHOREO_SPLIT : PWN_TILED_CHOREO_INSTREAM;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));
+	c->call_strips = -1; c->strip_ev_n = 0; c->d_strip_miss = NULL; c->h_strip_miss = NULL; c->strip_backoff = 0;
+	c->strip_calls = c->strip_redone = 0; c->strips_last = 1; c->host_regs_n = 0;
+	memset(c->strip_ev, 0, sizeof(c->strip_ev));
+	if(const char *e = getenv("PWN_CALL_STRIPS")) if(*e) { const int v = atoi(e); if(v >= -1 && v <= PWN_CALL_STRIPS_MAX && v != 1) c->call_strips = v; }
 	c->frame_timing = 1; c->wave_log_on = 0; c->d_wave_log = NULL; c->wave_log_cap = 0;
 	c->nslots = 0; c->frame_flags = 0; c->frame_scale = 1; c->frame_pitch = 0; c->frame_seq = 0;
 	memset(c->slot, 0, sizeof(c->slot));
@@ -196,6 +200,10 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 	(void)hipDeviceSynchronize();        // strip forms run on the caller's streams
 	frames_release(c);
 	for(int i = 0; i < 4; i++) if(c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	for(int i = 0; i < c->strip_ev_n; i++) if(c->strip_ev[i]) (void)hipEventDestroy(c->strip_ev[i]);
+	(void)hipFree(c->d_strip_miss);
+	if(c->h_strip_miss) (void)hipHostFree(c->h_strip_miss);
+	for(int i = 0; i < c->host_regs_n; i++) (void)hipHostUnregister(c->host_regs[i].base);
 	for(int i = 0; i < PWN_NBLOB; i++)
 	{
 		if(c->ev_tables[i]) (void)hipEventDestroy(c->ev_tables[i]);
@@ -209,6 +217,7 @@ extern "C" void pwn_destroy(pwn_ctx *c)
 	}
 	if(c->stream) (void)hipStreamDestroy(c->stream);
 	if(c->stream2) (void)hipStreamDestroy(c->stream2);
+	if(c->copy_stream2) { (void)hipStreamSynchronize(c->copy_stream2); (void)hipStreamDestroy(c->copy_stream2); }
 	if(c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
 	if(c->up_stream) (void)hipStreamDestroy(c->up_stream);
 	(void)hipFree(c->d_pre); (void)hipFree(c->d_out); (void)hipFree(c->d_z); (void)hipFree(c->d_pre2);
@@ -291,6 +300,9 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 			if(c->tiled != NULL) return PWN_EBUSY;
 			c->tiled_streams = value; return PWN_OK;
 		case PWN_OPT_TRACE_ROOM: if(value < -1 || value > 4096) return PWN_EINVAL; memset(&c->room, 0, sizeof(c->room)); c->room.mode = value; return PWN_OK;
+		case PWN_OPT_CALL_STRIPS:
+			if(value < -1 || value == 1 || value > PWN_CALL_STRIPS_MAX) return PWN_EINVAL;
+			c->call_strips = value; c->strip_backoff = 0; return PWN_OK;
 		case PWN_OPT_FRAME_OVERLAP:
 			for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
 			c->frame_overlap = value ? 1 : 0; return PWN_OK;
@@ -961,6 +973,236 @@ extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const vo
 	return rc;
 }
 
+// ---- the blocking call in row strips (PWN_OPT_CALL_STRIPS, include/pwnhip.h) ----
+// One pwn_trace_screen_centred of a 4K frame is 0.32 ms of trace, 0.03 ms of blur and 0.64 ms of PCIe (33 MB at the
+// link's 52 GB/s): one after the other the GPU idles for two thirds of the call.  In strips the copy starts when the
+// first strips are blurred and runs beside the kernels of the rest: the call is the copy plus the first strips.
+// Strips grow from the top -- the first ones small so that the copy starts early, each later one 1.2 times the one before.
+
+static int blur_reach_rows(int h) { return (int)(0.002 * h * 24.0) + 2; }      // taps of depth <= 24 (screen.h:100-102), like the row tiling's halo
+
+static int strip_cuts(const pwn_ctx *c, int want, int *cuts)
+{
+	const int h = c->h;
+	int n = 0;
+	cuts[0] = 0;
+	if(want >= 2)
+	{
+		const int per = ((h + want - 1) / want + 31) & ~31;           // (the blur works in 32-row tiles)
+		while(cuts[n] < h && n < PWN_CALL_STRIPS_MAX) { cuts[n + 1] = cuts[n] + per < h ? cuts[n] + per : h; n++; }
+		cuts[n] = h;
+		return n;
+	}
+	// (measured at 4K, profiles/r5/call_strips.txt: first strip 96 / 128 / 160 / 192 rows x growth 1.2 / 1.4 / 1.6 -- 128 x 1.2, eight
+	// strips, is the fastest; 1.6 costs 10 %: the last chunk's copy starts when everything else is done)
+	double grow = 1.2;
+	int rows = (h / 17 + 31) & ~31;
+	if(const char *e = getenv("PWN_DBG_STRIP_FIRST")) if(atoi(e) >= 8) rows = (atoi(e) + 7) & ~7;        // (experiments)
+	if(const char *e = getenv("PWN_DBG_STRIP_GROW")) if(atof(e) >= 1.0) grow = atof(e);
+	while(cuts[n] < h)
+	{
+		int y = cuts[n] + rows;
+		if(n == PWN_CALL_STRIPS_MAX - 1 || h - y < rows / 2) y = h;     // (a rest of less than half a strip goes with this one)
+		cuts[++n] = y;
+		rows = ((int)((double)rows * grow) + 31) & ~31;
+	}
+	return n;
+}
+
+// registered (pwn_host_register, hipHostRegister) or allocated pinned: a copy into it is DMA that does not hold the caller
+static bool host_is_pinned(const void *p, size_t bytes)
+{
+	if(p == NULL) return true;
+	const void *ends[2] = { p, (const char *)p + bytes - 1 };
+	for(int i = 0; i < 2; i++)
+	{
+		hipPointerAttribute_t a;
+		memset(&a, 0, sizeof(a));
+		if(hipPointerGetAttributes(&a, ends[i]) != hipSuccess) { (void)hipGetLastError(); return false; }
+		if(a.type != hipMemoryTypeHost) return false;
+	}
+	return true;
+}
+
+extern "C" int pwn_host_register(pwn_ctx *c, void *base, size_t bytes)
+{
+	if(c == NULL || base == NULL || bytes == 0) return PWN_EINVAL;
+	for(int i = 0; i < c->host_regs_n; i++) if(c->host_regs[i].base == base) return c->host_regs[i].bytes >= bytes ? PWN_OK : PWN_EINVAL;
+	if(c->host_regs_n >= PWN_HOST_REGS_MAX) return PWN_EBUSY;
+	(void)hipSetDevice(c->device);
+	const hipError_t e = hipHostRegister(base, bytes, hipHostRegisterPortable);
+	if(e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return PWN_OK; }       // (somebody else's registration: theirs to undo)
+	if(e != hipSuccess) { (void)hipGetLastError(); snprintf(c->err, sizeof(c->err), "hipHostRegister(%zu bytes): %s", bytes, hipGetErrorString(e)); return PWN_EHIP; }
+	c->host_regs[c->host_regs_n].base = base; c->host_regs[c->host_regs_n].bytes = bytes; c->host_regs_n++;
+	return PWN_OK;
+}
+
+extern "C" int pwn_host_unregister(pwn_ctx *c, void *base)
+{
+	if(c == NULL || base == NULL) return PWN_EINVAL;
+	for(int i = 0; i < c->host_regs_n; i++)
+		if(c->host_regs[i].base == base)
+		{
+			(void)hipSetDevice(c->device);
+			// (a copy of an earlier call into it is complete: the blocking call returns behind its copies)
+			const hipError_t e = hipHostUnregister(base);
+			c->host_regs[i] = c->host_regs[--c->host_regs_n];
+			if(e != hipSuccess) { (void)hipGetLastError(); snprintf(c->err, sizeof(c->err), "hipHostUnregister: %s", hipGetErrorString(e)); return PWN_EHIP; }
+			return PWN_OK;
+		}
+	return PWN_EINVAL;
+}
+
+extern "C" int pwn_call_strips_state(pwn_ctx *c, unsigned long long out[4])
+{
+	if(c == NULL || out == NULL) return PWN_EINVAL;
+	out[0] = (unsigned long long)(long long)c->call_strips; out[1] = (unsigned long long)c->strips_last; out[2] = c->strip_calls; out[3] = c->strip_redone;
+	return PWN_OK;
+}
+
+static int call_in_strips(pwn_ctx *c, const float cam[16], float sec, uint32_t *sbuf, float *zbuf, const int *cuts, int K)
+{
+	// chunks go to the host on two copy streams in turn: a DMA copy behind another on ONE stream starts ~11 us after that one ended
+	// (five chunks of a 4K frame: 0.05 of 0.77 ms), on two the link is busy throughout
+	if(c->copy_stream2 == NULL && hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->copy_stream2 = NULL; }
+	hipStream_t cs = c->copy_stream, cpy[2] = { c->copy_stream, c->copy_stream2 != NULL ? c->copy_stream2 : c->copy_stream };
+	if(const char *e = getenv("PWN_DBG_STRIP_COPY_STREAMS")) if(atoi(e) == 1) cpy[1] = cpy[0];
+	// Successive strips' trace launches alternate between the context's two compute streams (the pattern the work-queue
+	// counters are made for, include/pwnhip.h): strip k + 1's grid moves onto the CUs as strip k's waves run out of units.
+	// On one stream every launch waits for the tail of the one before it: 8 strips of a 4K frame took 0.61 ms where the
+	// whole frame takes 0.35 (two streams: 0.43).
+	hipStream_t st[2] = { c->stream, (c->frame_overlap && c->stream2 != NULL) ? c->stream2 : c->stream };
+	if(const char *e = getenv("PWN_DBG_STRIP_STREAMS")) if(atoi(e) == 1) st[1] = st[0];
+	const bool two = st[1] != st[0];
+	const size_t W = (size_t)c->w, n = W * (size_t)c->h;
+	const bool blur = c->blur_passes == 1;
+	for(; c->strip_ev_n < 2 * K; c->strip_ev_n++) HIPCHK(c, hipEventCreateWithFlags(&c->strip_ev[c->strip_ev_n], hipEventDisableTiming));
+	if(c->d_strip_miss == NULL)
+	{
+		HIPCHK(c, hipMalloc((void **)&c->d_strip_miss, 64));
+		HIPCHK(c, hipMemset(c->d_strip_miss, 0, 64));
+		HIPCHK(c, hipHostMalloc((void **)&c->h_strip_miss, 64, hipHostMallocDefault));
+		HIPCHK(c, hipDeviceSynchronize());
+	}
+	*c->h_strip_miss = 0u;
+	uint32_t *pre = c->d_pre, *fin = blur ? c->d_out : c->d_pre;
+	// The blur is cut apart from the trace: behind strip k's trace the rows [0, cuts[k + 1]) are there, and every row whose
+	// taps of depth <= 24 stay inside them is blurred and sent -- chunk k = rows [sent, cuts[k + 1] - H), the last one to the end.
+	// So the first bytes leave behind the FIRST strip's trace, not the second's.
+	int H = blur ? blur_reach_rows(c->h) : 0;
+	if(const char *e = getenv("PWN_DBG_STRIP_REACH")) if(*e && blur) H = atoi(e);
+	// A copy into memory the device does not know is staged by the runtime and holds this thread until it is through:
+	// two strips of kernels are then enqueued ahead of every copy, so that the GPU has work while the host waits in it.
+	// (Measured and dropped, profiles/r5/call_strips.txt: the blur storing its pixels into the registered buffer itself, and a
+	// copy kernel per chunk in place of the DMA copy -- stores to host memory that come from the CUs back up into the trace
+	// grids' own stores: the strips' traces of a 4K frame went from 0.43 to 0.9 ms.)
+	const bool pinned = host_is_pinned(sbuf, n * 4) && host_is_pinned(zbuf, n * 4);
+	int ahead = pinned ? 0 : 2;
+	if(const char *e = getenv("PWN_DBG_STRIP_AHEAD")) if(*e) ahead = atoi(e);
+	int room = two ? c->num_cus : 0;        // (workgroups the grids leave free for the other stream's kernels: the blurs find a place at once)
+	if(const char *e = getenv("PWN_DBG_STRIP_ROOM")) if(*e) room = atoi(e);
+	int traced = 0, chunks = 0, copied = 0, rc;
+	int chunk_y[PWN_CALL_STRIPS_MAX + 1];          // chunk j = rows [chunk_y[j], chunk_y[j + 1]), blurred behind the trace of strip chunk_k[j]
+	chunk_y[0] = 0;
+	// PWN_DBG_STRIP_TIMELINE: when every strip's trace, every chunk's blur and copy ended (experiments: timing events between the kernels cost a few us each)
+	static hipEvent_t tl[4 * PWN_CALL_STRIPS_MAX];
+	const bool timeline = getenv("PWN_DBG_STRIP_TIMELINE") != NULL;
+	if(timeline && tl[0] == NULL) for(int i = 0; i < 4 * PWN_CALL_STRIPS_MAX; i++) HIPCHK(c, hipEventCreate(&tl[i]));
+#define STRIPS_FAIL(code) do { (void)hipStreamSynchronize(st[0]); (void)hipStreamSynchronize(st[1]); (void)hipStreamSynchronize(cpy[0]); (void)hipStreamSynchronize(cpy[1]); return (code); } while(0)
+	HIPCHK(c, hipEventRecord(c->ev[0], st[0]));
+	while(traced < K || copied < chunks)
+	{
+		if(traced < K)
+		{
+			const int k = traced;
+			hipStream_t ts = st[k & 1];
+			if(k == 0 && blur) c->trace_clear_word = c->d_strip_miss;      // (cleared by the first strip's launch, in front of every blur)
+			c->trace_tables_event = c->strip_ev[2 * k];                   // recorded right behind the launch; its previous record is a call that returned
+			c->launch_room = room;
+			rc = pwn_i_launch_trace(c, cam, sec, cuts[k], cuts[k + 1], pre, c->d_z, ts);
+			if(rc != PWN_OK) { (void)hipEventRecord(c->strip_ev[2 * k], ts); STRIPS_FAIL(rc); }
+			HIPCHK(c, hipEventRecord(c->strip_ev[2 * k], ts));
+			if(timeline) HIPCHK(c, hipEventRecord(tl[4 * k], ts));
+			traced++;
+			if(traced == K) HIPCHK(c, hipEventRecord(c->ev[1], ts));
+			// the chunk this trace completes, on its stream: behind it and -- one wait between the streams -- behind the newest
+			// trace of the other stream (older ones are in front of those)
+			int to = traced == K ? c->h : ((cuts[traced] - H) & ~31);
+			if(to > chunk_y[chunks] || traced == K)
+			{
+				const int j = chunks, y0 = chunk_y[j];
+				if(to < y0) to = y0;
+				if(blur && to > y0)
+				{
+					if(two && k >= 1) HIPCHK(c, hipStreamWaitEvent(ts, c->strip_ev[2 * (k - 1)], 0));
+					const bool whole = traced == K;
+					rc = pwn_i_launch_blur(c, y0, to, pre, c->d_z, fin, ts, 0, whole ? 0 : cuts[traced], whole ? NULL : c->d_strip_miss, NULL, NULL);
+					if(rc != PWN_OK) STRIPS_FAIL(rc);
+				}
+				else if(!blur && two && k >= 1) HIPCHK(c, hipStreamWaitEvent(ts, c->strip_ev[2 * (k - 1)], 0));      // (the chunk's rows may be the other stream's)
+				HIPCHK(c, hipEventRecord(c->strip_ev[2 * j + 1], ts));
+				if(timeline) HIPCHK(c, hipEventRecord(tl[4 * j + 1], ts));
+				chunk_y[j + 1] = to;
+				chunks++;
+				if(traced == K) HIPCHK(c, hipEventRecord(c->ev[2], ts));
+			}
+		}
+		while(copied < chunks && (traced == K || traced - copied > ahead))
+		{
+			const int j = copied;
+			const size_t off = (size_t)chunk_y[j] * W, cnt = (size_t)(chunk_y[j + 1] - chunk_y[j]) * W * 4;
+			hipStream_t xs = cpy[j & 1];
+			HIPCHK(c, hipStreamWaitEvent(xs, c->strip_ev[2 * j + 1], 0));
+			if(timeline) HIPCHK(c, hipEventRecord(tl[4 * j + 2], xs));
+			if(cnt != 0)
+			{
+				if(zbuf != NULL) HIPCHK(c, hipMemcpyAsync(zbuf + off, c->d_z + off, cnt, hipMemcpyDeviceToHost, xs));
+				HIPCHK(c, hipMemcpyAsync(sbuf + off, fin + off, cnt, hipMemcpyDeviceToHost, xs));
+			}
+			if(timeline) HIPCHK(c, hipEventRecord(tl[4 * j + 3], xs));
+			copied++;
+		}
+	}
+	if(cpy[1] != cpy[0])
+	{
+		// (the first copy stream behind the second's last copy; strip_ev[0] -- strip 0's trace, long over -- is free for it)
+		HIPCHK(c, hipEventRecord(c->strip_ev[0], cpy[1]));
+		HIPCHK(c, hipStreamWaitEvent(cs, c->strip_ev[0], 0));
+	}
+	if(blur && chunks > 0) HIPCHK(c, hipStreamWaitEvent(cs, c->strip_ev[2 * (chunks - 1) + 1], 0));       // (the last chunk's blur)
+	if(blur) HIPCHK(c, hipMemcpyAsync(c->h_strip_miss, c->d_strip_miss, 4, hipMemcpyDeviceToHost, cs));
+	HIPCHK(c, hipEventRecord(c->ev[3], cs));
+	HIPCHK(c, hipEventSynchronize(c->ev[3]));
+	if(timeline)
+	{
+		fprintf(stderr, "strips %d, chunks %d:", K, chunks);
+		for(int k = 0; k < K; k++) { float a = 0; (void)hipEventElapsedTime(&a, c->ev[0], tl[4 * k]); fprintf(stderr, " T%d(%d rows) %.3f", k, cuts[k + 1] - cuts[k], a); }
+		for(int j = 0; j < chunks; j++)
+		{
+			float b = 0, d = 0, e = 0;
+			(void)hipEventElapsedTime(&b, c->ev[0], tl[4 * j + 1]); (void)hipEventElapsedTime(&d, c->ev[0], tl[4 * j + 2]); (void)hipEventElapsedTime(&e, c->ev[0], tl[4 * j + 3]);
+			fprintf(stderr, "\n   chunk %d rows %d: blur end %.3f copy %.3f..%.3f", j, chunk_y[j + 1] - chunk_y[j], b, d, e);
+		}
+		fprintf(stderr, "\n");
+	}
+	c->strip_calls++;
+	if(blur && *c->h_strip_miss != 0u)
+	{
+		// a tap landed below the rows that were traced when its chunk was blurred: the whole pre-blur frame is there now, so
+		// the pass again in one piece, and the frame again to the host (depth is what it was); the next calls in one piece
+		c->strip_redone++;
+		c->strip_backoff = 64;
+		rc = pwn_i_launch_blur(c, 0, c->h, pre, c->d_z, fin, st[0], 0, 0, NULL, NULL, NULL);
+		if(rc != PWN_OK) return rc;
+		HIPCHK(c, hipEventRecord(c->ev[2], st[0]));
+		HIPCHK(c, hipMemcpyAsync(sbuf, fin, n * 4, hipMemcpyDeviceToHost, st[0]));
+		HIPCHK(c, hipEventRecord(c->ev[3], st[0]));
+		HIPCHK(c, hipEventSynchronize(c->ev[3]));
+	}
+#undef STRIPS_FAIL
+	return PWN_OK;
+}
+
 extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float sec, uint32_t *sbuf, float *zbuf)
 {
 	if(c == NULL || cam == NULL || sbuf == NULL) return PWN_EINVAL;
@@ -970,7 +1212,34 @@ extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float s
 	hipStream_t s = c->stream;
 	// behind the frames in flight, whichever compute stream their kernels are on
 	if(c->last_frame_done != NULL && c->last_frame_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->last_frame_done, 0));
+	if(c->last_frame_done != NULL && c->stream2 != NULL && c->last_frame_stream != c->stream2) HIPCHK(c, hipStreamWaitEvent(c->stream2, c->last_frame_done, 0));      // (strips use both)
 	c->last_frame_done = NULL;       // (this call ends with the stream empty)
+	// ---- in row strips, the copies beside the kernels (PWN_OPT_CALL_STRIPS)
+	{
+		int cuts[PWN_CALL_STRIPS_MAX + 1], K = 1;
+		const bool can = c->blur_passes <= 1 && !c->counters_on && !c->wave_log_on && !c->unit_order && c->have_level;
+		if(can && c->call_strips >= 2) K = strip_cuts(c, c->call_strips, cuts);
+		// by frame size (profiles/r5/call_strips.txt): into registered buffers strips pay from 2560 x 1440 on (0.43 against 0.51 ms; 4K
+		// 0.76 against 0.99, 8K 2.66 against 3.93) and not at 1080p (0.32 / 0.31); into pageable ones, where every chunk's copy holds
+		// the caller, from 4K on (0.88 against 1.02 ms; 1440p equal, 1080p 0.44 against 0.33)
+		else if(can && c->call_strips < 0 && c->h >= 256 &&
+		        n >= ((host_is_pinned(sbuf, n * 4) && host_is_pinned(zbuf, n * 4)) ? 3000000u : 6000000u))
+		{
+			if(c->strip_backoff > 0) c->strip_backoff--;
+			else K = strip_cuts(c, 0, cuts);
+		}
+		c->strips_last = K >= 2 ? K : 1;
+		if(K >= 2)
+		{
+			const int rc = call_in_strips(c, cam, sec, sbuf, zbuf, cuts, K);
+			if(rc != PWN_OK) return rc;
+			if(c->blur_passes == 0) { uint32_t *t = c->d_pre; c->d_pre = c->d_out; c->d_out = t; }      // (the final frame stays addressable as d_out)
+			(void)hipEventElapsedTime(&c->stats.trace_ms, c->ev[0], c->ev[1]);
+			(void)hipEventElapsedTime(&c->stats.blur_ms, c->ev[1], c->ev[2]);
+			(void)hipEventElapsedTime(&c->stats.total_ms, c->ev[0], c->ev[3]);
+			return PWN_OK;
+		}
+	}
 	HIPCHK(c, hipEventRecord(c->ev[0], s));
 	// trace into d_pre; with blur on, d_pre plays tsbuf and d_out plays sbuf
 	// (the memcpy of screen.h:75 becomes a pointer swap per pass)

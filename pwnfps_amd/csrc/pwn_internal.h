@@ -51,6 +51,8 @@ extern "C" hipError_t pwn_launch_probe(int op, const uint32_t *in, uint32_t *out
 #define PWN_TILED_STREAMS_DEFAULT 2
 #define PWN_TICKET_SETS 6u  // launch n counts in set n mod 2R and clears set (n + R) mod 2R, R = pwn_ctx.launch_rot streams in rotation, 2 or 3 (pwn_i_launch_trace)
 #define PWN_NSTAGE 4      // pinned staging buffers for those uploads
+#define PWN_CALL_STRIPS_MAX 32   // row strips of one blocking call at most
+#define PWN_HOST_REGS_MAX 16     // host buffers a context keeps registered (pwn_host_register)
 
 // one frame in flight (pwn_submit_frame / pwn_wait_frame)
 struct pwn_slot
@@ -163,7 +165,17 @@ struct pwn_ctx
 	int frame_overlap;               // PWN_OPT_FRAME_OVERLAP
 	hipEvent_t last_frame_done; hipStream_t last_frame_stream;   // "kernels done" of the frame submitted last, and its stream
 	hipStream_t copy_stream;         // frames in flight: D2H of finished frames
+	hipStream_t copy_stream2;        // the blocking call in strips: chunks go out on the two in turn (made on first use)
 	hipEvent_t ev[4];
+	// The blocking call in row strips (PWN_OPT_CALL_STRIPS; pwn_api.cpp, call_in_strips): trace strip k, blur strip k - 1 from the
+	// rows traced so far, strip k - 2 on its way to the caller's buffer -- the copy over PCIe is twice a 4K frame's kernels
+	int call_strips;                 // the option: -1 = by frame size (default), 0 = one launch per pass, n >= 2 = that many strips
+	hipEvent_t strip_ev[2 * PWN_CALL_STRIPS_MAX]; int strip_ev_n;      // behind strip k's trace [2k] and blur [2k + 1]; made on first use
+	uint32_t *d_strip_miss, *h_strip_miss;     // taps of a strip's blur that left the rows traced so far: the device word, its pinned copy
+	int strips_last;                 // strips of the last blocking call (1 = one launch per pass)
+	int strip_backoff;               // blocking calls left before strips are tried again after such a frame
+	unsigned long long strip_calls, strip_redone;      // blocking calls that ran in strips; ... whose blur was repeated over the whole frame
+	struct host_reg { void *base; size_t bytes; } host_regs[PWN_HOST_REGS_MAX]; int host_regs_n;     // pwn_host_register
 	pwn_stats stats;
 
 	// frames in flight

@@ -208,6 +208,23 @@ class Renderer:
                   "pwn_trace_screen_centred")
         return (sbuf, zbuf) if want_z else sbuf
 
+    def set_call_strips(self, n):
+        """PWN_OPT_CALL_STRIPS: -1 = by frame size (default), 0 = one launch per pass, 2..32 = that many row strips"""
+        self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_CALL_STRIPS, int(n)), "pwn_set_option(CALL_STRIPS)")
+
+    def call_strips_state(self):
+        v = (C.c_ulonglong * 4)()
+        self._chk(lib.pwn_call_strips_state(self._ctx, v), "pwn_call_strips_state")
+        opt = int(v[0])
+        return {"option": opt - (1 << 64) if opt >= (1 << 63) else opt, "strips_last": int(v[1]), "calls_in_strips": int(v[2]), "redone": int(v[3])}
+
+    def host_register(self, arr):
+        """pwn_host_register: the host's frame buffer (main.c:395-400), made known to the device once"""
+        self._chk(lib.pwn_host_register(self._ctx, arr.ctypes.data, arr.nbytes), "pwn_host_register")
+
+    def host_unregister(self, arr):
+        self._chk(lib.pwn_host_unregister(self._ctx, arr.ctypes.data), "pwn_host_unregister")
+
     # -- frames in flight (main.c:93-109 with the hand-over to the host overlapped) ----------
     def frames_config(self, nslots, sbuf=True, zbuf=False, surface_scale=0, pitch_bytes=0):
         flags = (_lib.PWN_FRAME_SBUF if sbuf else 0) | (_lib.PWN_FRAME_ZBUF if zbuf else 0) | \

@@ -1,0 +1,198 @@
+"""The blocking call in row strips (PWN_OPT_CALL_STRIPS): pwn_trace_screen_centred -- the one call an unchanged
+reference loop makes per frame, main.c:107 / screen.h:31-124 -- traces strip k while strip k - 1 is blurred from the
+rows traced so far and strip k - 2 travels to the caller's buffers.  Same pixels and depth as one launch per pass,
+whatever the strips: goldens of the compiled reference, the oracle, the stale-depth rule, taps that leave the rows
+traced so far (repeat over the whole frame), pageable and registered host buffers."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLD, level_path, load_spheres
+
+pytestmark = pytest.mark.gpu
+
+
+def _renderer(w, h):
+    import pwnfps_amd
+    return pwnfps_amd.Renderer(w, h)
+
+
+def _case(cases, name):
+    return [c for c in cases if c["name"] == name][0]
+
+
+def _load(r, c):
+    r.level_load(level_path(c["level"]))
+    r.set_objects(load_spheres(c["spheres"]))
+    return np.array(c["cam"], np.float32)
+
+
+def test_default_runs_large_frames_in_strips_and_small_ones_in_one_piece(oracle_lib, cases):
+    c = _case(cases, "level_spawn_3840x2160")
+    r = _renderer(c["w"], c["h"])
+    cam = _load(r, c)
+    post, z = r.trace_screen_centred(cam, c["sec"])
+    st = r.call_strips_state()
+    assert st["option"] == -1 and st["strips_last"] >= 4 and st["calls_in_strips"] == 1 and st["redone"] == 0, st
+    assert oracle_lib.fnv64(post) == c["post"] and oracle_lib.fnv64(z) == c["z"]
+    s = r.stats()
+    assert s["total_ms"] > 0 and s["trace_ms"] > 0
+    # the final frame stays addressable on the device (pwn_screen_upscale(NULL, ...), main.c:108)
+    big = r.screen_upscale(None, 1)
+    assert (big == post).all()
+    # one launch per pass: the same frame
+    r.set_call_strips(0)
+    post0, z0 = r.trace_screen_centred(cam, c["sec"])
+    assert r.call_strips_state()["strips_last"] == 1
+    assert (post0 == post).all() and (z0.view(np.uint32) == z.view(np.uint32)).all()
+    # without the blur, and without depth wanted
+    r.set_call_strips(-1)
+    r.set_blur_passes(0)
+    pre = r.trace_screen_centred(cam, c["sec"], want_z=False)
+    assert r.call_strips_state()["strips_last"] >= 4
+    assert oracle_lib.fnv64(pre) == c["pre"]
+    assert (r.screen_upscale(None, 1) == pre).all()
+    r.close()
+    c = _case(cases, "level_spawn_1280x720")
+    r = _renderer(c["w"], c["h"])
+    cam = _load(r, c)
+    post, z = r.trace_screen_centred(cam, c["sec"])
+    assert r.call_strips_state()["strips_last"] == 1
+    assert oracle_lib.fnv64(post) == c["post"]
+    r.close()
+
+
+@pytest.mark.parametrize("name,strips", [("level_spawn_1280x720", 2), ("level_spawn_1280x720", 7), ("level_pose1_1280x720", 23),
+                                         ("synth64_cam2_1920x1080", 5), ("level_spawn_320x240", 3), ("level_spawn_320x240", 32),
+                                         ("synth64_cam1_480x272", 4)])
+def test_any_number_of_strips_gives_the_golden_frame(oracle_lib, cases, name, strips):
+    c = _case(cases, name)
+    r = _renderer(c["w"], c["h"])
+    cam = _load(r, c)
+    r.set_call_strips(strips)
+    post, z = r.trace_screen_centred(cam, c["sec"])
+    st = r.call_strips_state()
+    assert 2 <= st["strips_last"] <= strips, st
+    assert oracle_lib.fnv64(post) == c["post"], (name, strips, st)
+    assert oracle_lib.fnv64(z) == c["z"], (name, strips)
+    r.close()
+
+
+def test_taps_below_the_rows_traced_so_far_repeat_the_blur(oracle_lib, cases):
+    """synth256: halls of mirrors, depths in the hundreds -- the blur's taps reach far below a chunk; the call notices, repeats the
+    pass over the whole frame and hands over the exact frame"""
+    c = _case(cases, "synth256_cam0_1920x1080")
+    r = _renderer(c["w"], c["h"])
+    cam = _load(r, c)
+    r.set_call_strips(8)
+    post, z = r.trace_screen_centred(cam, c["sec"])
+    st = r.call_strips_state()
+    assert st["strips_last"] >= 2 and st["redone"] == 1, st
+    assert oracle_lib.fnv64(post) == c["post"] and oracle_lib.fnv64(z) == c["z"]
+    r.close()
+
+
+def test_after_a_repeat_the_next_calls_run_in_one_piece():
+    """by frame size (the default): a frame whose blur had to be repeated costs more than one launch per pass, so the calls behind it
+    run in one piece for a while.  Two contexts, the same three frames (this scene's rays run out of steps: depth carries over
+    from frame to frame), one by size into a registered buffer, one with one launch per pass: the same frames."""
+    w, h = 2560, 1440
+    cams = np.load(os.path.join(GOLD, "levels", "synth256_cams.npy"))
+    sph = load_spheres("synth256")
+    out = []
+    for strips in (-1, 0):
+        r = _renderer(w, h)
+        r.level_load(level_path("synth256"))
+        r.set_objects(sph)
+        r.set_call_strips(strips)
+        sb = np.zeros((h, w), np.uint32)
+        zb = np.zeros((h, w), np.float32)
+        r.host_register(sb)
+        r.host_register(zb)
+        frames = []
+        for i, sec in enumerate((0.0, 0.5, 1.0)):
+            r.trace_screen_centred(cams[i % 2], sec, sbuf=sb, zbuf=zb)
+            frames.append((sb.copy(), zb.copy()))
+            st = r.call_strips_state()
+            if strips < 0:
+                assert st["strips_last"] == (8 if i == 0 else 1) or (i == 0 and st["strips_last"] >= 4), (i, st)
+        if strips < 0:
+            assert st["calls_in_strips"] == 1 and st["redone"] == 1, st
+        r.host_unregister(sb)
+        r.host_unregister(zb)
+        r.close()
+        out.append(frames)
+    for (a, za), (b, zb_) in zip(out[0], out[1]):
+        assert (a == b).all() and (za.view(np.uint32) == zb_.view(np.uint32)).all()
+
+
+def test_stale_depth_semantics_through_strips(oracle_lib):
+    """zbuf keeps its previous value where the primary ray exhausts maxsteps (trace.h:677), strip by strip as in one launch"""
+    cams = np.load(os.path.join(GOLD, "levels", "synth256_cams.npy"))
+    sph = load_spheres("synth256")
+    O = oracle_lib.Oracle()
+    O.load_level(level_path("synth256"))
+    O.set_spheres(sph)
+    w, h = 480, 272
+    for blur in (0, 1):
+        r = _renderer(w, h)
+        r.level_load(level_path("synth256"))
+        r.set_objects(sph)
+        r.set_blur_passes(blur)
+        r.set_call_strips(5)
+        _, z1 = r.trace_screen_centred(cams[1], 0.0)
+        a, z2 = r.trace_screen_centred(cams[0], 0.0)
+        assert r.call_strips_state()["calls_in_strips"] == 2
+        sb, zb, st = O.trace_rows(w, h, 0, h, cams[1])
+        sb, zb, st = O.trace_rows(w, h, 0, h, cams[0], sb=sb, zb=zb)
+        assert st.exhausted > 0
+        assert (z2.view(np.uint32) == zb.view(np.uint32)).all()
+        assert (a == (O.blur_rows(0, h, sb, zb) if blur else sb)).all()
+        r.close()
+
+
+def test_registered_and_pageable_host_buffers(oracle_lib, cases):
+    c = _case(cases, "level_spawn_1920x1080")
+    r = _renderer(c["w"], c["h"])
+    cam = _load(r, c)
+    r.set_call_strips(6)
+    sb = np.zeros((c["h"], c["w"]), np.uint32)
+    zb = np.zeros((c["h"], c["w"]), np.float32)
+    r.host_register(sb)
+    r.host_register(zb)
+    r.host_register(sb)                                # (again: the same range, fine)
+    r.trace_screen_centred(cam, c["sec"], sbuf=sb, zbuf=zb)
+    assert oracle_lib.fnv64(sb) == c["post"] and oracle_lib.fnv64(zb) == c["z"]
+    sb[:] = 0
+    r.trace_screen_centred(cam, c["sec"], sbuf=sb, want_z=False)
+    assert oracle_lib.fnv64(sb) == c["post"]
+    r.host_unregister(zb)
+    r.host_unregister(sb)
+    with pytest.raises(Exception):
+        r.host_unregister(sb)
+    sb[:] = 0
+    zb[:] = 0
+    r.trace_screen_centred(cam, c["sec"], sbuf=sb, zbuf=zb)          # pageable again
+    assert oracle_lib.fnv64(sb) == c["post"] and oracle_lib.fnv64(zb) == c["z"]
+    r.close()
+
+
+def test_strips_mixed_with_frames_in_flight(oracle_lib, cases):
+    """the blocking call is ordered behind the frames in flight, in strips too"""
+    c = _case(cases, "level_spawn_1920x1080")
+    r = _renderer(c["w"], c["h"])
+    cam = _load(r, c)
+    r.set_call_strips(4)
+    r.frames_config(3, sbuf=True)
+    for i in range(3):
+        r.submit_frame(cam, c["sec"], i)
+    post, z = r.trace_screen_centred(cam, c["sec"])
+    assert oracle_lib.fnv64(post) == c["post"] and oracle_lib.fnv64(z) == c["z"]
+    for i in range(3):
+        f = r.wait_frame(i)
+        assert oracle_lib.fnv64(f["sbuf"]) == c["post"]
+    r.submit_frame(cam, c["sec"], 0)
+    assert oracle_lib.fnv64(r.wait_frame(0)["sbuf"]) == c["post"]
+    r.frames_config(0)
+    r.close()
