@@ -1060,7 +1060,6 @@ def main():
         def blocking(n=7):
             best = 1e9
             for _ in range(n):
-                r.set_objects(spheres)
                 t1 = time.perf_counter()
                 r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
                 best = min(best, time.perf_counter() - t1)
@@ -1083,7 +1082,7 @@ def main():
                          "strips": cs_state["strips_last"], "strips_pageable": strips_pageable, "blur_repeated": cs_state["redone"],
                          "frame_equals_resident_frame": blocking_same,
                          "pcie_floor_ms": round(4 * w * h / 54e9 * 1e3, 4),
-                         "what": "best of 7 wall times of set_objects + one pwn_trace_screen_centred(cam, sec, sbuf, NULL): one launch per pass and then "
+                         "what": "best of 7 wall times of one pwn_trace_screen_centred(cam, sec, sbuf, NULL): one launch per pass and then "
                                  "the copy (PWN_OPT_CALL_STRIPS 0); in row strips (the default) into a malloc'ed sbuf; in row strips into the same "
                                  "sbuf registered with pwn_host_register"}
     if world == 1 and not args.no_d2h:

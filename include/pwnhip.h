@@ -172,6 +172,39 @@ typedef struct pwn_stats
  */
 int pwn_init(pwn_ctx **out, int device, int width, int height);
 void pwn_destroy(pwn_ctx *ctx);
+/*
+ * The same for several GPUs of ONE process.  The reference's host is one process with one loop (main.c:93-109) whose row
+ * parallelism -- the OpenMP pragmas of screen.h:63-67,77 -- is invisible to it; so is this: the handle is used exactly
+ * like pwn_init's (the level and object calls, pwn_trace_screen_centred, the frames in flight, pwn_screen_upscale,
+ * pwn_get_stats, pwn_host_register), and every frame is row-tiled over the devices behind it -- the choreography of
+ * pwn_tiled_* (strip per device, halo rows to the neighbours, bounded blur with exact repeat, moving cuts), driven by one
+ * library-owned thread per device, the devices' tables filled from the one level and object table of the handle.  No
+ * unique id, no second process, no replicated game state.
+ *   devices[ndev]   HIP ordinals, 1..PWN_TILED_MAX_WORLD of them.  The same ordinal may appear more than once: so many
+ *                   members share that device (tests on a box with one GPU; no use otherwise).  ndev = 1 is pwn_init.
+ *   frames          pwn_trace_screen_centred: every device copies its finished strip (and its depth strip) straight into the
+ *                   caller's sbuf / zbuf over its own PCIe link.  pwn_frames_config with PWN_FRAME_SBUF / _ZBUF: the same
+ *                   into the group's pinned frames, up to PWN_MAX_SLOTS in flight; with flags 0 the finished strips are
+ *                   gathered on devices[0] (pwn_frame.d_sbuf) and nothing goes to the host.  PWN_FRAME_SURFACE: PWN_ENOTSUP
+ *                   (pwn_screen_upscale works on the delivered frame).
+ *   exchange        between devices: RCCL (ncclSend / ncclRecv groups over xGMI, one communicator rank per device, made
+ *                   in-process under the bring-up deadline) when the ordinals are distinct and librccl loads, else -- and
+ *                   with PWN_GROUP_TRANSPORT=local in the environment -- PWN_TRANSPORT_LOCAL: peer-to-peer copies behind
+ *                   events.  pwn_group_info says which.
+ *   errors          a member's error is the call's (pwn_last_error names the member); a member that stops answering ends the
+ *                   call with PWN_ETIMEDOUT after pwn_tiled_set_timeouts' limits, which the handle takes too.
+ * pwn_tiled_* (other than set_timeouts) and the strip forms are refused on such a handle (PWN_ENOTSUP): it runs its own tiling.
+ */
+typedef struct pwn_group_info
+{
+	int members, transport;                  /* PWN_TRANSPORT_RCCL or _LOCAL */
+	int devices[64];                         /* the ordinals as given (PWN_TILED_MAX_WORLD) */
+	int cuts[65];                            /* member m traces rows [cuts[m], cuts[m + 1]) of the next frame */
+	int halo_rows, host_sink;                /* of the tiling in force (0, 0 before the first frame) */
+	uint64_t frames, frames_redone, recuts;  /* delivered; repeated with whole strips; how often the cuts moved */
+} pwn_group_info;
+int pwn_init_multi(pwn_ctx **out, const int *devices, int ndev, int width, int height);
+int pwn_group_info_get(pwn_ctx *ctx, pwn_group_info *out);
 int pwn_set_option(pwn_ctx *ctx, int option, int value);
 /* PWN_OPT_UNIT_ORDER as it stands: out[0] the option, out[1] trace launches so far that handed their units out in a sorted order,
    out[2] sorts launched (one behind every frame whose trace wrote its units' costs), out[3] units the first compute stream's
@@ -407,6 +440,7 @@ int pwn_blur_rows_device_bounded(pwn_ctx *ctx, int y0, int y1, const void *d_pre
 #define PWN_TILED_ID_BYTES 128
 #define PWN_TRANSPORT_RCCL 0
 #define PWN_TRANSPORT_SHM  1
+#define PWN_TRANSPORT_LOCAL 2      /* between the members of a group inside one process (pwn_init_multi): device-to-device copies behind events */
 #define PWN_TILED_HOST     1
 #define PWN_TILED_SLOTS    6       /* frames a host sink holds (at most five in flight and the one being reused) */
 #define PWN_TILED_MAX_WORLD 64

@@ -66,8 +66,13 @@ class TiledInfo(C.Structure):
                 ("init_timeout_ms", C.c_int), ("wait_timeout_ms", C.c_int), ("dead", C.c_int), ("compute_streams", C.c_int), ("choreography", C.c_int), ("communicators", C.c_int)]
 
 
+class GroupInfo(C.Structure):
+    _fields_ = [("members", C.c_int), ("transport", C.c_int), ("devices", C.c_int * 64), ("cuts", C.c_int * 65),
+                ("halo_rows", C.c_int), ("host_sink", C.c_int), ("frames", C.c_uint64), ("frames_redone", C.c_uint64), ("recuts", C.c_uint64)]
+
+
 PWN_TILED_ID_BYTES = 128
-PWN_TRANSPORT_RCCL, PWN_TRANSPORT_SHM = 0, 1
+PWN_TRANSPORT_RCCL, PWN_TRANSPORT_SHM, PWN_TRANSPORT_LOCAL = 0, 1, 2
 PWN_TILED_HOST = 1
 PWN_TILED_SLOTS = 6
 PWN_TILED_MAX_WORLD = 64
@@ -76,6 +81,8 @@ PWN_TILED_MAX_WORLD = 64
 _vp, _i, _f, _d = C.c_void_p, C.c_int, C.c_float, C.c_double
 ABI = [
     ("pwn_init", _i, [C.POINTER(_vp), _i, _i, _i]),
+    ("pwn_init_multi", _i, [C.POINTER(_vp), _vp, _i, _i, _i]),
+    ("pwn_group_info_get", _i, [_vp, C.POINTER(GroupInfo)]),
     ("pwn_destroy", None, [_vp]),
     ("pwn_set_option", _i, [_vp, _i, _i]),
     ("pwn_trace_room_state", _i, [_vp, _vp]),

@@ -49,6 +49,12 @@ static int ensure_scratch(pwn_ctx *c, size_t bytes)
 static void expand_tables(uint16_t *rcp, uint16_t *rsq);
 static void frames_release(pwn_ctx *c);
 
+// pwn_init_multi's handle (pwn_group.cpp): the call goes to the group, or to its member 0 where it is about the one
+// level and object table, or is refused
+#define GRP_HEAD(c) ((c) != NULL && (c)->grp != NULL && (c)->grp_head)
+#define GRP_M0(c) pwn_group_member((c), 0)
+#define GRP_REFUSE(c, what) do { if(GRP_HEAD(c)) { snprintf((c)->err, sizeof((c)->err), "%s is not available on a group's handle", what); return PWN_ENOTSUP; } } while(0)
+
 extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 {
 	if(out == NULL || width <= 0 || height <= 0 || width > 32768 || height > 32768) return PWN_EINVAL;
@@ -107,7 +113,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->frame_timing = 1; c->wave_log_on = 0; c->d_wave_log = NULL; c->wave_log_cap = 0;
 	c->nslots = 0; c->frame_flags = 0; c->frame_scale = 1; c->frame_pitch = 0; c->frame_seq = 0;
 	memset(c->slot, 0, sizeof(c->slot));
-	c->tiled = NULL;
+	c->tiled = NULL; c->grp = NULL; c->grp_head = false; c->hub = NULL;
 	c->err[0] = 0;
 	pwn_level_clear(c->cells, c->pmap, c->spawn);
 	c->bin_off.assign(4097, 0);
@@ -190,6 +196,7 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 
 extern "C" void pwn_destroy(pwn_ctx *c)
 {
+	if(GRP_HEAD(c)) { pwn_group_destroy(c); return; }
 	if(c == NULL) return;
 	(void)hipSetDevice(c->device);
 	if(c->tiled) pwn_tiled_destroy(c);
@@ -264,6 +271,7 @@ void pwn_room_frame_done(pwn_ctx *c)
 
 extern "C" int pwn_trace_room_state(pwn_ctx *c, int out[4])
 {
+	if(GRP_HEAD(c)) return pwn_trace_room_state(GRP_M0(c), out);
 	if(c == NULL || out == NULL) return PWN_EINVAL;
 	out[0] = c->room.mode; out[1] = pwn_room_for_launch(c); out[2] = (int)c->room.looks; out[3] = (int)c->room.switches;
 	return PWN_OK;
@@ -271,6 +279,7 @@ extern "C" int pwn_trace_room_state(pwn_ctx *c, int out[4])
 
 extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 {
+	if(GRP_HEAD(c)) return pwn_group_set_option(c, option, value);
 	if(c == NULL) return PWN_EINVAL;
 	switch(option)
 	{
@@ -429,6 +438,7 @@ static int valid_portals(const pwn_portal *pm)
 
 extern "C" int pwn_upload_level(pwn_ctx *c, const uint8_t data[4096], const pwn_portal pmap[26])
 {
+	if(GRP_HEAD(c)) return (data == NULL || pmap == NULL) ? PWN_EINVAL : pwn_group_upload_level(c, data, pmap);
 	if(c == NULL || data == NULL || pmap == NULL || !valid_portals(pmap)) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	memcpy(c->cells, data, 4096);
@@ -441,6 +451,7 @@ extern "C" int pwn_upload_level(pwn_ctx *c, const uint8_t data[4096], const pwn_
 
 extern "C" int pwn_level_load_mem(pwn_ctx *c, const char *text, int len)
 {
+	if(GRP_HEAD(c)) return (text == NULL || len < 0) ? PWN_EINVAL : pwn_group_level_mem(c, text, len);
 	if(c == NULL || text == NULL || len < 0) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	if(pwn_parse_level(text, len, c->cells, c->pmap, c->spawn) != 0) return PWN_EINVAL;
@@ -463,6 +474,7 @@ extern "C" int pwn_level_load(pwn_ctx *c, const char *path)
 
 extern "C" int pwn_get_level(pwn_ctx *c, uint8_t data[4096], pwn_portal pmap[26], int32_t spawn[2])
 {
+	if(GRP_HEAD(c)) return pwn_get_level(GRP_M0(c), data, pmap, spawn);
 	if(c == NULL) return PWN_EINVAL;
 	if(data) memcpy(data, c->cells, 4096);
 	if(pmap) memcpy(pmap, c->pmap, sizeof(c->pmap));
@@ -477,6 +489,7 @@ static int upload_live(pwn_ctx *c, const pwn_sphere *s, int n);
 
 extern "C" int pwn_upload_spheres(pwn_ctx *c, const pwn_sphere *s, int n)
 {
+	if(GRP_HEAD(c)) return (n < 0 || n > PWN_OBJ_MAX || (n > 0 && s == NULL)) ? PWN_EINVAL : pwn_group_upload_spheres(c, s, n);
 	if(c == NULL || n < 0 || n > PWN_OBJ_MAX || (n > 0 && s == NULL)) return PWN_EINVAL;
 	int rc = upload_live(c, s, n);
 	if(rc == PWN_OK)
@@ -489,6 +502,7 @@ extern "C" int pwn_upload_spheres(pwn_ctx *c, const pwn_sphere *s, int n)
 
 extern "C" int pwn_obj_new(pwn_ctx *c)
 {
+	if(GRP_HEAD(c)) { const int r = pwn_obj_new(GRP_M0(c)); if(r < 0) snprintf(c->err, sizeof(c->err), "%s", GRP_M0(c)->err); return r; }
 	if(c == NULL) return PWN_EINVAL;
 	for(size_t i = 0; i < c->obj_typ.size(); i++)
 		if(c->obj_typ[i] == OBJ_FREE) { c->obj_typ[i] = OBJ_INVAL; return (int)i; }
@@ -516,6 +530,7 @@ static bool obj_ok(pwn_ctx *c, int obj, const char *who)
 extern "C" int pwn_obj_set_sphere(pwn_ctx *c, int obj, double r, double refl, double x, double y, double z,
 	double cb, double cg, double cr)
 {
+	if(GRP_HEAD(c)) { const int q = pwn_obj_set_sphere(GRP_M0(c), obj, r, refl, x, y, z, cb, cg, cr); if(q < 0) snprintf(c->err, sizeof(c->err), "%s", GRP_M0(c)->err); return q; }
 	if(!obj_ok(c, obj, "obj_set")) return PWN_EINVAL;
 	pwn_sphere &s = c->objs[(size_t)obj];
 	s.r = (float)r; s.refl = (float)refl;
@@ -527,6 +542,7 @@ extern "C" int pwn_obj_set_sphere(pwn_ctx *c, int obj, double r, double refl, do
 
 extern "C" int pwn_obj_free(pwn_ctx *c, int obj)
 {
+	if(GRP_HEAD(c)) { const int q = pwn_obj_free(GRP_M0(c), obj); if(q < 0) snprintf(c->err, sizeof(c->err), "%s", GRP_M0(c)->err); return q; }
 	if(!obj_ok(c, obj, "obj_free")) return PWN_EINVAL;
 	c->obj_typ[(size_t)obj] = OBJ_FREE;
 	return PWN_OK;
@@ -534,6 +550,7 @@ extern "C" int pwn_obj_free(pwn_ctx *c, int obj)
 
 extern "C" int pwn_level_get(pwn_ctx *c, int cx, int cz)
 {
+	if(GRP_HEAD(c)) return pwn_level_get(GRP_M0(c), cx, cz);
 	if(c == NULL) return PWN_EINVAL;
 	if(!c->have_level) return PWN_ENOLEVEL;
 	if(cx < 0 || cx >= 64) cx = 0;
@@ -558,6 +575,7 @@ static int live_objects(pwn_ctx *c, std::vector<pwn_sphere> &live)
 
 extern "C" int pwn_prepare_render(pwn_ctx *c)
 {
+	if(GRP_HEAD(c)) return pwn_group_prepare_render(c);
 	if(c == NULL) return PWN_EINVAL;
 	std::vector<pwn_sphere> live;
 	int rc = live_objects(c, live);
@@ -567,6 +585,7 @@ extern "C" int pwn_prepare_render(pwn_ctx *c)
 
 extern "C" int pwn_get_objects(pwn_ctx *c, pwn_sphere *out, int cap)
 {
+	if(GRP_HEAD(c)) { const int q = pwn_get_objects(GRP_M0(c), out, cap); if(q < 0) snprintf(c->err, sizeof(c->err), "%s", GRP_M0(c)->err); return q; }
 	if(c == NULL || cap < 0 || (cap > 0 && out == NULL)) return PWN_EINVAL;
 	std::vector<pwn_sphere> live;
 	int rc = live_objects(c, live);
@@ -574,6 +593,8 @@ extern "C" int pwn_get_objects(pwn_ctx *c, pwn_sphere *out, int cap)
 	for(size_t i = 0; i < live.size() && i < (size_t)cap; i++) out[i] = live[i];
 	return (int)live.size();
 }
+
+int pwn_i_upload_live(pwn_ctx *c, const pwn_sphere *s, int n) { return upload_live(c, s, n); }
 
 static int upload_live(pwn_ctx *c, const pwn_sphere *s, int n)
 {
@@ -602,6 +623,7 @@ static int upload_live(pwn_ctx *c, const pwn_sphere *s, int n)
 
 extern "C" int pwn_get_bins(pwn_ctx *c, uint16_t counts[4096], int32_t *idx, int cap)
 {
+	if(GRP_HEAD(c)) return pwn_get_bins(GRP_M0(c), counts, idx, cap);
 	if(c == NULL || counts == NULL) return PWN_EINVAL;
 	for(int i = 0; i < 4096; i++) counts[i] = (uint16_t)(c->bin_off[i + 1] - c->bin_off[i]);
 	int n = c->bin_off[4096];
@@ -883,6 +905,7 @@ int pwn_i_launch_order(pwn_ctx *c, hipStream_t stream)
 // the sort by itself, host arrays in and out (tests): perm_out has 64 * ceil(units / 64) entries, queue q's at [q * cap, q * cap + its length)
 extern "C" int pwn_unit_order_probe(pwn_ctx *c, const uint16_t *cost, uint32_t units, uint32_t *perm_out)
 {
+	if(GRP_HEAD(c)) return pwn_unit_order_probe(GRP_M0(c), cost, units, perm_out);
 	if(c == NULL || cost == NULL || perm_out == NULL || units == 0u) return PWN_EINVAL;
 	const uint32_t cap = (units + PWN_QUEUES - 1u) / PWN_QUEUES;
 	(void)hipSetDevice(c->device);
@@ -900,6 +923,7 @@ extern "C" int pwn_unit_order_probe(pwn_ctx *c, const uint16_t *cost, uint32_t u
 
 extern "C" int pwn_launch_order_waits(pwn_ctx *c, unsigned long long *out)
 {
+	if(GRP_HEAD(c)) return pwn_launch_order_waits(GRP_M0(c), out);
 	if(c == NULL || out == NULL) return PWN_EINVAL;
 	*out = c->launch_waits;
 	return PWN_OK;
@@ -907,6 +931,7 @@ extern "C" int pwn_launch_order_waits(pwn_ctx *c, unsigned long long *out)
 
 extern "C" int pwn_unit_order_state(pwn_ctx *c, unsigned long long out[4])
 {
+	if(GRP_HEAD(c)) return pwn_unit_order_state(GRP_M0(c), out);
 	if(c == NULL || out == NULL) return PWN_EINVAL;
 	out[0] = (unsigned long long)c->unit_order; out[1] = c->order_used; out[2] = c->order_sorts;
 	out[3] = c->order[0].perm_valid ? c->order[0].perm_units : 0ull;
@@ -946,6 +971,7 @@ int pwn_i_launch_blur(pwn_ctx *c, int y0, int y1, const uint32_t *d_pre, const f
 extern "C" int pwn_trace_rows_device(pwn_ctx *c, const float cam[16], float sec, int y0, int y1,
 	void *d_sbuf, void *d_zbuf, void *stream)
 {
+	GRP_REFUSE(c, "pwn_trace_rows_device");
 	if(c == NULL || cam == NULL || d_sbuf == NULL || d_zbuf == NULL || y0 < 0 || y1 > c->h || y0 > y1) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	return pwn_i_launch_trace(c, cam, sec, y0, y1, (uint32_t *)d_sbuf, (float *)d_zbuf, (hipStream_t)stream);
@@ -953,6 +979,7 @@ extern "C" int pwn_trace_rows_device(pwn_ctx *c, const float cam[16], float sec,
 
 extern "C" int pwn_blur_rows_device(pwn_ctx *c, int y0, int y1, const void *d_pre, const void *d_zbuf, void *d_out, void *stream)
 {
+	GRP_REFUSE(c, "pwn_blur_rows_device");
 	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || y0 < 0 || y1 > c->h || y0 > y1 || d_pre == d_out) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	int rc = pwn_i_launch_blur(c, y0, y1, (const uint32_t *)d_pre, (const float *)d_zbuf, (uint32_t *)d_out, (hipStream_t)stream, 0, 0, NULL, NULL, NULL);
@@ -964,6 +991,7 @@ extern "C" int pwn_blur_rows_device(pwn_ctx *c, int y0, int y1, const void *d_pr
 extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const void *d_pre, const void *d_zbuf, void *d_out,
 	int avail_y0, int avail_y1, void *d_miss, void *stream)
 {
+	GRP_REFUSE(c, "pwn_blur_rows_device_bounded");
 	if(c == NULL || d_pre == NULL || d_zbuf == NULL || d_out == NULL || d_miss == NULL || y0 < 0 || y1 > c->h || y0 > y1 ||
 	   d_pre == d_out || avail_y0 > avail_y1) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
@@ -1026,6 +1054,7 @@ static bool host_is_pinned(const void *p, size_t bytes)
 
 extern "C" int pwn_host_register(pwn_ctx *c, void *base, size_t bytes)
 {
+	if(GRP_HEAD(c)) return (base == NULL || bytes == 0) ? PWN_EINVAL : pwn_group_host_register(c, base, bytes);
 	if(c == NULL || base == NULL || bytes == 0) return PWN_EINVAL;
 	for(int i = 0; i < c->host_regs_n; i++) if(c->host_regs[i].base == base) return c->host_regs[i].bytes >= bytes ? PWN_OK : PWN_EINVAL;
 	if(c->host_regs_n >= PWN_HOST_REGS_MAX) return PWN_EBUSY;
@@ -1039,6 +1068,7 @@ extern "C" int pwn_host_register(pwn_ctx *c, void *base, size_t bytes)
 
 extern "C" int pwn_host_unregister(pwn_ctx *c, void *base)
 {
+	if(GRP_HEAD(c)) return base == NULL ? PWN_EINVAL : pwn_group_host_unregister(c, base);
 	if(c == NULL || base == NULL) return PWN_EINVAL;
 	for(int i = 0; i < c->host_regs_n; i++)
 		if(c->host_regs[i].base == base)
@@ -1055,6 +1085,7 @@ extern "C" int pwn_host_unregister(pwn_ctx *c, void *base)
 
 extern "C" int pwn_call_strips_state(pwn_ctx *c, unsigned long long out[4])
 {
+	if(GRP_HEAD(c)) return pwn_call_strips_state(GRP_M0(c), out);
 	if(c == NULL || out == NULL) return PWN_EINVAL;
 	out[0] = (unsigned long long)(long long)c->call_strips; out[1] = (unsigned long long)c->strips_last; out[2] = c->strip_calls; out[3] = c->strip_redone;
 	return PWN_OK;
@@ -1205,6 +1236,7 @@ static int call_in_strips(pwn_ctx *c, const float cam[16], float sec, uint32_t *
 
 extern "C" int pwn_trace_screen_centred(pwn_ctx *c, const float cam[16], float sec, uint32_t *sbuf, float *zbuf)
 {
+	if(GRP_HEAD(c)) return pwn_group_trace_screen_centred(c, cam, sec, sbuf, zbuf);
 	if(c == NULL || cam == NULL || sbuf == NULL) return PWN_EINVAL;
 	if(c->blur_passes > 0 && (c->w & 3) != 0) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
@@ -1304,6 +1336,7 @@ static void frames_release(pwn_ctx *c)
 
 extern "C" int pwn_frames_config(pwn_ctx *c, int nslots, int flags, int scale, int pitch_bytes)
 {
+	if(GRP_HEAD(c)) return pwn_group_frames_config(c, nslots, flags, scale, pitch_bytes);
 	if(c == NULL || nslots < 0 || nslots > PWN_MAX_SLOTS || (flags & ~(PWN_FRAME_SBUF | PWN_FRAME_ZBUF | PWN_FRAME_SURFACE)) != 0) return PWN_EINVAL;
 	if(flags & PWN_FRAME_SURFACE)
 	{
@@ -1352,6 +1385,7 @@ extern "C" int pwn_frames_config(pwn_ctx *c, int nslots, int flags, int scale, i
 
 extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int slot)
 {
+	if(GRP_HEAD(c)) return pwn_group_submit_frame(c, cam, sec, slot);
 	if(c == NULL || cam == NULL || slot < 0 || slot >= c->nslots) return PWN_EINVAL;
 	if(c->blur_passes > 0 && (c->w & 3) != 0) return PWN_EINVAL;
 	pwn_slot &sl = c->slot[slot];
@@ -1428,6 +1462,7 @@ extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int 
 
 extern "C" int pwn_read_plane(pwn_ctx *c, const void *d_src, void *dst, size_t bytes)
 {
+	if(GRP_HEAD(c)) return pwn_read_plane(GRP_M0(c), d_src, dst, bytes);       // (a frame that stayed on the devices was gathered on member 0's)
 	if(c == NULL || d_src == NULL || dst == NULL) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	HIPCHK(c, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
@@ -1436,6 +1471,7 @@ extern "C" int pwn_read_plane(pwn_ctx *c, const void *d_src, void *dst, size_t b
 
 extern "C" int pwn_frame_ready(pwn_ctx *c, int slot)
 {
+	if(GRP_HEAD(c)) return pwn_group_frame_ready(c, slot);
 	if(c == NULL || slot < 0 || slot >= c->nslots) return PWN_EINVAL;
 	if(!c->slot[slot].in_flight) return 1;
 	(void)hipSetDevice(c->device);
@@ -1448,6 +1484,7 @@ extern "C" int pwn_frame_ready(pwn_ctx *c, int slot)
 
 extern "C" int pwn_wait_frame(pwn_ctx *c, int slot, pwn_frame *out)
 {
+	if(GRP_HEAD(c)) return pwn_group_wait_frame(c, slot, out);
 	if(c == NULL || slot < 0 || slot >= c->nslots) return PWN_EINVAL;
 	pwn_slot &sl = c->slot[slot];
 	if(sl.seq == 0) return PWN_EINVAL;            // nothing was ever submitted here
@@ -1479,6 +1516,7 @@ extern "C" int pwn_wait_frame(pwn_ctx *c, int slot, pwn_frame *out)
 
 extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 {
+	if(GRP_HEAD(c)) return out == NULL ? PWN_EINVAL : pwn_group_get_stats(c, out);
 	if(c == NULL || out == NULL) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	if(c->counters_on)
@@ -1522,6 +1560,7 @@ extern "C" int pwn_get_stats(pwn_ctx *c, pwn_stats *out)
 
 extern "C" int pwn_upscale_device(pwn_ctx *c, const void *d_src, int scale, int pitch_bytes, void *d_dst, void *stream)
 {
+	GRP_REFUSE(c, "pwn_upscale_device");
 	if(c == NULL || d_src == NULL || d_dst == NULL || scale <= 0 || (pitch_bytes & 3) != 0 ||
 	   (long long)pitch_bytes < (long long)c->w * scale * 4) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
@@ -1531,6 +1570,7 @@ extern "C" int pwn_upscale_device(pwn_ctx *c, const void *d_src, int scale, int 
 
 extern "C" int pwn_screen_upscale(pwn_ctx *c, const uint32_t *sbuf, int scale, int pitch_bytes, uint32_t *pixels)
 {
+	if(GRP_HEAD(c)) return pwn_group_screen_upscale(c, sbuf, scale, pitch_bytes, pixels);
 	if(c == NULL || pixels == NULL || scale <= 0 || (pitch_bytes & 3) != 0 ||
 	   (long long)pitch_bytes < (long long)c->w * scale * 4) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
@@ -1561,6 +1601,7 @@ extern "C" int pwn_screen_upscale(pwn_ctx *c, const uint32_t *sbuf, int scale, i
 
 extern "C" int pwn_probe(pwn_ctx *c, int op, const uint32_t *in, uint32_t *out, int n)
 {
+	if(GRP_HEAD(c)) return pwn_probe(GRP_M0(c), op, in, out, n);
 	if(c == NULL || in == NULL || out == NULL || n < 0 || op < 0 || op > PWN_PROBE_COS_OF_PAIR) return PWN_EINVAL;
 	if(n == 0) return PWN_OK;
 	(void)hipSetDevice(c->device);

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <vector>
+#include <atomic>
 
 #include "pwnhip.h"
 #include "tables.h"
@@ -84,6 +85,33 @@ int pwn_room_for_launch(struct pwn_ctx *c);          // workgroups to leave free
 void pwn_room_frame_done(struct pwn_ctx *c);         // a frame of such a sequence was delivered to the host
 
 struct pwn_tiled;        // pwn_tiled.cpp
+struct pwn_group;        // pwn_group.cpp: several contexts of one process behind one handle (pwn_init_multi)
+
+// What the members of a group share besides their handle (pwn_group.cpp makes it, pwn_tiled.cpp uses it): a meeting point for the
+// members' threads with a deadline, a flag that ends every wait when a member has failed, the members themselves (every member
+// reads the others' two words of a frame straight from their pinned memory: one process, no exchange needed for eight bytes),
+// and the mailboxes of the in-process transport (PWN_TRANSPORT_LOCAL).
+#define PWN_HUB_RING 64
+// One box per ordered pair (from -> to).  A message is a rendezvous: the receiver posts where the bytes are to go and an event
+// behind whatever of its own still uses that place; the sender, on ITS stream, waits for that event, copies, and says so with an
+// event the receiver's stream then waits for.  So a send is complete, in the sender's stream order, when the bytes have left --
+// the sender may overwrite its buffer behind it, as with ncclSend.
+struct pwn_hub_post { void *dst; size_t bytes; hipEvent_t ev_free; int device; };
+struct pwn_hub_box
+{
+	std::atomic<unsigned long long> posted, copied, consumed;      // by the receiver; by the sender (<= posted); by the receiver (<= copied)
+	pwn_hub_post post[PWN_HUB_RING];
+	hipEvent_t done[PWN_HUB_RING];
+};
+struct pwn_hub
+{
+	int world;
+	std::atomic<int> failed;                     // a member gave up (an error, a deadline): nobody waits for it any more
+	std::atomic<unsigned> bar_count, bar_gen;
+	struct pwn_ctx *member[PWN_TILED_MAX_WORLD];
+	pwn_hub_box *boxes;                          // world x world, [from * world + to]
+};
+int pwn_hub_meet(pwn_hub *h, int wait_ms);       // every member's thread arrives, or PWN_ETIMEDOUT / PWN_EHIP (failed)
 
 struct pwn_ctx
 {
@@ -183,6 +211,8 @@ struct pwn_ctx
 	pwn_slot slot[PWN_MAX_SLOTS];
 	uint64_t frame_seq;
 
+	pwn_group *grp; bool grp_head;   // pwn_init_multi: the group this context is the handle of (grp_head) or a member of; NULL otherwise
+	pwn_hub *hub;                    // ... and what its members share (NULL outside a group)
 	pwn_tiled *tiled;                // row tiling over RCCL, NULL until pwn_tiled_init
 	int tiled_init_ms, tiled_wait_ms;   // pwn_tiled_set_timeouts (0 = the default: environment, else 120 s / 60 s)
 
@@ -209,3 +239,26 @@ int pwn_i_set_launch_rotation(pwn_ctx *c, int rot);
 int pwn_i_launch_order(pwn_ctx *c, hipStream_t stream);      // behind a frame's last kernel on `stream`: sort that stream's unit costs (no-op when there are none)
 void pwn_tiled_destroy(pwn_ctx *c);
 bool pwn_tiled_busy(pwn_ctx *c);        // frames of the row tiling in flight
+// pwn_tiled.cpp internals used by pwn_group.cpp: a member's frame with the host buffers its strip is delivered into (NULL: the
+// frame stays on the devices and is gathered on member 0), and the switch that makes the tiling deliver to the host
+int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *host_sbuf, float *host_zbuf, int carry_depth);
+int pwn_i_tiled_sink(pwn_ctx *c);
+int pwn_i_upload_live(pwn_ctx *c, const pwn_sphere *s, int n);      // pwn_api.cpp: level_prepare_render's binning + upload of a compact list
+// pwn_group.cpp: the entry points of include/pwnhip.h when the context is a group's handle
+int pwn_group_set_option(pwn_ctx *h, int option, int value);
+int pwn_group_level_mem(pwn_ctx *h, const char *text, int len);
+int pwn_group_upload_level(pwn_ctx *h, const uint8_t *data, const pwn_portal *pmap);
+int pwn_group_upload_spheres(pwn_ctx *h, const pwn_sphere *s, int n);
+int pwn_group_prepare_render(pwn_ctx *h);
+int pwn_group_trace_screen_centred(pwn_ctx *h, const float cam[16], float sec, uint32_t *sbuf, float *zbuf);
+int pwn_group_frames_config(pwn_ctx *h, int nslots, int flags, int scale, int pitch_bytes);
+int pwn_group_submit_frame(pwn_ctx *h, const float cam[16], float sec, int slot);
+int pwn_group_wait_frame(pwn_ctx *h, int slot, pwn_frame *out);
+int pwn_group_frame_ready(pwn_ctx *h, int slot);
+int pwn_group_get_stats(pwn_ctx *h, pwn_stats *out);
+int pwn_group_screen_upscale(pwn_ctx *h, const uint32_t *sbuf, int scale, int pitch_bytes, uint32_t *pixels);
+int pwn_group_host_register(pwn_ctx *h, void *base, size_t bytes);
+int pwn_group_host_unregister(pwn_ctx *h, void *base);
+int pwn_group_set_timeouts(pwn_ctx *h, int init_ms, int wait_ms);
+pwn_ctx *pwn_group_member(pwn_ctx *h, int i);                 // member i (0 = the one that holds the level and the object table)
+void pwn_group_destroy(pwn_ctx *h);

@@ -553,6 +553,137 @@ struct shm_transport : pwn_transport
 	const char *name() const { return "shm"; }
 };
 
+// ---- inside one process (pwn_init_multi: the members of a group, one thread each; PWN_TRANSPORT_LOCAL).  A send is an entry in
+// the mailbox of the ordered pair (pwn_hub_box, pwn_internal.h): the receiver posts the place, the sender copies there on its own
+// stream -- device to device: a peer-to-peer DMA over xGMI between two GPUs, a plain copy on one -- and the receiver's stream
+// waits for the sender's event.  Messages between two ranks are matched in order, like RCCL's.  Nothing here is a kernel, so nothing
+// competes with the persistent trace grids for CUs.  A member that waits for a peer's entry gives up at the deadline
+// (pwn_tiled_set_timeouts) or as soon as the group says that a member has failed.
+struct local_transport : pwn_transport
+{
+	pwn_hub *hub; int rank, world, device; hipStream_t stream;
+	hipEvent_t evs[PWN_HUB_RING]; unsigned ev_next;
+	struct op { bool is_send; const void *src; void *dst; size_t bytes; int peer; };
+	std::vector<op> ops;
+	local_transport() : hub(NULL), rank(0), world(1), device(0), stream(NULL), ev_next(0) { err[0] = 0; for(int i = 0; i < PWN_HUB_RING; i++) evs[i] = NULL; }
+	~local_transport() { (void)hipSetDevice(device); for(int i = 0; i < PWN_HUB_RING; i++) if(evs[i]) (void)hipEventDestroy(evs[i]); }
+	int open(pwn_hub *h, int rank_, int world_, int device_)
+	{
+		hub = h; rank = rank_; world = world_; device = device_;
+		for(int i = 0; i < PWN_HUB_RING; i++) if(hipEventCreateWithFlags(&evs[i], hipEventDisableTiming) != hipSuccess) { snprintf(err, sizeof(err), "hipEventCreate failed"); return PWN_EHIP; }
+		return PWN_OK;
+	}
+	pwn_hub_box *box(int from, int to) { return &hub->boxes[(size_t)from * (size_t)world + (size_t)to]; }
+	int begin(hipStream_t s)
+	{
+		if(dead) { snprintf(err, sizeof(err), "rank %d: the transport is dead (a deadline passed earlier)", rank); return PWN_ETIMEDOUT; }
+		stream = s; ops.clear(); return PWN_OK;
+	}
+	int send(const void *p, size_t n, int peer) { op o = { true, p, NULL, n, peer }; ops.push_back(o); return PWN_OK; }
+	int recv(void *p, size_t n, int peer) { op o = { false, NULL, p, n, peer }; ops.push_back(o); return PWN_OK; }
+	int wait_until(std::atomic<unsigned long long> *word, unsigned long long at_least, const char *what, int peer)
+	{
+		const double t0 = now_ms();
+		for(unsigned long long spins = 0; word->load(std::memory_order_acquire) < at_least; spins++)
+		{
+			if(hub->failed.load(std::memory_order_relaxed)) { dead = true; snprintf(err, sizeof(err), "rank %d of %d: another member of the group has failed", rank, world); return PWN_ETIMEDOUT; }
+			if(spins > 2000)
+			{
+				if(now_ms() - t0 > (double)wait_ms)
+				{
+					dead = true; hub->failed.store(1);
+					snprintf(err, sizeof(err), "rank %d of %d: member %d did not %s within %d ms", rank, world, peer, what, wait_ms);
+					return PWN_ETIMEDOUT;
+				}
+				if(spins > 20000) { struct timespec ts = { 0, 50 * 1000 }; nanosleep(&ts, NULL); }
+			}
+		}
+		return PWN_OK;
+	}
+	int end()
+	{
+		// 1. every receive of the group is posted: the place, and an event behind what this stream has enqueued so far (whatever still
+		//    reads or writes the place is in front of it)
+		hipEvent_t ev_free = NULL;
+		for(size_t i = 0; i < ops.size(); i++)
+		{
+			const op &o = ops[i];
+			if(o.is_send) continue;
+			if(ev_free == NULL)
+			{
+				ev_free = evs[ev_next++ % PWN_HUB_RING];
+				if(hipEventRecord(ev_free, stream) != hipSuccess) { snprintf(err, sizeof(err), "hipEventRecord failed"); return PWN_EHIP; }
+			}
+			pwn_hub_box *b = box(o.peer, rank);
+			const unsigned long long n = b->posted.load(std::memory_order_relaxed);
+			int rc = wait_until(&b->consumed, n + 1 >= PWN_HUB_RING ? n + 1 - PWN_HUB_RING : 0, "get through its earlier messages", o.peer);       // (room in the ring: this rank's own progress)
+			if(rc != PWN_OK) return rc;
+			pwn_hub_post &m = b->post[n % PWN_HUB_RING];
+			m.dst = o.dst; m.bytes = o.bytes; m.ev_free = ev_free; m.device = device;
+			b->posted.store(n + 1, std::memory_order_release);
+		}
+		// 2. every send: wait for the peer's post (it posts before it waits for anything), copy on THIS stream behind the peer's event,
+		//    one event behind the group's copies
+		bool sent = false;
+		size_t first_send = ops.size();
+		for(size_t i = 0; i < ops.size(); i++)
+		{
+			const op &o = ops[i];
+			if(!o.is_send) continue;
+			pwn_hub_box *b = box(rank, o.peer);
+			unsigned long long n = b->copied.load(std::memory_order_relaxed);
+			for(size_t k = 0; k < i; k++) if(ops[k].is_send && ops[k].peer == o.peer) n++;        // (earlier sends of this group to the same peer: published below)
+			int rc = wait_until(&b->posted, n + 1, "post its receive", o.peer);
+			if(rc != PWN_OK) return rc;
+			const pwn_hub_post m = b->post[n % PWN_HUB_RING];
+			if(m.bytes != o.bytes) { snprintf(err, sizeof(err), "rank %d: member %d expects %zu bytes where %zu are sent", rank, o.peer, m.bytes, o.bytes); hub->failed.store(1); return PWN_EINVAL; }
+			hipError_t he = hipStreamWaitEvent(stream, m.ev_free, 0);
+			if(he == hipSuccess && o.bytes)
+				he = m.device == device ? hipMemcpyAsync(m.dst, o.src, o.bytes, hipMemcpyDeviceToDevice, stream)
+				                        : hipMemcpyPeerAsync(m.dst, m.device, o.src, device, o.bytes, stream);
+			if(he != hipSuccess) { snprintf(err, sizeof(err), "rank %d: copy to member %d: %s", rank, o.peer, hipGetErrorString(he)); hub->failed.store(1); return PWN_EHIP; }
+			if(!sent) { sent = true; first_send = i; }
+		}
+		if(sent)
+		{
+			hipEvent_t e = evs[ev_next++ % PWN_HUB_RING];
+			if(hipEventRecord(e, stream) != hipSuccess) { snprintf(err, sizeof(err), "hipEventRecord failed"); return PWN_EHIP; }
+			for(size_t i = first_send; i < ops.size(); i++)
+			{
+				const op &o = ops[i];
+				if(!o.is_send) continue;
+				pwn_hub_box *b = box(rank, o.peer);
+				const unsigned long long n = b->copied.load(std::memory_order_relaxed);
+				b->done[n % PWN_HUB_RING] = e;
+				b->copied.store(n + 1, std::memory_order_release);
+			}
+		}
+		// 3. every receive: this stream behind the sender's event
+		for(size_t i = 0; i < ops.size(); i++)
+		{
+			const op &o = ops[i];
+			if(o.is_send) continue;
+			pwn_hub_box *b = box(o.peer, rank);
+			const unsigned long long n = b->consumed.load(std::memory_order_relaxed);
+			int rc = wait_until(&b->copied, n + 1, "send", o.peer);
+			if(rc != PWN_OK) return rc;
+			const hipEvent_t e = b->done[n % PWN_HUB_RING];
+			const hipError_t he = hipStreamWaitEvent(stream, e, 0);
+			b->consumed.store(n + 1, std::memory_order_release);
+			if(he != hipSuccess) { snprintf(err, sizeof(err), "rank %d: waiting for member %d's copy: %s", rank, o.peer, hipGetErrorString(he)); hub->failed.store(1); return PWN_EHIP; }
+		}
+		return PWN_OK;
+	}
+	int alive()
+	{
+		if(dead) return PWN_ETIMEDOUT;
+		if(hub->failed.load(std::memory_order_relaxed)) { snprintf(err, sizeof(err), "rank %d: another member of the group has failed", rank); return PWN_EHIP; }
+		return PWN_OK;
+	}
+	void abort() { dead = true; hub->failed.store(1); }
+	const char *name() const { return "local"; }
+};
+
 // ---------------------------------------------------------------- state ----
 #define NSLOT 6          // buffer sets: at most five frames in flight and the one being reused
 #define MAXW PWN_TILED_MAX_WORLD
@@ -611,6 +742,13 @@ struct pwn_tiled
 	hipEvent_t gathered_by[NSLOT];      // which of the above marks the slot's gather as done
 	// host sink: NSLOT whole frames in host memory shared by the ranks; this rank's copies on their own stream
 	uint8_t *host_base; void *host_registered;   // the frames; what this context registered with the device (or NULL)
+	bool sink;                          // frames are delivered to the host by every rank (pwn_tiled_host_sink, or a group's own: pwn_i_tiled_sink)
+	// a group (pwn_init_multi): where the slot's frame goes -- the caller's own sbuf / zbuf (main.c:31,33) or the group's pinned
+	// frames -- instead of a place in host_base; and what the members share
+	uint32_t *hdst[NSLOT]; float *hzdst[NSLOT];
+	float *fz[NSLOT];                   // the depth plane of the slot's frame: z[s], or -- a group's blocking call, one frame at a time -- always z[0], so
+	                                    // that a pixel whose primary ray runs out of steps keeps the PREVIOUS call's depth (trace.h:677) as on one device
+	pwn_hub *hub;
 	hipStream_t copy;
 	hipEvent_t ev_h[NSLOT];             // behind the copy of the slot's strip into the host frame
 	bool timed[NSLOT]; bool timed_g2[NSLOT];
@@ -620,6 +758,8 @@ struct pwn_tiled
 	pwn_tiled_info info;
 };
 
+#define GRP_HEAD(c) ((c) != NULL && (c)->grp != NULL && (c)->grp_head)
+#define GRP_REFUSE(c) do { if(GRP_HEAD(c)) { snprintf((c)->err, sizeof((c)->err), "a group's handle runs its own tiling (pwn_init_multi)"); return PWN_ENOTSUP; } } while(0)
 #define TPCHK(c, call) do { int rc_ = (call); if(rc_ != PWN_OK) { snprintf((c)->err, sizeof((c)->err), "%s transport: %s", \
 	(c)->tiled->tp->name(), (c)->tiled->tp->err); return rc_; } } while(0)
 
@@ -633,6 +773,7 @@ static bool rccl_mode_nonblocking(void)
 
 extern "C" int pwn_tiled_set_timeouts(pwn_ctx *c, int init_ms, int wait_ms)
 {
+	if(GRP_HEAD(c)) return pwn_group_set_timeouts(c, init_ms, wait_ms);
 	if(c == NULL) return PWN_EINVAL;
 	if(init_ms != 0) c->tiled_init_ms = init_ms > 0 ? init_ms : 0;
 	if(wait_ms != 0) c->tiled_wait_ms = wait_ms > 0 ? wait_ms : 0;
@@ -647,6 +788,7 @@ extern "C" int pwn_tiled_set_timeouts(pwn_ctx *c, int init_ms, int wait_ms)
 // What a first multi-GPU run wants on record before it starts (pwnhip.h).  No tiling needed.
 extern "C" int pwn_tiled_preflight(pwn_ctx *c, char *json, size_t n)
 {
+	if(GRP_HEAD(c)) return pwn_tiled_preflight(pwn_group_member(c, 0), json, n);
 	if(c == NULL || json == NULL || n < 2) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	int count = 0;
@@ -807,12 +949,13 @@ void pwn_tiled_destroy(pwn_ctx *c)
 	(void)pwn_i_set_launch_rotation(c, 2);
 }
 
-extern "C" void pwn_tiled_shutdown(pwn_ctx *c) { if(c != NULL) pwn_tiled_destroy(c); }
+extern "C" void pwn_tiled_shutdown(pwn_ctx *c) { if(c != NULL && !GRP_HEAD(c)) pwn_tiled_destroy(c); }
 
 bool pwn_tiled_busy(pwn_ctx *c) { return c->tiled != NULL && c->tiled->submitted != c->tiled->delivered; }
 
 extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, int transport, int halo_rows)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || id == NULL || world < 1 || world > MAXW || rank < 0 || rank >= world) return PWN_EINVAL;
 	if(c->tiled != NULL) return PWN_EBUSY;
 	for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
@@ -886,7 +1029,19 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 			rc = st->open_region(name, rank, world, strip_bytes);
 			if(rc != PWN_OK) { snprintf(c->err, sizeof(c->err), "%s", st->err); break; }
 		}
+		else if(transport == PWN_TRANSPORT_LOCAL)
+		{
+			// (the id is the group's: only members of a group have a hub)
+			if(c->hub == NULL || c->hub->world != world) { snprintf(c->err, sizeof(c->err), "PWN_TRANSPORT_LOCAL is the transport of a group's members (pwn_init_multi)"); rc = PWN_EINVAL; break; }
+			local_transport *lt = new(std::nothrow) local_transport();
+			if(lt == NULL) { rc = PWN_ENOMEM; break; }
+			t->tp = lt;
+			lt->wait_ms = wait_timeout_ms(c);
+			rc = lt->open(c->hub, rank, world, c->device);
+			if(rc != PWN_OK) { snprintf(c->err, sizeof(c->err), "%s", lt->err); break; }
+		}
 		else { rc = PWN_EINVAL; break; }
+		t->hub = c->hub;
 
 		// the exchange on a hardware queue of its own (queues are pooled per priority level: pwn_init on stream2) -- on a
 		// queue shared with a compute stream the transport's kernels would wait behind that stream's trace launches
@@ -1012,6 +1167,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 
 extern "C" int pwn_tiled_balance(pwn_ctx *c, int every_frames)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || c->tiled == NULL || every_frames < 0) return PWN_EINVAL;
 	c->tiled->balance_every = every_frames;
 	return PWN_OK;
@@ -1019,6 +1175,7 @@ extern "C" int pwn_tiled_balance(pwn_ctx *c, int every_frames)
 
 extern "C" int pwn_tiled_set_reserve(pwn_ctx *c, int workgroups)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || c->tiled == NULL || workgroups < 0 || workgroups > 512) return PWN_EINVAL;
 	c->grid_reserve = workgroups;
 	c->tiled->info.grid_reserve = workgroups;
@@ -1027,10 +1184,11 @@ extern "C" int pwn_tiled_set_reserve(pwn_ctx *c, int workgroups)
 
 extern "C" int pwn_tiled_gather_root(pwn_ctx *c, int mode)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || c->tiled == NULL || (mode != PWN_TILED_ROOT_FIXED && mode != PWN_TILED_ROOT_ROTATE)) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
 	if(t->submitted != t->delivered) return PWN_EBUSY;
-	if(mode == PWN_TILED_ROOT_ROTATE && t->host_base == NULL)
+	if(mode == PWN_TILED_ROOT_ROTATE && !t->sink)
 	{
 		// every rank is the root of some frames: the buffers a root assembles frames in
 		(void)hipSetDevice(c->device);
@@ -1049,6 +1207,7 @@ extern "C" int pwn_tiled_gather_root(pwn_ctx *c, int mode)
 
 extern "C" int pwn_tiled_set_cuts(pwn_ctx *c, const int *cuts, int n)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || c->tiled == NULL || cuts == NULL) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
 	if(n != t->world + 1) return PWN_EINVAL;
@@ -1066,6 +1225,7 @@ extern "C" int pwn_tiled_set_cuts(pwn_ctx *c, const int *cuts, int n)
 
 extern "C" int pwn_tiled_get_cuts(pwn_ctx *c, int *cuts, uint32_t *cost)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || c->tiled == NULL || cuts == NULL) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
 	memcpy(cuts, t->cuts, sizeof(int) * (size_t)(t->world + 1));
@@ -1075,6 +1235,7 @@ extern "C" int pwn_tiled_get_cuts(pwn_ctx *c, int *cuts, uint32_t *cost)
 
 extern "C" int pwn_tiled_host_sink(pwn_ctx *c, void *base, size_t bytes)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || c->tiled == NULL || base == NULL) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
 	if(t->submitted != 0 || t->host_base != NULL) return PWN_EBUSY;
@@ -1090,12 +1251,29 @@ extern "C" int pwn_tiled_host_sink(pwn_ctx *c, void *base, size_t bytes)
 	if(hipStreamCreateWithFlags(&t->copy, hipStreamNonBlocking) != hipSuccess) return PWN_EHIP;
 	for(int s = 0; s < NSLOT; s++) if(hipEventCreateWithFlags(&t->ev_h[s], hipEventDisableTiming) != hipSuccess) return PWN_EHIP;
 	t->host_base = (uint8_t *)base;
+	t->sink = true;
+	t->info.host_sink = 1;
+	return PWN_OK;
+}
+
+// A group's tiling delivers to the host too, into the buffers handed over with every frame (pwn_i_tiled_submit): every
+// member copies its strip there over its own PCIe link.  Before the first frame.
+int pwn_i_tiled_sink(pwn_ctx *c)
+{
+	if(c == NULL || c->tiled == NULL) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	if(t->submitted != 0 || t->sink) return PWN_EBUSY;
+	(void)hipSetDevice(c->device);
+	if(hipStreamCreateWithFlags(&t->copy, hipStreamNonBlocking) != hipSuccess) return PWN_EHIP;
+	for(int s = 0; s < NSLOT; s++) if(hipEventCreateWithFlags(&t->ev_h[s], hipEventDisableTiming) != hipSuccess) return PWN_EHIP;
+	t->sink = true;
 	t->info.host_sink = 1;
 	return PWN_OK;
 }
 
 extern "C" int pwn_tiled_get_info(pwn_ctx *c, pwn_tiled_info *out)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || out == NULL || c->tiled == NULL) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
 	t->info.halo_rows = t->halo;
@@ -1112,6 +1290,8 @@ static inline void rows_of(const pwn_tiled *t, int s, int r, int *a, int *b) { *
 // the two words of every rank to every rank
 static int add_words(pwn_ctx *c, pwn_tiled *t, int s)
 {
+	// (a group's members read each other's words from pinned memory when they meet in pwn_tiled_wait)
+	if(t->hub != NULL) return PWN_OK;
 	for(int r = 0; r < t->world; r++)
 	{
 		if(r == t->rank) continue;
@@ -1129,7 +1309,7 @@ static int add_gather(pwn_ctx *c, pwn_tiled *t, unsigned long long g)
 	uint32_t *mine = c->blur_passes ? t->out[s] : t->pre[s];
 	int y0, y1; rows_of(t, s, t->rank, &y0, &y1);
 	// host sink: no strips; the words go out behind this rank's copy to the host
-	if(t->host_base != NULL) return add_words(c, t, s);
+	if(t->sink) return add_words(c, t, s);
 	const int root = t->froot[s];
 	if(t->rank == root)
 	{
@@ -1197,7 +1377,13 @@ static int copy_strip_to_host(pwn_ctx *c, pwn_tiled *t, int s)
 	const size_t w4 = (size_t)c->w * 4, frame = w4 * (size_t)c->h;
 	const uint32_t *src = c->blur_passes ? t->out[s] : t->pre[s];
 	HIPCHK(c, hipStreamWaitEvent(t->copy, t->ev_b[s], 0));
-	HIPCHK(c, hipMemcpyAsync(t->host_base + (size_t)s * frame + (size_t)y0 * w4, src + (size_t)y0 * c->w,
+	uint8_t *frame_at = t->hdst[s] != NULL ? (uint8_t *)t->hdst[s] : t->host_base + (size_t)s * frame;
+	if(t->hzdst[s] != NULL)          // (zbuf, main.c:33: the depth strip as the trace left it)
+	{
+		HIPCHK(c, hipMemcpyAsync(t->hzdst[s] + (size_t)y0 * c->w, t->fz[s] + (size_t)y0 * c->w, (size_t)(y1 - y0) * w4, hipMemcpyDeviceToHost, t->copy));
+		t->info.bytes_to_host += (unsigned long long)(y1 - y0) * w4;
+	}
+	HIPCHK(c, hipMemcpyAsync(frame_at + (size_t)y0 * w4, src + (size_t)y0 * c->w,
 		(size_t)(y1 - y0) * w4, hipMemcpyDeviceToHost, t->copy));
 	HIPCHK(c, hipEventRecord(t->ev_h[s], t->copy));
 	t->info.bytes_to_host += (unsigned long long)(y1 - y0) * w4;
@@ -1214,7 +1400,7 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 	{
 		if(!t->instream) HIPCHK(c, hipStreamWaitEvent(cs, t->ev_x[s], 0));          // (in-stream: the halo rows came in front of this on cs)
 		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k2[s], cs));
-		uint32_t *dst = (t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->out[s];
+		uint32_t *dst = (t->rank == t->froot[s] && !t->sink) ? t->fin[s] : t->out[s];
 		// the trace of this frame, in front of this launch on the stream, added up what the strip cost: the blur
 		// moves that into the frame's second word and clears the accumulator for the stream's next trace
 		uint32_t *acc = t->cost_acc + 16 * s;
@@ -1224,20 +1410,20 @@ static int enqueue_blur(pwn_ctx *c, pwn_tiled *t, unsigned long long k)
 		{
 			const int H = t->fhalo[s];
 			const int a0 = t->rank > 0 ? y0 - H : 0, a1 = (t->rank < t->world - 1 && y1 < c->h) ? y1 + H : c->h;
-			rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->z[s], dst, cs, a0, a1, t->missw[s], acc, t->missw[s] + 1);
+			rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->fz[s], dst, cs, a0, a1, t->missw[s], acc, t->missw[s] + 1);
 		}
-		else rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL, acc, t->missw[s] + 1);
+		else rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->fz[s], dst, cs, 0, 0, NULL, acc, t->missw[s] + 1);
 		if(rc != PWN_OK) return rc;
 		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k3[s], cs));
 	}
-	if(!t->instream || t->host_base != NULL) HIPCHK(c, hipEventRecord(t->ev_b[s], cs));       // (in-stream: what follows the blur follows it on cs; only the copy to the host waits for it)
+	if(!t->instream || t->sink) HIPCHK(c, hipEventRecord(t->ev_b[s], cs));       // (in-stream: what follows the blur follows it on cs; only the copy to the host waits for it)
 	// PWN_OPT_UNIT_ORDER: the strip's unit costs (written by the frame's trace, in front of this on the stream) sorted into
 	// the order of the stream's next trace of the same rows; behind ev_b, which is what the exchange waits for
 	{
 		const int rc = pwn_i_launch_order(c, cs);
 		if(rc != PWN_OK) return rc;
 	}
-	if(t->host_base != NULL) return copy_strip_to_host(c, t, s);
+	if(t->sink) return copy_strip_to_host(c, t, s);
 	return PWN_OK;
 }
 
@@ -1251,14 +1437,14 @@ static int gather_frames(pwn_ctx *c, pwn_tiled *t, unsigned long long from, unsi
 	for(unsigned long long g = from; g < to; g++)
 	{
 		const int s = (int)(g % NSLOT);
-		if(t->host_base != NULL)
+		if(t->sink)
 		{
 			if(gs != t->copy) HIPCHK(c, hipStreamWaitEvent(gs, t->ev_h[s], 0));       // the word goes out behind the copy (which is behind the blur)
 		}
 		else if(gs != t->fstream[s]) HIPCHK(c, hipStreamWaitEvent(gs, t->ev_b[s], 0));
 	}
 	if(t->timed[ls]) HIPCHK(c, hipEventRecord(t->ev_g0[ls], gs));
-	if(t->world > 1 || t->self_exchange)
+	if((t->world > 1 && !(t->hub != NULL && t->sink)) || t->self_exchange)          // (a group's sink: no strips travel, and no words)
 	{
 		TPCHK(c, t->tp->begin(gs));
 		for(unsigned long long g = from; g < to; g++) { rc = t->self_exchange ? add_self_gather(c, t, g) : add_gather(c, t, g); if(rc != PWN_OK) return rc; }
@@ -1325,10 +1511,14 @@ static double now_us(void)
 	return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
 }
 
-extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
+extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec) { return pwn_i_tiled_submit(c, cam, sec, NULL, NULL, 0); }
+
+int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *host_sbuf, float *host_zbuf, int carry_depth)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || cam == NULL || c->tiled == NULL) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
+	if(t->sink && host_sbuf == NULL && t->host_base == NULL) return PWN_EINVAL;
 	if(t->submitted - t->delivered >= NSLOT - 1) return PWN_EBUSY;
 	if(t->tp->dead) { snprintf(c->err, sizeof(c->err), "%s transport: dead (%s)", t->tp->name(), t->tp->err); return PWN_ETIMEDOUT; }
 	(void)hipSetDevice(c->device);
@@ -1342,6 +1532,8 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	const bool counted = c->counters_on || c->wave_log_on;
 	hipStream_t cs = counted ? t->cs[0] : t->cs[f % (unsigned long long)t->ncs];
 	t->fstream[s] = cs;
+	t->hdst[s] = host_sbuf; t->hzdst[s] = host_zbuf;
+	t->fz[s] = (carry_depth && t->submitted == t->delivered) ? t->z[0] : t->z[s];        // (carried only with nothing else in flight)
 	// (a counted frame right behind uncounted ones on the OTHER streams: wait for those frames' traces, so that the
 	// counters and the wave log are this launch's alone)
 	for(int back = 1; counted && back < t->ncs && (unsigned long long)back <= f; back++)
@@ -1353,7 +1545,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	// The slot's buffers were frame f-NSLOT's.  Its blur ran on this stream (NSLOT is even); its strips left in
 	// G(f-NSLOT) and in the group that carried its gather, and the frame was delivered (NSLOT-1 in flight at most), which
 	// waited for that group on the host: nothing to wait for here.
-	uint32_t *plane = c->blur_passes ? t->pre[s] : ((t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->pre[s]);
+	uint32_t *plane = c->blur_passes ? t->pre[s] : ((t->rank == t->froot[s] && !t->sink) ? t->fin[s] : t->pre[s]);
 	t->timed[s] = c->frame_timing > 0 && (f % (unsigned long long)c->frame_timing) == 0;
 	t->timed_g2[s] = false;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k0[s], cs));
@@ -1361,7 +1553,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 	c->trace_cost_word = c->blur_passes ? t->cost_acc + 16 * s : NULL;      // (the blur moves it on: enqueue_blur)
 	c->trace_tables_event = t->ev_t[s];          // ... and ev_t, recorded right behind it, also tells when its tables are free again
 	c->launch_room = t->ncs > 1 ? pwn_room_for_launch(c) : 0;          // PWN_OPT_TRACE_ROOM
-	int rc = pwn_i_launch_trace(c, cam, sec, y0, y1, plane, t->z[s], cs);
+	int rc = pwn_i_launch_trace(c, cam, sec, y0, y1, plane, t->fz[s], cs);
 	if(rc != PWN_OK) { (void)hipEventRecord(t->ev_t[s], cs); return rc; }
 	t->fcost_mul[s] = c->cost_mul; t->fcost_div[s] = c->cost_div;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
@@ -1377,7 +1569,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 		// Host sink: the words of a frame go out behind this rank's copy of its strip to the host, on the copy's stream (the
 		// compute stream does not wait for PCIe) -- and one submit late, IN FRONT of this frame's copy: the transport runs
 		// its launches in the order they were made, so G1(f+1) would otherwise wait for G2(f) and with it for copy f.
-		if(t->host_base != NULL && t->gathered < f)
+		if(t->sink && t->gathered < f)
 		{
 			rc = gather_frames(c, t, t->gathered, f, t->copy);
 			if(rc != PWN_OK) return rc;
@@ -1385,7 +1577,7 @@ extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec)
 		rc = enqueue_blur(c, t, f);
 		if(rc != PWN_OK) return rc;
 		t->blurred = f + 1;
-		if(t->host_base == NULL)
+		if(!t->sink)
 		{
 			rc = gather_frames(c, t, f, f + 1, cs);
 			if(rc != PWN_OK) return rc;
@@ -1472,6 +1664,7 @@ static int wait_event(pwn_ctx *c, pwn_tiled *t, hipEvent_t ev, const char *what,
 
 extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 {
+	GRP_REFUSE(c);
 	if(c == NULL || c->tiled == NULL) return PWN_EINVAL;
 	pwn_tiled *t = c->tiled;
 	if(t->delivered >= t->submitted) return PWN_EINVAL;          // nothing in flight
@@ -1490,18 +1683,30 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	if(t->gathered <= d)
 	{
 		// (in-stream, which leaves only a host sink's words for later: behind the copies, on their stream)
-		rc = gather_frames(c, t, t->gathered, d + 1, t->instream ? (t->host_base != NULL ? t->copy : t->fstream[s]) : t->comm);
+		rc = gather_frames(c, t, t->gathered, d + 1, t->instream ? (t->sink ? t->copy : t->fstream[s]) : t->comm);
 		if(rc != PWN_OK) return rc;
 	}
 	rc = wait_event(c, t, t->gathered_by[s], "the group that carries its strips and words", d);
 	if(rc != PWN_OK) return rc;
-	if(!t->instream || t->host_base != NULL)         // (in-stream the gather's event is behind the blur on the frame's stream)
+	if(!t->instream || t->sink)         // (in-stream the gather's event is behind the blur on the frame's stream)
 	{
 		rc = wait_event(c, t, t->ev_b[s], "its blur (behind the halo rows of its neighbours)", d);               // (world 1, and rank 0's own strip)
 		if(rc != PWN_OK) return rc;
 	}
-	if(t->host_base != NULL) { rc = wait_event(c, t, t->ev_h[s], "the copy of its strip into the host frame", d); if(rc != PWN_OK) return rc; }      // this rank's own strip is in the host frame
+	if(t->sink) { rc = wait_event(c, t, t->ev_h[s], "the copy of its strip into the host frame", d); if(rc != PWN_OK) return rc; }      // this rank's own strip is in the host frame
 
+	// ---- a group's members meet here: every member's kernels and copies of this frame are through, its two words are in ITS pinned
+	// memory (fetch_words), and everybody reads everybody's from there
+	if(t->hub != NULL)
+	{
+		rc = pwn_hub_meet(t->hub, t->tp->wait_ms);
+		if(rc != PWN_OK)
+		{
+			t->tp->abort();
+			snprintf(c->err, sizeof(c->err), "rank %d of %d: frame %llu: the group's members did not all arrive with it within %d ms (or one of them failed)", t->rank, t->world, d, t->tp->wait_ms);
+			return rc;
+		}
+	}
 	// ---- the ranks' words of this frame (they came to pinned memory behind the group that carried them: fetch_words)
 	const uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1) * 2;
 	uint32_t cost[MAXW];
@@ -1509,6 +1714,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	for(int r = 0; r < t->world; r++)
 	{
 		const uint32_t *wr = r == t->rank ? h + 2 * t->world : h + 2 * r;
+		if(t->hub != NULL && r != t->rank) wr = t->hub->member[r]->tiled->h_missv + ((size_t)s * ((size_t)t->world + 1) + (size_t)t->world) * 2;
 		if(t->fhalo[s] && wr[0] != 0u) miss = true;           // was the bounded halo enough for this frame, on every rank?
 		cost[r] = wr[1];
 	}
@@ -1530,14 +1736,14 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		TPCHK(c, t->tp->end());
 		HIPCHK(c, hipEventRecord(t->ev_d[s], xs));
 		HIPCHK(c, hipStreamWaitEvent(cs, t->ev_d[s], 0));
-		uint32_t *dst = (t->rank == t->froot[s] && t->host_base == NULL) ? t->fin[s] : t->out[s];
+		uint32_t *dst = (t->rank == t->froot[s] && !t->sink) ? t->fin[s] : t->out[s];
 		// (this stream's cost accumulator may hold the trace of frame d+2 by now: it is left alone, the frame's
 		// cost word was moved by its first blur)
-		rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->z[s], dst, cs, 0, 0, NULL, NULL, NULL);
+		rc = pwn_i_launch_blur(c, y0, y1, t->pre[s], t->fz[s], dst, cs, 0, 0, NULL, NULL, NULL);
 		if(rc != PWN_OK) return rc;
 		HIPCHK(c, hipEventRecord(t->ev_b[s], cs));
 		HIPCHK(c, hipStreamWaitEvent(xs, t->ev_b[s], 0));
-		if(t->host_base != NULL)
+		if(t->sink)
 		{
 			rc = copy_strip_to_host(c, t, s);                     // the strip again, and the words behind it
 			if(rc != PWN_OK) return rc;
@@ -1554,7 +1760,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		rc = wait_event(c, t, t->ev_d[s], "its repeat with whole strips", d);
 		if(rc != PWN_OK) return rc;
 		HIPCHK(c, hipStreamSynchronize(cs));
-		if(t->host_base != NULL) HIPCHK(c, hipStreamSynchronize(t->copy));
+		if(t->sink) HIPCHK(c, hipStreamSynchronize(t->copy));
 	}
 	// ---- moving cuts: every balance_every delivered frames, new cuts from what this frame's strips cost.  Every
 	// rank has the same words and the same cuts of this frame, so every rank computes the same new cuts, and they
@@ -1590,7 +1796,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 		out->timed = t->timed[s] ? 1 : 0;
 		out->y0 = t->fcuts[s][t->rank]; out->y1 = t->fcuts[s][t->rank + 1];
 		out->cost = cost[t->rank];
-		out->root = t->host_base != NULL ? -1 : t->froot[s];
+		out->root = t->sink ? -1 : t->froot[s];
 		out->enqueue_us = t->enqueue_us[s];
 		if(t->timed[s])
 		{
@@ -1604,7 +1810,8 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 			if(t->timed_g2[s]) (void)hipEventElapsedTime(&out->gather_ms, t->ev_g0[s], t->ev_g1[s]);
 			if(hipGetLastError() != hipSuccess) { /* (an event without timing data: the figure stays 0) */ }
 		}
-		if(t->host_base != NULL) out->sbuf = (const uint32_t *)(t->host_base + (size_t)s * n * 4);
+		if(t->hdst[s] != NULL) out->sbuf = t->hdst[s];
+		else if(t->host_base != NULL) out->sbuf = (const uint32_t *)(t->host_base + (size_t)s * n * 4);
 		else if(t->rank == t->froot[s])
 		{
 			out->d_sbuf = t->fin[s];

@@ -29,13 +29,33 @@ class PwnError(RuntimeError):
 class Renderer:
     """One GPU context for a fixed frame size (rwidth x rheight, main.c:26-27)."""
 
-    def __init__(self, width, height, device=0):
+    def __init__(self, width, height, device=0, devices=None):
+        """devices: a list of HIP ordinals -> pwn_init_multi, ONE handle whose frames are row-tiled over them inside this
+        process (the same ordinal several times: so many members on that device)"""
         self.w, self.h, self.device = int(width), int(height), int(device)
         self._ctx = C.c_void_p()
+        self.devices = None
+        if devices is not None:
+            self.devices = [int(d) for d in devices]
+            self.device = self.devices[0]
+            arr = (C.c_int * len(self.devices))(*self.devices)
+            rc = lib.pwn_init_multi(C.byref(self._ctx), arr, len(self.devices), self.w, self.h)
+            if rc != 0:
+                self._ctx = C.c_void_p()
+                raise PwnError(rc, "pwn_init_multi(devices=%s, %dx%d)" % (self.devices, width, height))
+            return
         rc = lib.pwn_init(C.byref(self._ctx), self.device, self.w, self.h)
         if rc != 0:
             self._ctx = C.c_void_p()
             raise PwnError(rc, "pwn_init(device=%d, %dx%d)" % (device, width, height))
+
+    def group_info(self):
+        gi = _lib.GroupInfo()
+        self._chk(lib.pwn_group_info_get(self._ctx, C.byref(gi)), "pwn_group_info_get")
+        n = gi.members
+        return {"members": n, "transport": {0: "rccl", 1: "shm", 2: "local"}.get(gi.transport, gi.transport), "devices": [gi.devices[i] for i in range(n)],
+                "cuts": [gi.cuts[i] for i in range(n + 1)], "halo_rows": gi.halo_rows, "host_sink": bool(gi.host_sink),
+                "frames": int(gi.frames), "frames_redone": int(gi.frames_redone), "recuts": int(gi.recuts)}
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:
