@@ -357,6 +357,137 @@ def host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barr
     return pcie
 
 
+def single_process(args):
+    """--single-process: ONE process, ONE handle (pwn_init_multi), the frame row-tiled over --gpus devices by the library's own
+    member threads -- what a host shaped like the reference's (one loop, main.c:93-109) gets.  The same step, the same K-step
+    blocks and median as the one-process-per-GPU run; `value` = frames that stay on the devices (gathered on device 0),
+    `d2h_inclusive` = every frame delivered to the host, every device copying its strip over its own PCIe link."""
+    import torch
+    import pwnfps_amd
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: libpwnhip.so has no CPU fallback")
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    # test hook: PWN_BENCH_ONE_DEVICE=1 puts every member on device 0 (the in-process transport between them)
+    devices = [0] * n if os.environ.get("PWN_BENCH_ONE_DEVICE") else list(range(n))
+    if max(devices) >= ndev:
+        sys.exit("bench.py --single-process --gpus %d: this process sees %d device(s)" % (n, ndev))
+    w, h = args.width, args.height
+    level_file = os.path.join(GOLD, "levels", args.level + ".txt")
+    spheres = np.load(os.path.join(GOLD, "spheres_t0.npy")) if args.level == "pwnfps_level" else np.load(os.path.join(GOLD, "levels", args.level + "_spheres.npy"))
+    r = pwnfps_amd.Renderer(w, h, devices=devices)
+    r.level_load(level_file)
+    r.set_objects(spheres)
+    r.set_blur_passes(args.blur)
+    r.set_frame_timing(max(1, args.time_every))
+    r.tiled_set_timeouts(max(5.0, min(120.0, args.bringup_timeout * 0.4)), max(3.0, min(30.0, args.headline_timeout * 0.25)))
+    _, _, spawn = r.get_level()
+    cam = pwnfps_amd.spawn_camera(spawn)
+    sec = 0.0
+    early = args.prepare == "early"
+    nsl = 3
+    launch_ms = []
+    last = {"f": None}
+
+    def run(k):
+        for i in range(k):
+            s = i % nsl
+            if early:
+                r.set_objects(spheres)
+            if i >= nsl:
+                last["f"] = r.wait_frame(s)
+                if last["f"]["timed"]:
+                    launch_ms.append(last["f"]["trace_ms"])
+            if not early:
+                r.set_objects(spheres)
+            r.submit_frame(cam, sec, s)
+        for i in range(max(0, k - nsl), k):
+            last["f"] = r.wait_frame(i % nsl)
+
+    def leg(warmup, min_time):
+        run(warmup)
+        launch_ms.clear()
+        blocks = []
+        while sum(blocks) < min_time and len(blocks) < 500:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(args.steps)
+            torch.cuda.synchronize()
+            blocks.append(time.perf_counter() - t0)
+        return float(np.median(blocks)), blocks
+    r.frames_config(nsl, sbuf=False)
+    dt, block_s = leg(args.warmup, args.min_time)
+    one = {"members": 1, "transport": None, "devices": devices, "cuts": [0, h], "halo_rows": 0, "host_sink": False, "frames": 0, "frames_redone": 0, "recuts": 0}
+    gi = r.group_info() if n > 1 else one
+    trace_ms = float(np.mean(launch_ms)) if launch_ms else 0.0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    frame_hash, parity = None, None
+    try:
+        import oracle
+        frame_hash = oracle.fnv64(r.read_plane(last["f"]["d_sbuf"]))
+        with open(os.path.join(GOLD, "frames.json")) as f:
+            want = [c for c in json.load(f)["cases"] if c["level"] == args.level and (c["w"], c["h"]) == (w, h) and c["sec"] == 0.0
+                    and c["nspheres"] == len(spheres) and c["name"].startswith(("level_spawn", args.level + "_cam0"))]
+        if want and args.level == "pwnfps_level":
+            parity = bool(frame_hash == (want[0]["post"] if args.blur else want[0]["pre"]))
+    except Exception as e:                                           # noqa: BLE001
+        sys.stderr.write("parity check skipped: %s\n" % e)
+    # ---- every frame delivered to the host
+    pcie = None
+    if not args.no_d2h:
+        r.frames_config(nsl, sbuf=True)
+        dth, bh = leg(max(2, args.warmup // 2), args.min_time)
+        same = bool(oracle.fnv64(last["f"]["sbuf"]) == frame_hash) if frame_hash is not None else None
+        sb = np.zeros((h, w), np.uint32)
+        r.frames_config(0)
+        r.host_register(sb)
+        best = 1e9
+        for _ in range(7):
+            t1 = time.perf_counter()
+            r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
+            best = min(best, time.perf_counter() - t1)
+        same_b = bool(oracle.fnv64(sb) == frame_hash) if frame_hash is not None else None
+        r.host_unregister(sb)
+        pcie = {"value": round(w * h * args.steps / dth / 1e6, 3), "unit": "Mpixels/s", "ms_per_step": round(dth / args.steps * 1e3, 4),
+                "frames_in_flight": nsl, "blocks": len(bh), "pcie_links": len(set(devices)), "host_frame_gbs": round(4 * w * h * args.steps / dth / 1e9, 2),
+                "last_frame_equals_resident_frame": same,
+                "blocking_call_mpix_s": round(w * h / best / 1e6, 2), "blocking_call_ms": round(best * 1e3, 4), "blocking_call_frame_equals_resident_frame": same_b,
+                "what": "pwn_frames_config(PWN_FRAME_SBUF) on the group's handle: every member copies its finished strip into the group's pinned frame "
+                        "over its own device's PCIe link; blocking_call = one pwn_trace_screen_centred at a time into the host's registered sbuf"}
+    gi2 = r.group_info() if n > 1 else one
+    pix = w * h
+    rows = [gi["cuts"][i + 1] - gi["cuts"][i] for i in range(n)]
+    strip_pix = max(rows) * w
+    achieved = TRACE_BYTES_PER_PIXEL * strip_pix / (trace_ms * 1e-3) / 1e9 if trace_ms > 0 else 0.0
+    one_device = len(set(devices)) == 1 and n > 1
+    line = {
+        "metric": ("Mpixels/s at %dx%d (level.txt scene, trace + blur), frames resident on the devices (gathered on device 0); ONE process, one handle "
+                   "(pwn_init_multi), %d member threads" % (w, h, n))
+                  + (" -- ALL MEMBERS ON ONE DEVICE (test hook): not a multi-GPU figure" if one_device else ""),
+        "value": round(pix * args.steps / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "single_process": True, "transport": gi["transport"], "devices": devices,
+        "timing": {"blocks_of_k_steps": len(block_s), "value_is": "median block",
+                   "block_ms_p10_p50_p90": [round(float(np.percentile(block_s, q)) * 1e3, 4) for q in (10, 50, 90)]},
+        "config": {"workload": "pwnfps level.txt scene (14 game.lua spheres, spawn pose, sec_current=0), %dx%d, POSTPROC_BLUR=%d, one frame per step" % (w, h, args.blur),
+                   "level": args.level, "width": w, "height": h, "blur_passes": args.blur,
+                   "parallelism": "rows/%d with moving cuts inside ONE process: a library-owned thread per device drives pwn_tiled.cpp's in-stream choreography, "
+                                  "exchange over %s, 3 frames in flight" % (n, gi["transport"]),
+                   "host_loop": "set_objects(i) / wait for a free slot / submit(i) on the one handle"},
+        "tiling": {"cuts": gi["cuts"], "halo_rows": gi["halo_rows"], "frames": gi2["frames"], "frames_redone": gi2["frames_redone"], "recuts": gi2["recuts"]},
+        "roofline": {"bound": "hbm", "kernel": "pwn_trace_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "algorithmic_bytes_per_launch": TRACE_BYTES_PER_PIXEL * strip_pix,
+                     "bytes_per_pixel": TRACE_BYTES_PER_PIXEL, "pixels_per_launch": strip_pix, "avg_launch_ms": round(trace_ms, 4),
+                     "note": "the slowest member's strip, HIP events on its launch stream (the launches share their chip with the neighbour frames' kernels)"},
+        "frame_bytes_per_pixel": FRAME_BYTES_PER_PIXEL, "frame_gbs": round(FRAME_BYTES_PER_PIXEL * pix * args.steps / dt / 1e9, 3),
+        "parity_vs_reference_golden": parity, "frame_fnv64": frame_hash,
+    }
+    if pcie:
+        line["d2h_inclusive"] = pcie
+    print(json.dumps(line), flush=True)
+    r.close()
+
+
 def _lib_slots():
     from pwnfps_amd import _lib
     return _lib.PWN_TILED_SLOTS
@@ -403,7 +534,15 @@ def main():
     ap.add_argument("--no-d2h", action="store_true",
                     help="skip the d2h_inclusive leg: for rocprofv3 --kernel-trace runs, where the profiler serialises the copies of "
                          "that leg with the kernels and their durations (2.7x) would be averaged into the resident loop's")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N in ONE process: one handle (pwn_init_multi), the library's member threads row-tile every frame over devices 0..N-1; "
+                         "started plainly (python bench.py --gpus N --single-process), not under torch.distributed.run")
     args = ap.parse_args()
+    if args.single_process:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            sys.exit("bench.py --single-process is one process: start it without torch.distributed.run")
+        return single_process(args)
 
     # (multi-process GPU work on this pool: the host driver only supports dmabuf IPC; already exported where the driver runs this)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

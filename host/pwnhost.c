@@ -35,7 +35,9 @@
  * presents the frames.  -H ROWS sets the halo (default -1 = depth 24, 0 = whole strips).
  * -M 1: the frames are delivered to the host by every rank (pwn_tiled_host_sink): one frame buffer in POSIX
  * shared memory, every rank copies its strip into it over its own PCIe link, nothing is gathered to rank 0.
- * -G 1: the gather's root rotates over the ranks (pwn_tiled_gather_root): frame f is assembled, and presented, on rank f mod WORLD.
+ * -O 1: the gather's root rotates over the ranks (pwn_tiled_gather_root): frame f is assembled, and presented, on rank f mod WORLD.
+ * -G N: the frame row-tiled over N GPUs by THIS process (pwn_init_multi): one handle, the loops below unchanged -- the blocking
+ * loop of main.c:93-109, or with -q the frames in flight; devices 0..N-1, or N members on the one device of -d (boxes with one GPU).
  * -X SECONDS / -Y SECONDS: how long the tiling's bring-up / a wait for a frame may wait for the other ranks (pwn_tiled_set_timeouts;
  * defaults 120 / 60); a rank that does not answer ends the run with the library's message and exit status 2, not with a hang.
  * -q SLOTS (2..4) keeps that many frames in flight (pwn_submit_frame /
@@ -184,7 +186,7 @@ int main(int argc, char **argv)
 	int frames = 1, device = 0, blur = 1, pitch = 0, verbose = 0, slots = 0;
 	int world = 1, rank = 0, halo = -1, transport = PWN_TRANSPORT_RCCL, window = 0, frames_given = 0, hostsink = 0;
 	float tiled_init_s = 0.0f, tiled_wait_s = 0.0f;
-	int rotate_root = 0;
+	int rotate_root = 0, group = 0;
 	int rank_given = 0, device_given = 0;
 	const char *idfile = NULL, *nonce = "";
 	const time_t started = time(NULL);
@@ -218,7 +220,8 @@ int main(int argc, char **argv)
 			case 'N': nonce = argv[++i]; break;
 			case 'H': halo = atoi(argv[++i]); break;
 			case 'M': hostsink = atoi(argv[++i]); break;
-			case 'G': rotate_root = atoi(argv[++i]); break;
+			case 'O': rotate_root = atoi(argv[++i]); break;
+			case 'G': group = atoi(argv[++i]); break;
 			case 'T': transport = strcmp(argv[++i], "shm") == 0 ? PWN_TRANSPORT_SHM : PWN_TRANSPORT_RCCL; break;
 			case 'X': tiled_init_s = (float)atof(argv[++i]); break;
 			case 'Y': tiled_wait_s = (float)atof(argv[++i]); break;
@@ -229,7 +232,8 @@ int main(int argc, char **argv)
 	{
 		fprintf(stderr, "usage: pwnhost level.txt [-s spheres.txt | -g game_objects.txt] [-w W] [-h H] [-x SCALE] "
 			"[-n FRAMES] [-t SEC_PER_FRAME] [-a TURN] [-p PITCH_BYTES] [-b BLUR] [-o out.ppm] [-d DEVICE] [-v 1] [-q SLOTS]\n"
-			"       [-W WORLD -R RANK -I IDFILE [-N LAUNCH_NONCE] [-T rccl|shm] [-H HALO_ROWS] [-M 1 | -G 1]]\n");
+			"       [-W WORLD -R RANK -I IDFILE [-N LAUNCH_NONCE] [-T rccl|shm] [-H HALO_ROWS] [-M 1 | -O 1]]\n"
+			"       [-G GPUS_OF_THIS_PROCESS]\n");
 		return 2;
 	}
 	/* -W WORLD without -R: this process starts the other ranks itself (fork, before anything touches a GPU): rank r
@@ -277,7 +281,21 @@ int main(int argc, char **argv)
 	if(sbuf == NULL || zbuf == NULL || surface.pixels == NULL) { fprintf(stderr, "out of memory\n"); return 1; }
 
 	pwn_ctx *ctx = NULL;
-	int rc = pwn_init(&ctx, device, rwidth, rheight);
+	int rc;
+	if(group > 1)
+	{
+		/* one process, one handle, GROUP devices behind it (main.c's one loop stays what it is) */
+		int devs[PWN_TILED_MAX_WORLD];
+		if(group > PWN_TILED_MAX_WORLD || world > 1) { fprintf(stderr, "-G takes 2..%d GPUs of this one process (not with -W)\n", PWN_TILED_MAX_WORLD); return 2; }
+		for(int i = 0; i < group; i++) devs[i] = device_given ? device : i;
+		rc = pwn_init_multi(&ctx, devs, group, rwidth, rheight);
+		if(rc != PWN_OK) { fprintf(stderr, "pwn_init_multi: %s (%d)\n", pwn_strerror(rc), rc); return 1; }
+		if(tiled_init_s > 0.0f || tiled_wait_s > 0.0f) CHK(pwn_tiled_set_timeouts(ctx, (int)(tiled_init_s * 1000.0f), (int)(tiled_wait_s * 1000.0f)));
+		/* (main.c:395-400's buffers, made known to the devices once: every device copies its strip straight into them) */
+		CHK(pwn_host_register(ctx, sbuf, npix * 4));
+		CHK(pwn_host_register(ctx, zbuf, npix * 4));
+	}
+	else rc = pwn_init(&ctx, device, rwidth, rheight);
 	if(rc != PWN_OK) { fprintf(stderr, "pwn_init: %s (%d)\n", pwn_strerror(rc), rc); return 1; }
 	CHK(pwn_set_option(ctx, PWN_OPT_BLUR_PASSES, blur));
 
@@ -424,7 +442,7 @@ int main(int argc, char **argv)
 			if(f >= 2)
 			{
 				CHK(pwn_tiled_wait(ctx, PWN_TILED_HOST, &tf));
-				if(tf.sbuf != NULL && verbose)                 /* (the frame's root -- rank 0 unless -G 1 --, or every rank with a host sink) */
+				if(tf.sbuf != NULL && verbose)                 /* (the frame's root -- rank 0 unless -O 1 --, or every rank with a host sink) */
 					printf("frame %d sec %.9g fnv64 %016llx\n", f - 2, (double)(fixed_dt * (float)(f - 2)), (unsigned long long)fnv64(tf.sbuf, npix));
 				if(f == 2) t1 = now_s();
 			}
@@ -477,7 +495,8 @@ int main(int argc, char **argv)
 	if(slots > 0)
 	{
 		/* frames in flight: the loop of main.c:93-140 with the present step SLOTS-1 frames behind */
-		CHK(pwn_frames_config(ctx, slots, PWN_FRAME_SBUF | PWN_FRAME_SURFACE, rscale, pitch));
+		/* (a group delivers sbuf; its sink runs on the delivered frame: pwn_screen_upscale below) */
+		CHK(pwn_frames_config(ctx, slots, group > 1 ? PWN_FRAME_SBUF : (PWN_FRAME_SBUF | PWN_FRAME_SURFACE), rscale, pitch));
 		pwn_frame fr;
 		memset(&fr, 0, sizeof(fr));
 		double t0 = now_s(), t1 = t0;
@@ -506,6 +525,11 @@ int main(int argc, char **argv)
 			}
 		}
 		double t2 = now_s();
+		if(group > 1)
+		{
+			CHK(pwn_screen_upscale(ctx, fr.sbuf, rscale, surface.pitch, surface.pixels));      /* main.c:108 */
+			fr.surface = surface.pixels;
+		}
 		printf("frame %dx%d x%d: sbuf fnv64 %016llx, surface fnv64 %016llx\n", rwidth, rheight, rscale,
 			(unsigned long long)fnv64(fr.sbuf, npix),
 			(unsigned long long)fnv64(fr.surface, (size_t)(pitch / 4) * (size_t)rheight * (size_t)rscale));
@@ -592,6 +616,15 @@ int main(int argc, char **argv)
 
 	pwn_stats st;
 	CHK(pwn_get_stats(ctx, &st));
+	if(group > 1)
+	{
+		pwn_group_info gi;
+		CHK(pwn_group_info_get(ctx, &gi));
+		printf("group of %d in one process, exchange over %s: rows", gi.members, gi.transport == PWN_TRANSPORT_RCCL ? "RCCL" : "copies inside the process");
+		for(int i = 0; i <= gi.members; i++) printf(" %d", gi.cuts[i]);
+		printf(" (the cuts moved %llu times), halo %d rows, %llu frames (%llu repeated with whole strips)\n", (unsigned long long)gi.recuts, gi.halo_rows,
+			(unsigned long long)gi.frames, (unsigned long long)gi.frames_redone);
+	}
 	printf("frame %dx%d x%d: sbuf fnv64 %016llx, surface fnv64 %016llx\n", rwidth, rheight, rscale,
 		(unsigned long long)fnv64(sbuf, npix),
 		(unsigned long long)fnv64(surface.pixels, (size_t)(pitch / 4) * (size_t)rheight * (size_t)rscale));

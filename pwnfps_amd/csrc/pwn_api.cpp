@@ -594,7 +594,35 @@ extern "C" int pwn_get_objects(pwn_ctx *c, pwn_sphere *out, int cap)
 	return (int)live.size();
 }
 
-int pwn_i_upload_live(pwn_ctx *c, const pwn_sphere *s, int n) { return upload_live(c, s, n); }
+// (a group, pwn_group.cpp: the list is binned once and every member uploads it)
+int pwn_i_bin_spheres(const pwn_sphere *s, int n, pwn_binned *out)
+{
+	out->off.assign(4097, 0);
+	const int nb = pwn_bin_spheres(s, n, out->off.data(), NULL, 0);
+	if(nb < 0) return PWN_ENOMEM;
+	out->idx.assign((size_t)(nb > 0 ? nb : 1), 0);
+	if(pwn_bin_spheres(s, n, out->off.data(), out->idx.data(), nb) != nb) return PWN_ENOMEM;
+	out->s.assign(s, s + n);
+	// what pack_blob would refuse
+	uint32_t nbin = 0;
+	for(int i = 0; i < 4096; i++) { const uint32_t cnt = (uint32_t)(out->off[i + 1] - out->off[i]); if(cnt) nbin += cnt + 1u; }
+	if(nbin > 32767u || (uint32_t)n * 32u >= PWN_LIST_END || ((pwn_t_total(nbin, (uint32_t)n) + 15u) & ~15u) > PWN_BLOB_MAX) return PWN_ETOOBIG;
+	return PWN_OK;
+}
+
+int pwn_i_upload_binned(pwn_ctx *c, const pwn_binned &b)
+{
+	(void)hipSetDevice(c->device);
+	c->spheres = b.s; c->bin_off = b.off; c->bin_idx = b.idx;
+	c->blob_dirty = true;
+	return pack_blob(c);
+}
+
+void pwn_i_set_object_table(pwn_ctx *c, const pwn_sphere *s, int n)
+{
+	c->objs.assign(s, s + n);
+	c->obj_typ.assign((size_t)n, OBJ_SPHERE);
+}
 
 static int upload_live(pwn_ctx *c, const pwn_sphere *s, int n)
 {
@@ -623,7 +651,7 @@ static int upload_live(pwn_ctx *c, const pwn_sphere *s, int n)
 
 extern "C" int pwn_get_bins(pwn_ctx *c, uint16_t counts[4096], int32_t *idx, int cap)
 {
-	if(GRP_HEAD(c)) return pwn_get_bins(GRP_M0(c), counts, idx, cap);
+	if(GRP_HEAD(c)) { const int rc = pwn_group_sync(c); return rc != PWN_OK ? rc : pwn_get_bins(GRP_M0(c), counts, idx, cap); }      // (the lists are the members' threads' work)
 	if(c == NULL || counts == NULL) return PWN_EINVAL;
 	for(int i = 0; i < 4096; i++) counts[i] = (uint16_t)(c->bin_off[i + 1] - c->bin_off[i]);
 	int n = c->bin_off[4096];
@@ -905,7 +933,7 @@ int pwn_i_launch_order(pwn_ctx *c, hipStream_t stream)
 // the sort by itself, host arrays in and out (tests): perm_out has 64 * ceil(units / 64) entries, queue q's at [q * cap, q * cap + its length)
 extern "C" int pwn_unit_order_probe(pwn_ctx *c, const uint16_t *cost, uint32_t units, uint32_t *perm_out)
 {
-	if(GRP_HEAD(c)) return pwn_unit_order_probe(GRP_M0(c), cost, units, perm_out);
+	if(GRP_HEAD(c)) return pwn_group_on_member0(c, [cost, units, perm_out](pwn_ctx *m0) { return pwn_unit_order_probe(m0, cost, units, perm_out); });
 	if(c == NULL || cost == NULL || perm_out == NULL || units == 0u) return PWN_EINVAL;
 	const uint32_t cap = (units + PWN_QUEUES - 1u) / PWN_QUEUES;
 	(void)hipSetDevice(c->device);
@@ -1462,7 +1490,7 @@ extern "C" int pwn_submit_frame(pwn_ctx *c, const float cam[16], float sec, int 
 
 extern "C" int pwn_read_plane(pwn_ctx *c, const void *d_src, void *dst, size_t bytes)
 {
-	if(GRP_HEAD(c)) return pwn_read_plane(GRP_M0(c), d_src, dst, bytes);       // (a frame that stayed on the devices was gathered on member 0's)
+	if(GRP_HEAD(c)) return pwn_group_on_member0(c, [d_src, dst, bytes](pwn_ctx *m0) { return pwn_read_plane(m0, d_src, dst, bytes); });       // (a frame that stayed on the devices was gathered on member 0's)
 	if(c == NULL || d_src == NULL || dst == NULL) return PWN_EINVAL;
 	(void)hipSetDevice(c->device);
 	HIPCHK(c, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
@@ -1601,7 +1629,7 @@ extern "C" int pwn_screen_upscale(pwn_ctx *c, const uint32_t *sbuf, int scale, i
 
 extern "C" int pwn_probe(pwn_ctx *c, int op, const uint32_t *in, uint32_t *out, int n)
 {
-	if(GRP_HEAD(c)) return pwn_probe(GRP_M0(c), op, in, out, n);
+	if(GRP_HEAD(c)) return pwn_group_on_member0(c, [op, in, out, n](pwn_ctx *m0) { return pwn_probe(m0, op, in, out, n); });
 	if(c == NULL || in == NULL || out == NULL || n < 0 || op < 0 || op > PWN_PROBE_COS_OF_PAIR) return PWN_EINVAL;
 	if(n == 0) return PWN_OK;
 	(void)hipSetDevice(c->device);

@@ -21,7 +21,9 @@
 #include <new>
 #include <atomic>
 #include <condition_variable>
+#include <array>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -29,6 +31,7 @@
 #include "pwn_internal.h"
 
 #define MAXM PWN_TILED_MAX_WORLD
+#define GROUP_RING 32u
 enum { MODE_NONE = 0, MODE_SINK = 1, MODE_RESIDENT = 2 };
 
 struct pwn_group
@@ -37,14 +40,21 @@ struct pwn_group
 	pwn_ctx *head, *m[MAXM];
 	int devices[MAXM];
 	pwn_hub hub;
-	// the members' threads: a job is a function of the member's index; the caller's thread runs member 0's share
+	// The members' threads, one per member.  A job is a function of the member's index; the caller posts it for all members and
+	// either goes on (the tables of the next frame, a frame's submission: the members run ahead of the host loop like the ranks
+	// of a process-per-GPU run do) or waits for it (a frame's delivery, everything rare).  Jobs run in the order they were
+	// posted, on every member.  The first failure marks the group broken: the members skip what is queued behind it, and the
+	// next call that waits reports it.
 	std::thread th[MAXM];
 	std::mutex mu; std::condition_variable cv;
-	std::atomic<unsigned long long> seq;
-	std::atomic<int> pending;
-	std::atomic<bool> quit;
-	std::function<int(int)> job;
-	int rc[MAXM];
+	struct job_t { std::function<int(int)> fn; bool always; } jobs[GROUP_RING];
+	std::atomic<unsigned long long> posted;                 // jobs 1..posted exist (job k in jobs[k % GROUP_RING])
+	std::atomic<unsigned long long> done[MAXM];             // ... and member i is through jobs 1..done[i]
+	std::atomic<bool> quit, broken;
+	std::mutex err_mu; int err_rc, err_member; char err_text[200];
+	// PWN_DBG_GROUP_PROF: where the time goes (printed when the group goes): how long the caller waits per job it waits for, how
+	// long the members take per job
+	bool prof; double p_join, p_job[MAXM]; unsigned long long p_jobs, p_joins;
 	// the tiling in force
 	int mode;
 	int init_ms, wait_ms;
@@ -52,7 +62,7 @@ struct pwn_group
 	int nslots, flags;
 	uint32_t *h_sbuf[PWN_MAX_SLOTS]; float *h_zbuf[PWN_MAX_SLOTS];
 	bool in_flight[PWN_MAX_SLOTS], delivered[PWN_MAX_SLOTS];
-	pwn_frame done[PWN_MAX_SLOTS];
+	pwn_frame fdone[PWN_MAX_SLOTS];
 	float sec[PWN_MAX_SLOTS];
 	int fifo[PWN_MAX_SLOTS + 1], fifo_n;        // slots in submission order, oldest first
 	uint64_t frame_seq;
@@ -98,47 +108,87 @@ static void worker(pwn_group *g, int i)
 	unsigned long long seen = 0;
 	for(;;)
 	{
-		// a frame loop hands out jobs back to back: look for the next one for a while before going to sleep
-		unsigned long long now = g->seq.load(std::memory_order_acquire);
-		for(unsigned spins = 0; now == seen && spins < 20000u && !g->quit.load(std::memory_order_relaxed); spins++) now = g->seq.load(std::memory_order_acquire);
+		// a frame loop posts jobs back to back: look for the next one for a while (~0.2 ms) before going to sleep
+		unsigned long long now = g->posted.load(std::memory_order_acquire);
+		for(unsigned spins = 0; now == seen && spins < 100000u && !g->quit.load(std::memory_order_relaxed); spins++) now = g->posted.load(std::memory_order_acquire);
 		if(now == seen)
 		{
 			std::unique_lock<std::mutex> lk(g->mu);
-			g->cv.wait_for(lk, std::chrono::milliseconds(2), [&] { return g->seq.load(std::memory_order_acquire) != seen || g->quit.load(); });
-			now = g->seq.load(std::memory_order_acquire);
+			g->cv.wait_for(lk, std::chrono::milliseconds(2), [&] { return g->posted.load(std::memory_order_acquire) != seen || g->quit.load(); });
+			now = g->posted.load(std::memory_order_acquire);
 		}
-		if(g->quit.load()) return;
-		if(now == seen) continue;
-		seen = now;
-		g->rc[i] = g->job(i);
-		if(g->rc[i] != PWN_OK) g->hub.failed.store(1);          // (nobody waits for this member's share of the job any longer)
-		g->pending.fetch_sub(1, std::memory_order_acq_rel);
+		if(now == seen) { if(g->quit.load()) return; continue; }
+		while(seen < now)
+		{
+			pwn_group::job_t &j = g->jobs[(seen + 1) % GROUP_RING];
+			const double t0 = g->prof ? now_ms() : 0.0;
+			if(j.always || !g->broken.load(std::memory_order_acquire))
+			{
+				const int rc = j.fn(i);
+				if(rc != PWN_OK)
+				{
+					std::lock_guard<std::mutex> lk(g->err_mu);
+					if(g->err_rc == PWN_OK)
+					{
+						g->err_rc = rc; g->err_member = i;
+						snprintf(g->err_text, sizeof(g->err_text), "%.190s", g->m[i]->err[0] ? g->m[i]->err : pwn_strerror(rc));
+					}
+					g->broken.store(true, std::memory_order_release);
+					g->hub.failed.store(1);             // (nobody waits for this member any longer)
+				}
+			}
+			if(g->prof) g->p_job[i] += now_ms() - t0;
+			seen++;
+			g->done[i].store(seen, std::memory_order_release);
+		}
 	}
 }
 
-// run `fn` for every member -- member i on its own thread -- and come back when all are through.  The first error (lowest
-// member) is the job's; its text goes to the handle.
-static int run_all(pwn_group *g, const std::function<int(int)> &fn)
+// post `fn` for every member -- member i runs fn(i) on its own thread, behind everything posted before -- and go on
+static unsigned long long post(pwn_group *g, std::function<int(int)> fn, bool always = false)
 {
-	g->job = fn;
-	g->pending.store(g->n - 1, std::memory_order_relaxed);
+	const unsigned long long id = g->posted.load(std::memory_order_relaxed) + 1;
+	// (the slot's last job, GROUP_RING jobs back, has to be through on every member)
+	if(id > GROUP_RING)
+		for(int i = 0; i < g->n; i++)
+			for(unsigned long long spins = 0; g->done[i].load(std::memory_order_acquire) + GROUP_RING < id; spins++)
+				if(spins > 100000) { struct timespec ts = { 0, 20 * 1000 }; nanosleep(&ts, NULL); }
+	g->jobs[id % GROUP_RING].fn = std::move(fn);
+	g->jobs[id % GROUP_RING].always = always;
 	{
 		std::lock_guard<std::mutex> lk(g->mu);
-		g->seq.fetch_add(1, std::memory_order_release);
+		g->posted.store(id, std::memory_order_release);
 	}
 	g->cv.notify_all();
-	(void)hipSetDevice(g->devices[0]);
-	g->rc[0] = fn(0);
-	if(g->rc[0] != PWN_OK) g->hub.failed.store(1);
-	for(unsigned long long spins = 0; g->pending.load(std::memory_order_acquire) != 0; spins++)
-		if(spins > 20000) { struct timespec ts = { 0, 20 * 1000 }; nanosleep(&ts, NULL); }
+	if(g->prof) g->p_jobs++;
+	return id;
+}
+
+// wait until every member is through job `id`; the first failure since the group was last in order, if any
+static int join(pwn_group *g, unsigned long long id)
+{
+	const double t0 = g->prof ? now_ms() : 0.0;
 	for(int i = 0; i < g->n; i++)
-		if(g->rc[i] != PWN_OK)
-		{
-			snprintf(g->head->err, sizeof(g->head->err), "member %d (device %d): %.200s", i, g->devices[i], g->m[i]->err[0] ? g->m[i]->err : pwn_strerror(g->rc[i]));
-			return g->rc[i];
-		}
+		for(unsigned long long spins = 0; g->done[i].load(std::memory_order_acquire) < id; spins++)
+			if(spins > 200000) { struct timespec ts = { 0, 20 * 1000 }; nanosleep(&ts, NULL); }
+	if(g->prof) { g->p_join += now_ms() - t0; g->p_joins++; }
+	if(g->broken.load(std::memory_order_acquire))
+	{
+		std::lock_guard<std::mutex> lk(g->err_mu);
+		snprintf(g->head->err, sizeof(g->head->err), "member %d (device %d): %s", g->err_member, g->devices[g->err_member], g->err_text);
+		return g->err_rc != PWN_OK ? g->err_rc : PWN_EHIP;
+	}
 	return PWN_OK;
+}
+
+static int run_all(pwn_group *g, std::function<int(int)> fn, bool always = false) { return join(g, post(g, std::move(fn), always)); }
+
+// the group is in order again (the caller has dealt with the failure: the tiling is down)
+static void mend(pwn_group *g)
+{
+	std::lock_guard<std::mutex> lk(g->err_mu);
+	g->err_rc = PWN_OK; g->err_member = 0; g->err_text[0] = 0;
+	g->broken.store(false, std::memory_order_release);
 }
 
 pwn_ctx *pwn_group_member(pwn_ctx *h, int i) { return (h != NULL && h->grp != NULL && i >= 0 && i < h->grp->n) ? h->grp->m[i] : NULL; }
@@ -158,8 +208,9 @@ static void frames_free(pwn_group *g)
 static int tiling_down(pwn_group *g)
 {
 	if(g->mode == MODE_NONE) return PWN_OK;
-	(void)run_all(g, [g](int i) { pwn_tiled_shutdown(g->m[i]); return PWN_OK; });
+	(void)run_all(g, [g](int i) { pwn_tiled_shutdown(g->m[i]); return PWN_OK; }, true);
 	g->mode = MODE_NONE;
+	mend(g);
 	g->hub.failed.store(0);
 	g->hub.bar_count.store(0);
 	for(int i = 0; i < g->n * g->n; i++) { g->hub.boxes[i].posted.store(0); g->hub.boxes[i].copied.store(0); g->hub.boxes[i].consumed.store(0); }
@@ -177,8 +228,10 @@ static int tiling_up(pwn_group *g, int mode)
 		const int rc = pwn_tiled_unique_id(id, PWN_TRANSPORT_RCCL);
 		if(rc != PWN_OK) { snprintf(g->head->err, sizeof(g->head->err), "librccl: no unique id (%s)", pwn_strerror(rc)); return rc; }
 	}
-	const int rc = run_all(g, [g, &id, mode](int i)
+	std::vector<unsigned char> idv(id, id + sizeof(id));
+	const int rc = run_all(g, [g, idv, mode](int i)
 	{
+		const unsigned char *id = idv.data();
 		pwn_ctx *c = g->m[i];
 		int r = pwn_tiled_set_timeouts(c, g->init_ms ? g->init_ms : 0, g->wait_ms ? g->wait_ms : 0);
 		if(r == PWN_OK) r = pwn_tiled_init(c, i, g->n, id, g->transport, -1);
@@ -219,7 +272,10 @@ extern "C" int pwn_init_multi(pwn_ctx **out, const int *devices, int ndev, int w
 	pwn_group *g = new(std::nothrow) pwn_group();
 	pwn_ctx *h = new(std::nothrow) pwn_ctx();
 	if(g == NULL || h == NULL) { delete g; delete h; return PWN_ENOMEM; }
-	g->n = ndev; g->head = h; g->mode = MODE_NONE; g->seq.store(0); g->pending.store(0); g->quit.store(false);
+	g->n = ndev; g->head = h; g->mode = MODE_NONE; g->posted.store(0); g->quit.store(false); g->broken.store(false);
+	g->err_rc = PWN_OK; g->err_member = 0; g->err_text[0] = 0;
+	g->prof = getenv("PWN_DBG_GROUP_PROF") != NULL; g->p_join = 0.0; g->p_jobs = g->p_joins = 0;
+	for(int i = 0; i < MAXM; i++) { g->p_job[i] = 0.0; g->done[i].store(0); }
 	g->init_ms = g->wait_ms = 0; g->nslots = 0; g->flags = 0; g->fifo_n = 0; g->frame_seq = 0; g->last_sbuf = NULL;
 	for(int i = 0; i < PWN_MAX_SLOTS; i++) { g->h_sbuf[i] = NULL; g->h_zbuf[i] = NULL; g->in_flight[i] = g->delivered[i] = false; }
 	for(int i = 0; i < MAXM; i++) { g->m[i] = NULL; g->devices[i] = -1; g->hub.member[i] = NULL; }
@@ -267,7 +323,7 @@ extern "C" int pwn_init_multi(pwn_ctx **out, const int *devices, int ndev, int w
 			(void)hipSetDevice(devices[a]);
 			if(hipDeviceEnablePeerAccess(devices[b], 0) != hipSuccess) (void)hipGetLastError();          // (already enabled: fine)
 		}
-	for(int i = 1; i < ndev; i++) g->th[i] = std::thread(worker, g, i);
+	for(int i = 0; i < ndev; i++) g->th[i] = std::thread(worker, g, i);
 	*out = h;
 	return PWN_OK;
 }
@@ -276,14 +332,17 @@ void pwn_group_destroy(pwn_ctx *h)
 {
 	pwn_group *g = h->grp;
 	tiling_down(g);
+	(void)join(g, g->posted.load());
 	g->quit.store(true);
-	{
-		std::lock_guard<std::mutex> lk(g->mu);
-		g->seq.fetch_add(1, std::memory_order_release);
-	}
 	g->cv.notify_all();
-	for(int i = 1; i < g->n; i++) if(g->th[i].joinable()) g->th[i].join();
+	for(int i = 0; i < g->n; i++) if(g->th[i].joinable()) g->th[i].join();
 	frames_free(g);
+	if(g->prof && g->p_jobs)
+	{
+		fprintf(stderr, "group of %d: %llu jobs, %llu of them waited for: %.1f us per wait;", g->n, g->p_jobs, g->p_joins, g->p_joins ? g->p_join / g->p_joins * 1e3 : 0.0);
+		for(int i = 0; i < g->n; i++) fprintf(stderr, " member %d %.1f us per job;", i, g->p_job[i] / g->p_jobs * 1e3);
+		fprintf(stderr, "\n");
+	}
 	for(int i = 0; i < g->n; i++) if(g->m[i]) { g->m[i]->grp = NULL; g->m[i]->hub = NULL; pwn_destroy(g->m[i]); }
 	delete[] g->hub.boxes;
 	delete g;
@@ -299,6 +358,7 @@ extern "C" int pwn_group_info_get(pwn_ctx *h, pwn_group_info *out)
 	out->members = g->n; out->transport = g->transport;
 	for(int i = 0; i < g->n; i++) out->devices[i] = g->devices[i];
 	pwn_tiled_info ti;
+	(void)join(g, g->posted.load());          // (the members' threads are through what was posted: their tilings are at rest)
 	if(g->mode != MODE_NONE && pwn_tiled_get_info(g->m[0], &ti) == PWN_OK)
 	{
 		(void)pwn_tiled_get_cuts(g->m[0], out->cuts, NULL);
@@ -317,11 +377,8 @@ int pwn_group_set_option(pwn_ctx *h, int option, int value)
 	if(option == PWN_OPT_BLUR_PASSES || option == PWN_OPT_FRAME_OVERLAP || option == PWN_OPT_TILED_CHOREO || option == PWN_OPT_TILED_COMMS ||
 	   option == PWN_OPT_TILED_STREAMS) tiling_down(g);
 	if(option == PWN_OPT_BLUR_PASSES && value > 1) { snprintf(h->err, sizeof(h->err), "a group renders with POSTPROC_BLUR 0 or 1"); return PWN_EINVAL; }
-	for(int i = 0; i < g->n; i++)
-	{
-		const int rc = pwn_set_option(g->m[i], option, value);
-		if(rc != PWN_OK) return rc;
-	}
+	const int rc = run_all(g, [g, option, value](int i) { return pwn_set_option(g->m[i], option, value); }, true);
+	if(rc != PWN_OK) { mend(g); return rc; }        // (a refused option is no failure of the group)
 	if(option == PWN_OPT_BLUR_PASSES) h->blur_passes = value;
 	return PWN_OK;
 }
@@ -338,12 +395,24 @@ int pwn_group_upload_level(pwn_ctx *h, const uint8_t *data, const pwn_portal *pm
 	return run_all(g, [g, data, pmap](int i) { return pwn_upload_level(g->m[i], data, pmap); });
 }
 
-// level_prepare_render (level.h:64-81) for every device: the handle's ONE object table (member 0's) gives the list of live
-// spheres; every member bins and uploads it on its own device, on its own thread
+// level_prepare_render (level.h:64-81) for every device: the handle's ONE object table (member 0's, touched by the caller's thread
+// only) gives the list of live spheres; it is binned once, here, and every member's thread packs and uploads the lists on its own
+// device -- behind whatever it is still doing: the call does not wait
+static int post_spheres(pwn_group *g, const pwn_sphere *s, int n)
+{
+	std::shared_ptr<pwn_binned> b = std::make_shared<pwn_binned>();
+	const int rc = pwn_i_bin_spheres(s, n, b.get());
+	if(rc != PWN_OK) { snprintf(g->head->err, sizeof(g->head->err), "%s", pwn_strerror(rc)); return rc; }
+	(void)post(g, [g, b](int i) { return pwn_i_upload_binned(g->m[i], *b); });
+	return PWN_OK;
+}
+
 int pwn_group_upload_spheres(pwn_ctx *h, const pwn_sphere *s, int n)
 {
 	pwn_group *g = h->grp;
-	return run_all(g, [g, s, n](int i) { return i == 0 ? pwn_upload_spheres(g->m[0], s, n) : pwn_i_upload_live(g->m[i], s, n); });
+	const int rc = post_spheres(g, s, n);
+	if(rc == PWN_OK) pwn_i_set_object_table(g->m[0], s, n);
+	return rc;
 }
 
 int pwn_group_prepare_render(pwn_ctx *h)
@@ -354,19 +423,40 @@ int pwn_group_prepare_render(pwn_ctx *h)
 	std::vector<pwn_sphere> live((size_t)(n > 0 ? n : 1));
 	const int got = pwn_get_objects(g->m[0], live.data(), n);
 	if(got < 0) return got;
-	const pwn_sphere *p = live.data();
-	return run_all(g, [g, p, n](int i) { return pwn_i_upload_live(g->m[i], p, n); });
+	return post_spheres(g, live.data(), n);
 }
 
-int pwn_group_host_register(pwn_ctx *h, void *base, size_t bytes) { const int rc = pwn_host_register(h->grp->m[0], base, bytes); if(rc != PWN_OK) snprintf(h->err, sizeof(h->err), "%s", h->grp->m[0]->err); return rc; }
-int pwn_group_host_unregister(pwn_ctx *h, void *base) { return pwn_host_unregister(h->grp->m[0], base); }
+// everything posted so far is through (what reads a member's tables from the caller's thread comes behind this)
+int pwn_group_sync(pwn_ctx *h) { return join(h->grp, h->grp->posted.load()); }
+
+// a call about member 0's device (the sink, a plane, the probes), on member 0's thread
+int pwn_group_on_member0(pwn_ctx *h, const std::function<int(pwn_ctx *)> &fn)
+{
+	pwn_group *g = h->grp;
+	const int rc = run_all(g, [g, &fn](int i) { return i == 0 ? fn(g->m[0]) : PWN_OK; }, true);
+	if(rc != PWN_OK && !g->broken.load()) snprintf(h->err, sizeof(h->err), "%s", g->m[0]->err);
+	return rc;
+}
+
+int pwn_group_host_register(pwn_ctx *h, void *base, size_t bytes)
+{
+	const int rc = pwn_group_on_member0(h, [base, bytes](pwn_ctx *m0) { return pwn_host_register(m0, base, bytes); });
+	if(rc != PWN_OK) mend(h->grp);
+	return rc;
+}
+int pwn_group_host_unregister(pwn_ctx *h, void *base)
+{
+	const int rc = pwn_group_on_member0(h, [base](pwn_ctx *m0) { return pwn_host_unregister(m0, base); });
+	if(rc != PWN_OK) mend(h->grp);
+	return rc;
+}
 
 int pwn_group_set_timeouts(pwn_ctx *h, int init_ms, int wait_ms)
 {
 	pwn_group *g = h->grp;
 	if(init_ms != 0) g->init_ms = init_ms > 0 ? init_ms : 0;
 	if(wait_ms != 0) g->wait_ms = wait_ms > 0 ? wait_ms : 0;
-	for(int i = 0; i < g->n; i++) (void)pwn_tiled_set_timeouts(g->m[i], init_ms, wait_ms);
+	(void)run_all(g, [g, init_ms, wait_ms](int i) { return pwn_tiled_set_timeouts(g->m[i], init_ms, wait_ms); }, true);
 	return PWN_OK;
 }
 
@@ -395,11 +485,13 @@ int pwn_group_trace_screen_centred(pwn_ctx *h, const float cam[16], float sec, u
 	const double t0 = now_ms();
 	int rc = tiling_up(g, MODE_SINK);
 	if(rc != PWN_OK) return rc;
-	rc = run_all(g, [g, cam, sec, sbuf, zbuf](int i)
+	std::array<float, 16> cm;
+	memcpy(cm.data(), cam, sizeof(float) * 16);
+	rc = run_all(g, [g, cm, sec, sbuf, zbuf](int i)
 	{
 		// (carry_depth: one call at a time -- every call's depth lives in the same plane, so that a pixel whose primary ray
 		// runs out of steps keeps the previous call's value, trace.h:677, as on one device)
-		int r = pwn_i_tiled_submit(g->m[i], cam, sec, sbuf, zbuf, 1);
+		int r = pwn_i_tiled_submit(g->m[i], cm.data(), sec, sbuf, zbuf, 1);
 		if(r == PWN_OK) r = pwn_tiled_wait(g->m[i], 0, &g->tf[i]);
 		return r;
 	});
@@ -444,12 +536,14 @@ int pwn_group_submit_frame(pwn_ctx *h, const float cam[16], float sec, int slot)
 	if(rc != PWN_OK) return rc;
 	uint32_t *hs = sink ? g->h_sbuf[slot] : NULL;
 	float *hz = (g->flags & PWN_FRAME_ZBUF) ? g->h_zbuf[slot] : NULL;
-	rc = run_all(g, [g, cam, sec, hs, hz](int i) { return pwn_i_tiled_submit(g->m[i], cam, sec, hs, hz, 0); });
-	if(rc != PWN_OK) return frame_failed(g, rc);
+	// (posted, not waited for: the members enqueue the frame while the host goes on; a failure shows at the frame's pwn_wait_frame)
+	std::array<float, 16> cm;
+	memcpy(cm.data(), cam, sizeof(float) * 16);
+	(void)post(g, [g, cm, sec, hs, hz](int i) { return pwn_i_tiled_submit(g->m[i], cm.data(), sec, hs, hz, 0); });
 	g->in_flight[slot] = true; g->delivered[slot] = false; g->sec[slot] = sec;
 	g->fifo[g->fifo_n++] = slot;
-	memset(&g->done[slot], 0, sizeof(pwn_frame));
-	g->done[slot].seq = ++g->frame_seq;
+	memset(&g->fdone[slot], 0, sizeof(pwn_frame));
+	g->fdone[slot].seq = ++g->frame_seq;
 	return PWN_OK;
 }
 
@@ -461,7 +555,7 @@ static int deliver_oldest(pwn_group *g)
 	if(rc != PWN_OK) return frame_failed(g, rc);
 	for(int i = 1; i < g->fifo_n; i++) g->fifo[i - 1] = g->fifo[i];
 	g->fifo_n--;
-	pwn_frame &f = g->done[slot];
+	pwn_frame &f = g->fdone[slot];
 	note_times(g, &f);
 	f.sec_current = g->sec[slot];
 	f.sbuf = (g->flags & PWN_FRAME_SBUF) ? g->h_sbuf[slot] : NULL;
@@ -474,14 +568,14 @@ static int deliver_oldest(pwn_group *g)
 int pwn_group_wait_frame(pwn_ctx *h, int slot, pwn_frame *out)
 {
 	pwn_group *g = h->grp;
-	if(slot < 0 || slot >= g->nslots || g->done[slot].seq == 0) return PWN_EINVAL;
+	if(slot < 0 || slot >= g->nslots || g->fdone[slot].seq == 0) return PWN_EINVAL;
 	while(g->in_flight[slot] && !g->delivered[slot])
 	{
 		const int rc = deliver_oldest(g);
 		if(rc != PWN_OK) return rc;
 	}
 	g->in_flight[slot] = false;
-	if(out != NULL) *out = g->done[slot];
+	if(out != NULL) *out = g->fdone[slot];
 	return PWN_OK;
 }
 
@@ -495,18 +589,24 @@ int pwn_group_frame_ready(pwn_ctx *h, int slot)
 int pwn_group_get_stats(pwn_ctx *h, pwn_stats *out)
 {
 	pwn_group *g = h->grp;
+	std::vector<pwn_stats> st((size_t)g->n);
+	pwn_stats *sp = st.data();
+	const int rc = run_all(g, [g, sp](int i) { return pwn_get_stats(g->m[i], &sp[i]); });
+	if(rc != PWN_OK) return rc;
 	pwn_stats sum = h->stats;
 	bool first = true;
 	for(int i = 0; i < g->n; i++)
 	{
-		pwn_stats s;
-		const int rc = pwn_get_stats(g->m[i], &s);
-		if(rc != PWN_OK) return rc;
 		if(!g->m[i]->counters_on && !g->m[i]->wave_log_on) continue;
 		// counted frames: every member counts its strip
-		uint64_t *a = (uint64_t *)&sum, *b = (uint64_t *)&s;
-		if(first) { sum.rays = sum.steps = sum.portals = sum.sphere_tests = sum.exhausted = sum.wave_steps = 0; memset(sum.wave_paths, 0, sizeof(sum.wave_paths)); memset(sum.regions, 0, sizeof(sum.regions)); sum.phase_passes = sum.phase_lanes = sum.wave_time = sum.waves = 0; sum.kernel_span = 0; first = false; }
-		(void)a; (void)b;
+		const pwn_stats &s = st[(size_t)i];
+		if(first)
+		{
+			sum.rays = sum.steps = sum.portals = sum.sphere_tests = sum.exhausted = sum.wave_steps = 0;
+			memset(sum.wave_paths, 0, sizeof(sum.wave_paths)); memset(sum.regions, 0, sizeof(sum.regions));
+			sum.phase_passes = sum.phase_lanes = sum.wave_time = sum.waves = sum.kernel_span = 0;
+			first = false;
+		}
 		sum.rays += s.rays; sum.steps += s.steps; sum.portals += s.portals; sum.sphere_tests += s.sphere_tests; sum.exhausted += s.exhausted; sum.wave_steps += s.wave_steps;
 		for(int k = 0; k < 8; k++) sum.wave_paths[k] += s.wave_paths[k];
 		for(int k = 0; k < 32; k++) sum.regions[k] += s.regions[k];
@@ -524,7 +624,5 @@ int pwn_group_screen_upscale(pwn_ctx *h, const uint32_t *sbuf, int scale, int pi
 	pwn_group *g = h->grp;
 	if(sbuf == NULL) sbuf = g->last_sbuf;
 	if(sbuf == NULL) { snprintf(h->err, sizeof(h->err), "no frame was delivered yet"); return PWN_EINVAL; }
-	const int rc = pwn_screen_upscale(g->m[0], sbuf, scale, pitch_bytes, pixels);
-	if(rc != PWN_OK) snprintf(h->err, sizeof(h->err), "%s", g->m[0]->err);
-	return rc;
+	return pwn_group_on_member0(h, [sbuf, scale, pitch_bytes, pixels](pwn_ctx *m0) { return pwn_screen_upscale(m0, sbuf, scale, pitch_bytes, pixels); });
 }

@@ -243,7 +243,12 @@ bool pwn_tiled_busy(pwn_ctx *c);        // frames of the row tiling in flight
 // frame stays on the devices and is gathered on member 0), and the switch that makes the tiling deliver to the host
 int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *host_sbuf, float *host_zbuf, int carry_depth);
 int pwn_i_tiled_sink(pwn_ctx *c);
-int pwn_i_upload_live(pwn_ctx *c, const pwn_sphere *s, int n);      // pwn_api.cpp: level_prepare_render's binning + upload of a compact list
+// pwn_api.cpp: level_prepare_render's binning of a compact list of live spheres (no context: PWN_ETOOBIG where the lists would not
+// fit on chip), and its upload into one context; the object table of pwn_upload_spheres by itself
+struct pwn_binned { std::vector<pwn_sphere> s; std::vector<int32_t> off, idx; };
+int pwn_i_bin_spheres(const pwn_sphere *s, int n, pwn_binned *out);
+int pwn_i_upload_binned(pwn_ctx *c, const pwn_binned &b);
+void pwn_i_set_object_table(pwn_ctx *c, const pwn_sphere *s, int n);
 // pwn_group.cpp: the entry points of include/pwnhip.h when the context is a group's handle
 int pwn_group_set_option(pwn_ctx *h, int option, int value);
 int pwn_group_level_mem(pwn_ctx *h, const char *text, int len);
@@ -261,4 +266,7 @@ int pwn_group_host_register(pwn_ctx *h, void *base, size_t bytes);
 int pwn_group_host_unregister(pwn_ctx *h, void *base);
 int pwn_group_set_timeouts(pwn_ctx *h, int init_ms, int wait_ms);
 pwn_ctx *pwn_group_member(pwn_ctx *h, int i);                 // member i (0 = the one that holds the level and the object table)
+int pwn_group_sync(pwn_ctx *h);                               // everything posted to the members is through
+#include <functional>
+int pwn_group_on_member0(pwn_ctx *h, const std::function<int(pwn_ctx *)> &fn);      // ... on member 0's thread
 void pwn_group_destroy(pwn_ctx *h);

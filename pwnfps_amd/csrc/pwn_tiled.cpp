@@ -602,18 +602,15 @@ struct local_transport : pwn_transport
 	}
 	int end()
 	{
-		// 1. every receive of the group is posted: the place, and an event behind what this stream has enqueued so far (whatever still
-		//    reads or writes the place is in front of it)
-		hipEvent_t ev_free = NULL;
+		// 1. every receive of the group is posted: the place.  (No event "the place is free": what the tiling receives into -- halo rows
+		//    and foreign strips of a slot's pre-blur plane, a root's assembled frame -- was last used by the frame NSLOT frames back, which
+		//    was delivered, i.e. waited for on the host, before the slot was handed out again.  An event here would be a second wait
+		//    between two queues per message: 20-50 us each beside a running trace grid.)
+		const hipEvent_t ev_free = NULL;
 		for(size_t i = 0; i < ops.size(); i++)
 		{
 			const op &o = ops[i];
 			if(o.is_send) continue;
-			if(ev_free == NULL)
-			{
-				ev_free = evs[ev_next++ % PWN_HUB_RING];
-				if(hipEventRecord(ev_free, stream) != hipSuccess) { snprintf(err, sizeof(err), "hipEventRecord failed"); return PWN_EHIP; }
-			}
 			pwn_hub_box *b = box(o.peer, rank);
 			const unsigned long long n = b->posted.load(std::memory_order_relaxed);
 			int rc = wait_until(&b->consumed, n + 1 >= PWN_HUB_RING ? n + 1 - PWN_HUB_RING : 0, "get through its earlier messages", o.peer);       // (room in the ring: this rank's own progress)
@@ -637,7 +634,7 @@ struct local_transport : pwn_transport
 			if(rc != PWN_OK) return rc;
 			const pwn_hub_post m = b->post[n % PWN_HUB_RING];
 			if(m.bytes != o.bytes) { snprintf(err, sizeof(err), "rank %d: member %d expects %zu bytes where %zu are sent", rank, o.peer, m.bytes, o.bytes); hub->failed.store(1); return PWN_EINVAL; }
-			hipError_t he = hipStreamWaitEvent(stream, m.ev_free, 0);
+			hipError_t he = m.ev_free != NULL ? hipStreamWaitEvent(stream, m.ev_free, 0) : hipSuccess;
 			if(he == hipSuccess && o.bytes)
 				he = m.device == device ? hipMemcpyAsync(m.dst, o.src, o.bytes, hipMemcpyDeviceToDevice, stream)
 				                        : hipMemcpyPeerAsync(m.dst, m.device, o.src, device, o.bytes, stream);
@@ -756,6 +753,9 @@ struct pwn_tiled
 	// frames: submitted (traced, group opened), blurred (blur enqueued), gathered (gather in a group), delivered
 	unsigned long long submitted, blurred, gathered, delivered;
 	pwn_tiled_info info;
+	// PWN_DBG_TILED_PROF: host time per frame inside pwn_tiled_submit (the trace launch; the halo group; the blur; the gather group)
+	// and pwn_tiled_wait (its events; the group's meeting), printed when the tiling goes
+	bool prof; double p_trace, p_halo, p_blur, p_gather, p_events, p_meet, p_rest; unsigned long long p_frames;
 };
 
 #define GRP_HEAD(c) ((c) != NULL && (c)->grp != NULL && (c)->grp_head)
@@ -921,6 +921,10 @@ void pwn_tiled_destroy(pwn_ctx *c)
 {
 	pwn_tiled *t = c->tiled;
 	if(t == NULL) return;
+	if(t->prof && t->p_frames)
+		fprintf(stderr, "tiling rank %d of %d, %llu frames, host us per frame: submit = trace launch %.1f + halo group %.1f + blur %.1f + gather group %.1f; wait = events %.1f + meeting %.1f + rest %.1f\n",
+			t->rank, t->world, t->p_frames, t->p_trace / t->p_frames, t->p_halo / t->p_frames, t->p_blur / t->p_frames, t->p_gather / t->p_frames,
+			t->p_events / t->p_frames, t->p_meet / t->p_frames, t->p_rest / t->p_frames);
 	(void)hipSetDevice(c->device);
 	(void)hipDeviceSynchronize();
 	// (the device is idle: no copy of the tables is in use, and the events that said so -- ev_t, handed to the trace
@@ -989,6 +993,7 @@ extern "C" int pwn_tiled_init(pwn_ctx *c, int rank, int world, const void *id, i
 	t->cs[0] = c->stream; t->cs[1] = (c->frame_overlap && c->stream2 != NULL) ? c->stream2 : c->stream;
 	t->ncs = t->cs[1] != t->cs[0] ? 2 : 1;
 	t->instream = c->tiled_choreo != PWN_TILED_CHOREO_SPLIT;
+	t->prof = getenv("PWN_DBG_TILED_PROF") != NULL;
 	c->tiled = t;
 
 	int rc = PWN_OK;
@@ -1558,6 +1563,8 @@ int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *hos
 	t->fcost_mul[s] = c->cost_mul; t->fcost_div[s] = c->cost_div;
 	if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_k1[s], cs));
 	HIPCHK(c, hipEventRecord(t->ev_t[s], cs));
+	double tp0 = 0.0, tp1 = 0.0, tp2 = 0.0;
+	if(t->prof) { tp0 = now_us(); t->p_trace += tp0 - t_in; }
 
 	if(t->instream)
 	{
@@ -1566,6 +1573,7 @@ int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *hos
 		rc = exchange_halo(c, t, s, cs, y0, y1);
 		if(rc != PWN_OK) return rc;
 		if(t->timed[s]) HIPCHK(c, hipEventRecord(t->ev_g3[s], cs));
+		if(t->prof) { tp1 = now_us(); t->p_halo += tp1 - tp0; }
 		// Host sink: the words of a frame go out behind this rank's copy of its strip to the host, on the copy's stream (the
 		// compute stream does not wait for PCIe) -- and one submit late, IN FRONT of this frame's copy: the transport runs
 		// its launches in the order they were made, so G1(f+1) would otherwise wait for G2(f) and with it for copy f.
@@ -1576,12 +1584,14 @@ int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *hos
 		}
 		rc = enqueue_blur(c, t, f);
 		if(rc != PWN_OK) return rc;
+		if(t->prof) { tp2 = now_us(); t->p_blur += tp2 - tp1; }
 		t->blurred = f + 1;
 		if(!t->sink)
 		{
 			rc = gather_frames(c, t, f, f + 1, cs);
 			if(rc != PWN_OK) return rc;
 		}
+		if(t->prof) { t->p_gather += now_us() - tp2; t->p_frames++; }
 		t->submitted = f + 1;
 		t->enqueue_us[s] = (float)(now_us() - t_in);
 		return PWN_OK;
@@ -1674,6 +1684,8 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	const int s = (int)(d % NSLOT);
 	const size_t n = (size_t)c->w * (size_t)c->h;
 	int rc;
+	const double tw0 = t->prof ? now_us() : 0.0;
+	double tw1 = 0.0, tw2 = 0.0;
 	// no newer frame has enqueued this one's blur / carried its gather: do both now
 	for(; t->blurred <= d; t->blurred++)
 	{
@@ -1695,6 +1707,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	}
 	if(t->sink) { rc = wait_event(c, t, t->ev_h[s], "the copy of its strip into the host frame", d); if(rc != PWN_OK) return rc; }      // this rank's own strip is in the host frame
 
+	if(t->prof) { tw1 = now_us(); t->p_events += tw1 - tw0; }
 	// ---- a group's members meet here: every member's kernels and copies of this frame are through, its two words are in ITS pinned
 	// memory (fetch_words), and everybody reads everybody's from there
 	if(t->hub != NULL)
@@ -1707,6 +1720,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 			return rc;
 		}
 	}
+	if(t->prof) { tw2 = now_us(); t->p_meet += tw2 - tw1; }
 	// ---- the ranks' words of this frame (they came to pinned memory behind the group that carried them: fetch_words)
 	const uint32_t *h = t->h_missv + (size_t)s * ((size_t)t->world + 1) * 2;
 	uint32_t cost[MAXW];
@@ -1787,6 +1801,7 @@ extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)
 	}
 	t->delivered = d + 1;
 	t->info.frames++;
+	if(t->prof) t->p_rest += now_us() - tw2;
 	if(t->ncs > 1) pwn_room_frame_done(c);
 	if(out != NULL)
 	{

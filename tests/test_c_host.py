@@ -83,6 +83,31 @@ def test_host_frame_is_the_reference_frame(host_bin, cases, tmp_path, oracle_lib
 
 
 @pytest.mark.gpu
+def test_one_process_several_gpus_shows_the_same_frames(host_bin):
+    """-G N: the SAME process and the same loop (main.c:93-109), its one handle made by pwn_init_multi -- here N members on the one
+    device of -d 0.  Frame by frame what the one-GPU loop shows: scripted spheres through the handle's one object table, a
+    turning camera, depth carried from call to call; blocking and with three frames in flight."""
+    args = [host_bin, level_path("pwnfps_level"), "-g", os.path.join(ROOT, "pwnfps_amd", "data", "game_objects.txt"),
+            "-w", "640", "-h", "360", "-x", "2", "-n", "12", "-t", "0.05", "-a", "0.07", "-v", "1"]
+    a = subprocess.run(args, capture_output=True, timeout=300)
+    assert a.returncode == 0, a.stderr.decode()
+    fa = re.findall(r"frame (\d+) sec (\S+) fnv64 ([0-9a-f]{16})", a.stdout.decode())
+    sa = re.search(r"surface fnv64 ([0-9a-f]{16})", a.stdout.decode()).group(1)
+    assert len(fa) == 12
+    for extra in (["-G", "3", "-d", "0"], ["-G", "2", "-d", "0", "-q", "3"]):
+        b = subprocess.run(args + extra, capture_output=True, timeout=300)
+        assert b.returncode == 0, (extra, b.stderr.decode())
+        out = b.stdout.decode()
+        assert re.findall(r"frame (\d+) sec (\S+) fnv64 ([0-9a-f]{16})", out) == fa, extra
+        assert re.search(r"surface fnv64 ([0-9a-f]{16})", out).group(1) == sa, extra
+        if "-q" not in extra:
+            assert "group of 3 in one process" in out and "12 frames" in out
+    # -G goes with one process
+    c = subprocess.run(args + ["-G", "2", "-W", "2"], capture_output=True, timeout=60)
+    assert c.returncode == 2
+
+
+@pytest.mark.gpu
 def test_host_frames_in_flight_present_the_same_frames(host_bin):
     """-q 3: the loop of main.c:93-140 with three frames in flight (pinned sbuf + surface through
     pwn_submit_frame / pwn_wait_frame) shows, frame by frame, what the blocking loop shows:
@@ -145,8 +170,8 @@ def test_host_row_tiled_over_three_processes(host_bin, tmp_path):
             assert re.search(r"surface fnv64 ([0-9a-f]{16})", o.decode()).group(1) == sa
 
 
-    # -G 1: the gather's root rotates (pwn_tiled_gather_root): frame f is presented by rank f mod 3, the last one (7) by rank 1
-    procs = [subprocess.Popen(base + ["-W", "3", "-R", str(r), "-I", idfile, "-N", "launch3", "-T", "shm", "-G", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    # -O 1: the gather's root rotates (pwn_tiled_gather_root): frame f is presented by rank f mod 3, the last one (7) by rank 1
+    procs = [subprocess.Popen(base + ["-W", "3", "-R", str(r), "-I", idfile, "-N", "launch3", "-T", "shm", "-O", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
              for r in range(3)]
     for r, p in enumerate(procs):
         o, e = p.communicate(timeout=300)

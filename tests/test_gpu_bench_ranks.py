@@ -25,6 +25,41 @@ def free_port():
     return p
 
 
+@pytest.mark.parametrize("members,size,golden", [(2, (3840, 2160), "a95833dac9624326"), (4, (1280, 720), "078fb94a5cd068f5")])
+def test_bench_single_process_over_one_device(members, size, golden):
+    """bench.py --gpus N --single-process: ONE process, one handle (pwn_init_multi), the library's member threads; here with every
+    member on device 0 (PWN_BENCH_ONE_DEVICE).  The line's keys, and the golden frame from the resident loop, the delivered
+    loop and the blocking call."""
+    env = dict(os.environ)
+    env.update(PWN_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(members), "--single-process", "--steps", "6", "--warmup", "2", "--min-time", "0.2",
+           "--time-every", "2", "--width", str(size[0]), "--height", str(size[1])]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == members and d["single_process"] is True and d["transport"] == "local" and d["devices"] == [0] * members
+    assert d["steps"] == 6 and d["value"] > 0 and d["scaling"] == "strong" and d["unit"] == "Mpixels/s"
+    assert d["frame_fnv64"] == golden
+    if size == (3840, 2160):
+        assert d["parity_vs_reference_golden"] is True
+    assert "ONE DEVICE" in d["metric"]
+    t = d["tiling"]
+    assert t["cuts"][0] == 0 and t["cuts"][-1] == size[1] and len(t["cuts"]) == members + 1 and t["frames_redone"] == 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["kernel"] == "pwn_trace_kernel" and r["achieved"] > 0 and r["pixels_per_launch"] <= size[0] * size[1]
+    q = d["d2h_inclusive"]
+    assert q["value"] > 0 and q["last_frame_equals_resident_frame"] is True
+    assert q["blocking_call_mpix_s"] > 0 and q["blocking_call_frame_equals_resident_frame"] is True
+    # under torch.distributed.run it refuses: it IS the one process
+    cmd2 = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process"]
+    if members == 2:
+        p2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+        assert p2.returncode != 0 and "one process" in (p2.stderr + p2.stdout)
+
+
 @pytest.mark.parametrize("world,size,golden", [(2, (3840, 2160), "a95833dac9624326"), (3, (1280, 720), "078fb94a5cd068f5")])
 def test_bench_with_ranks_on_one_device(world, size, golden):
     env = dict(os.environ)
