@@ -20,7 +20,6 @@
 #include <time.h>
 #include <new>
 #include <atomic>
-#include <condition_variable>
 #include <array>
 #include <functional>
 #include <memory>
@@ -46,7 +45,6 @@ struct pwn_group
 	// posted, on every member.  The first failure marks the group broken: the members skip what is queued behind it, and the
 	// next call that waits reports it.
 	std::thread th[MAXM];
-	std::mutex mu; std::condition_variable cv;
 	struct job_t { std::function<int(int)> fn; bool always; } jobs[GROUP_RING];
 	std::atomic<unsigned long long> posted;                 // jobs 1..posted exist (job k in jobs[k % GROUP_RING])
 	std::atomic<unsigned long long> done[MAXM];             // ... and member i is through jobs 1..done[i]
@@ -67,6 +65,7 @@ struct pwn_group
 	int fifo[PWN_MAX_SLOTS + 1], fifo_n;        // slots in submission order, oldest first
 	uint64_t frame_seq;
 	const uint32_t *last_sbuf;                   // where the last blocking call delivered (pwn_screen_upscale(NULL, ...), main.c:108)
+	unsigned long long calls; int stall_member, stall_ms; unsigned long long stall_call;      // PWN_DBG_GROUP_STALL (pwn_group_trace_screen_centred)
 	pwn_tiled_frame tf[MAXM];
 };
 
@@ -111,10 +110,12 @@ static void worker(pwn_group *g, int i)
 		// a frame loop posts jobs back to back: look for the next one for a while (~0.2 ms) before going to sleep
 		unsigned long long now = g->posted.load(std::memory_order_acquire);
 		for(unsigned spins = 0; now == seen && spins < 100000u && !g->quit.load(std::memory_order_relaxed); spins++) now = g->posted.load(std::memory_order_acquire);
-		if(now == seen)
+		// (asleep in slices that grow to 0.2 ms: an idle group costs its threads a few thousand wake-ups a second, and a job posted
+		// to a sleeping group starts that much late -- once)
+		for(long slice = 20 * 1000; now == seen && !g->quit.load(std::memory_order_relaxed); slice = slice < 200 * 1000 ? slice * 2 : slice)
 		{
-			std::unique_lock<std::mutex> lk(g->mu);
-			g->cv.wait_for(lk, std::chrono::milliseconds(2), [&] { return g->posted.load(std::memory_order_acquire) != seen || g->quit.load(); });
+			struct timespec ts = { 0, slice };
+			nanosleep(&ts, NULL);
 			now = g->posted.load(std::memory_order_acquire);
 		}
 		if(now == seen) { if(g->quit.load()) return; continue; }
@@ -155,11 +156,7 @@ static unsigned long long post(pwn_group *g, std::function<int(int)> fn, bool al
 				if(spins > 100000) { struct timespec ts = { 0, 20 * 1000 }; nanosleep(&ts, NULL); }
 	g->jobs[id % GROUP_RING].fn = std::move(fn);
 	g->jobs[id % GROUP_RING].always = always;
-	{
-		std::lock_guard<std::mutex> lk(g->mu);
-		g->posted.store(id, std::memory_order_release);
-	}
-	g->cv.notify_all();
+	g->posted.store(id, std::memory_order_release);
 	if(g->prof) g->p_jobs++;
 	return id;
 }
@@ -274,6 +271,8 @@ extern "C" int pwn_init_multi(pwn_ctx **out, const int *devices, int ndev, int w
 	if(g == NULL || h == NULL) { delete g; delete h; return PWN_ENOMEM; }
 	g->n = ndev; g->head = h; g->mode = MODE_NONE; g->posted.store(0); g->quit.store(false); g->broken.store(false);
 	g->err_rc = PWN_OK; g->err_member = 0; g->err_text[0] = 0;
+	g->calls = 0; g->stall_member = -1; g->stall_ms = 0; g->stall_call = 0;
+	if(const char *e = getenv("PWN_DBG_GROUP_STALL")) { int a = -1, c = 0; unsigned long long b = 0; if(sscanf(e, "%d:%llu:%d", &a, &b, &c) == 3) { g->stall_member = a; g->stall_call = b; g->stall_ms = c; } }
 	g->prof = getenv("PWN_DBG_GROUP_PROF") != NULL; g->p_join = 0.0; g->p_jobs = g->p_joins = 0;
 	for(int i = 0; i < MAXM; i++) { g->p_job[i] = 0.0; g->done[i].store(0); }
 	g->init_ms = g->wait_ms = 0; g->nslots = 0; g->flags = 0; g->fifo_n = 0; g->frame_seq = 0; g->last_sbuf = NULL;
@@ -334,7 +333,6 @@ void pwn_group_destroy(pwn_ctx *h)
 	tiling_down(g);
 	(void)join(g, g->posted.load());
 	g->quit.store(true);
-	g->cv.notify_all();
 	for(int i = 0; i < g->n; i++) if(g->th[i].joinable()) g->th[i].join();
 	frames_free(g);
 	if(g->prof && g->p_jobs)
@@ -487,8 +485,12 @@ int pwn_group_trace_screen_centred(pwn_ctx *h, const float cam[16], float sec, u
 	if(rc != PWN_OK) return rc;
 	std::array<float, 16> cm;
 	memcpy(cm.data(), cam, sizeof(float) * 16);
-	rc = run_all(g, [g, cm, sec, sbuf, zbuf](int i)
+	const unsigned long long call = ++g->calls;
+	rc = run_all(g, [g, cm, sec, sbuf, zbuf, call](int i)
 	{
+		// test hook (tests/test_gpu_group.py): PWN_DBG_GROUP_STALL=member:call:milliseconds -- that member's thread is late to that
+		// blocking call by so long (a device that stops answering): the others must come back with PWN_ETIMEDOUT at the deadline
+		if(g->stall_member == i && g->stall_call == call) { struct timespec ts = { g->stall_ms / 1000, (long)(g->stall_ms % 1000) * 1000000L }; nanosleep(&ts, NULL); }
 		// (carry_depth: one call at a time -- every call's depth lives in the same plane, so that a pixel whose primary ray
 		// runs out of steps keeps the previous call's value, trace.h:677, as on one device)
 		int r = pwn_i_tiled_submit(g->m[i], cm.data(), sec, sbuf, zbuf, 1);

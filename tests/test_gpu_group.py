@@ -209,6 +209,35 @@ def test_upscale_of_the_delivered_frame_and_what_a_group_refuses(oracle_lib, cas
     r1.close()
 
 
+def test_a_member_that_stops_answering_is_an_error_not_a_hang(oracle_lib, cases, monkeypatch):
+    """the reference's error model is print-and-return (level.h:35-37,110-115); a group adds a failure the reference cannot have -- a
+    device that does not answer -- and that comes back as PWN_ETIMEDOUT at the deadline (pwn_tiled_set_timeouts on the handle),
+    naming the member; the next call sets the tiling up again and delivers the golden frame"""
+    import time
+    import pwnfps_amd
+    from pwnfps_amd import _lib
+    monkeypatch.setenv("PWN_DBG_GROUP_STALL", "2:2:2500")          # member 2 is 2.5 s late to the second blocking call
+    c = _case(cases, "level_spawn_1280x720")
+    r = _group(c["w"], c["h"], 3)
+    cam = _load(r, c)
+    r.tiled_set_timeouts(20.0, 0.5)
+    sb, _ = r.trace_screen_centred(cam, c["sec"])
+    assert oracle_lib.fnv64(sb) == c["post"]
+    t0 = time.perf_counter()
+    with pytest.raises(pwnfps_amd.PwnError) as e:
+        r.trace_screen_centred(cam, c["sec"])
+    dt = time.perf_counter() - t0
+    assert e.value.code in (_lib.PWN_ETIMEDOUT, _lib.PWN_EHIP) and "member" in str(e.value), str(e.value)
+    assert dt < 4.0, dt                                    # (the late member's thread is waited for when the tiling is taken down: 2.5 s, not for ever)
+    sb, zb = r.trace_screen_centred(cam, c["sec"])
+    assert oracle_lib.fnv64(sb) == c["post"] and oracle_lib.fnv64(zb) == c["z"]
+    r.frames_config(2, sbuf=True)
+    r.submit_frame(cam, c["sec"], 0)
+    assert oracle_lib.fnv64(r.wait_frame(0)["sbuf"]) == c["post"]
+    r.frames_config(0)
+    r.close()
+
+
 def test_two_devices_over_rccl(oracle_lib, cases):
     """the same handle on two real GPUs: one RCCL communicator rank per device, brought up inside the process"""
     import torch
