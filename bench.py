@@ -713,6 +713,7 @@ def main():
             u = [pwnfps_amd.Renderer.tiled_unique_id(tp) if rank == 0 else None]
             dist.broadcast_object_list(u, src=0)
             err = None
+            timed_out = 0.0
             try:
                 board.mark(tag + "tiled_init", transport=tp, limit_s=lib_init_s)
                 die_here(tag + "tiled_init")
@@ -729,13 +730,23 @@ def main():
                 torch.cuda.synchronize()
             except Exception as e:                                   # noqa: BLE001 -- reported in the line
                 err = "rank %d: %s" % (rank, e)
+                timed_out = 1.0 if getattr(e, "code", 0) == pwnfps_amd._lib.PWN_ETIMEDOUT else 0.0
                 board.note_error(err)
             board.mark(tag + "agree", transport=tp, error=err)
-            good = torch.tensor([0.0 if err else 1.0], dtype=torch.float64)
+            good = torch.tensor([0.0 if err else 1.0, -timed_out], dtype=torch.float64)
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
-            return float(good.item()) == 1.0, err
+            bring_up.timed_out = float(good[1].item()) < 0.0          # a deadline of the library passed on some rank
+            return float(good[0].item()) == 1.0, err
+        bring_up.timed_out = False
 
         up, err = bring_up(transport)
+        if not up and transport == "rccl" and bring_up.timed_out:
+            # A bring-up that ran into its deadline inside ncclCommInitRank leaves a helper thread behind in RCCL (pwn_tiled.cpp:
+            # there is no communicator to abort yet).  Should the missing peer turn up later, that thread finishes the initialisation
+            # beside whatever this process does next: no fallback in the same process -- the diagnostic line, and a fresh start.
+            board.mark("bring_up_timed_out", error=err or "on another rank", transport=transport)
+            dog.bail("the RCCL bring-up ran into the library's deadline (%s): no fallback to the shared-memory transport in a process that may still "
+                     "hold a thread inside RCCL -- start again" % (err or "on another rank (see stage_reached)"))
         if not up and transport == "rccl":
             # (an error every rank can return from -- a communicator that cannot be made in this environment, or one that
             # did not come up within the library's deadline.  A peer that DIED leaves the agreement above hanging: that ends
@@ -825,11 +836,42 @@ def main():
             for _ in range(min(n, behind)):
                 note(r.tiled_wait())
 
+    class LegFailed(RuntimeError):
+        pass
+
+    def all_ranks_ok(err):
+        """the collective that closes a piece of work on every rank, whatever happened in it locally: True if no rank failed.  Every
+        rank makes the SAME sequence of collectives, exception or not -- a rank that raised and went off to some other collective
+        would leave the others in a barrier that never completes"""
+        if world == 1:
+            if err is not None:
+                raise err
+            return True
+        flag = torch.tensor([0.0 if err is not None else 1.0], dtype=torch.float64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return float(flag.item()) == 1.0
+
+    def guarded(fn):
+        """fn() on every rank, then the agreement: raises LegFailed on EVERY rank if it raised on any"""
+        err = None
+        try:
+            # test hook (tests/test_gpu_bench_ranks.py): PWN_BENCH_FAIL_LEG=LEG:RANK -- that rank's share of that leg raises
+            hook = os.environ.get("PWN_BENCH_FAIL_LEG", "")
+            if hook and hook.rsplit(":", 1)[0] == leg_name[0] and int(hook.rsplit(":", 1)[1]) == rank:
+                raise RuntimeError("injected failure (PWN_BENCH_FAIL_LEG)")
+            fn()
+            torch.cuda.synchronize()
+        except Exception as e:                                       # noqa: BLE001 -- agreed on below, reported in the line
+            err = e
+            board.note_error("rank %d: %s: %s" % (rank, leg_name[0], e))
+        if not all_ranks_ok(err):
+            raise LegFailed(("rank %d: %s" % (rank, err)) if err is not None else "another rank failed (see stage_reached)")
+
     def block():
         """exactly K steps between barrier + synchronize; seconds, max over ranks"""
         barrier()
         t0 = time.perf_counter()
-        run(args.steps)
+        guarded(lambda: run(args.steps))
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
@@ -839,7 +881,7 @@ def main():
         """warm-up, then K-step blocks until min_time seconds were timed: (median block seconds, all blocks)"""
         if world > 1:
             board.mark("%s: warm-up" % leg_name[0])
-        run(warmup)
+        guarded(lambda: run(warmup))
         diag_reset()
         blocks = []
         while True:
@@ -1028,6 +1070,18 @@ def main():
             # streams a trace shares the chip with the neighbour frames' kernels), the two grouped exchanges (halo = this
             # frame's border rows, gather = its finished strips + the ranks' words), host time inside pwn_tiled_submit per frame, the rows of its strip and what they cost
             line["tiling"]["per_rank"] = ranks
+            if first_legs is not None:
+                # the forms measured with the headline's own blocks; `value` is the default's (the contract: the configuration the metric
+                # names), `best` the fastest of them on this node; predicted_ms = DESIGN.md 6's link model on this run's kernel times
+                line["tiling"]["first_legs"] = first_legs
+                ok_legs = {k: v for k, v in first_legs.items() if v.get("value")}
+                if ok_legs:
+                    bk = max(ok_legs, key=lambda k: ok_legs[k]["value"])
+                    line["best"] = {"leg": bk, "value": ok_legs[bk]["value"], "unit": "Mpixels/s", "measured_ms": ok_legs[bk]["measured_ms"],
+                                    "predicted_ms": ok_legs[bk].get("predicted_ms"),
+                                    "note": "host_sink delivers every frame to the host; the others leave it on a device"}
+            if sweep_dead[0] is not None:
+                line["tiling"]["sweep_stopped_by"] = sweep_dead[0]
             if sweep is not None:
                 line["tiling"]["sweep"] = sweep
             if post["note"]:
@@ -1062,33 +1116,85 @@ def main():
         if args.post_timeout > 0:
             dog.arm(args.post_timeout, "the legs after the headline")
 
-    # ---- N > 1, first of the legs after the headline: the metric as SURVEY 8(d) words it (every frame delivered to the host).  In
-    # front of the sweep: should one of the sweep's legs not finish, this figure is in the line that the deadline prints.
+    # ---- N > 1: the forms that the link model expects to matter most, with the headline's own K-step blocks, BEFORE
+    # the long sweep: `value` stays the default's; `best` says which of them a host should pick on this node.
     tiling_up = world > 1
-    if world > 1 and not args.no_d2h:
+    sweep_dead = [None]                  # a leg failed on some rank: what it said; nothing that needs the tiling runs after it
+
+    def link_model(form):
+        """what the form should cost per frame by the link rates DESIGN.md 6 assumes (60 GB/s per direction and xGMI link, 52 GB/s per
+        PCIe link), from THIS run's kernel times: max(kernels of the slowest rank, the exchange that cannot hide)"""
+        if ranks is None:
+            return None
+        k = max((t or 0.0) + (b or 0.0) for t, b in zip(ranks["trace_ms"], ranks["blur_ms"]))
+        strip = 4.0 * w * h / world
+        halo = 2.0 * (tinfo["halo_rows"] * w * 4.0 if tinfo["halo_rows"] else strip * (world - 1)) / 60e9 * 1e3
+        if form == "fixed_root":
+            x = halo + strip / 60e9 * 1e3                      # every link into rank 0 carries one strip per frame
+        elif form == "rotating_root":
+            x = halo + strip / 60e9 * 1e3 / min(2.0, world)    # successive frames' gathers go to different ranks, two in flight
+        elif form == "host_sink":
+            x = max(halo, strip / 52e9 * 1e3)                  # every rank's strip over its own PCIe link, beside the halo rows
+        else:
+            return None
+        return round(max(k, x), 4)
+    first_legs = None
+    if world > 1:
+        first_legs = {"default": {"what": "fixed root (rank 0), in-stream choreography: the headline", "measured_ms": round(dt / args.steps * 1e3, 4),
+                                  "value": round(w * h * args.steps / dt / 1e6, 3), "predicted_ms": link_model("fixed_root")}}
+        leg_name[0] = "first.rotating_root"
+        try:
+            r.tiled_gather_root(True)
+            d2, _bl = leg(max(2, args.warmup // 2), min(args.min_time, 1.0))
+            first_legs["rotating_root"] = {"what": "pwn_tiled_gather_root(ROTATE): frame f gathered on rank f mod N", "measured_ms": round(d2 / args.steps * 1e3, 4),
+                                           "value": round(w * h * args.steps / d2 / 1e6, 3), "predicted_ms": link_model("rotating_root")}
+            r.tiled_gather_root(False)
+        except LegFailed as e:
+            first_legs["rotating_root"] = {"error": str(e)}
+            sweep_dead[0] = "first.rotating_root: %s" % e
+    if world > 1 and not args.no_d2h and sweep_dead[0] is None:
         leg_name[0] = "host_sink"
         pcie = host_sink_leg(r, args, w, h, cam, sec, spheres, rank, world, transport, barrier, max_over_ranks,
                              (lambda buf: oracle.fnv64(buf) == frame_hash) if (rank == 0 and oracle is not None and frame_hash is not None) else None,
                              mark=board.mark)
         tiling_up = False                 # (the leg leaves the tiling shut down)
+        if pcie and pcie.get("value"):
+            first_legs["host_sink"] = {"what": "pwn_tiled_host_sink: every rank's strip over its own PCIe link into one host frame, no gather",
+                                       "measured_ms": pcie["ms_per_step"], "value": pcie["value"], "predicted_ms": link_model("host_sink")}
+        elif pcie:
+            first_legs["host_sink"] = {"error": pcie.get("error")}
     # ---- N > 1: the same run, other settings, a fraction of a second each: what a first multi-GPU run should look at
-    if world > 1 and args.sweep_time > 0 and not tiling_up:
+    if world > 1 and args.sweep_time > 0 and not tiling_up and sweep_dead[0] is None:
         tiling_up, _ = bring_up(transport, tag="sweep:")
-    if world > 1 and args.sweep_time > 0 and tiling_up:
+    if world > 1 and args.sweep_time > 0 and tiling_up and sweep_dead[0] is None:
         sweep = {}
 
         def point(name, what):
+            # (ADVICE r4: a leg that fails -- a communicator that does not come up a second time, a deadline of the library -- is recorded
+            # and ends the sweep on EVERY rank at the same collective; the line is printed whole, the exit status stays 0)
+            if sweep_dead[0] is not None:
+                sweep[name] = {"skipped": "an earlier leg failed: " + sweep_dead[0]}
+                return
             leg_name[0] = "sweep." + name
-            d2, bl = leg(max(2, args.warmup // 2), args.sweep_time, 60)
+            try:
+                d2, bl = leg(max(2, args.warmup // 2), args.sweep_time, 60)
+            except LegFailed as e:
+                sweep[name] = {"what": what, "error": str(e)}
+                sweep_dead[0] = "%s: %s" % (name, e)
+                return
             pr = per_rank()
             sweep[name] = {"what": what, "value": round(w * h * args.steps / d2 / 1e6, 3), "ms_per_step": round(d2 / args.steps * 1e3, 4),
                            "blocks": len(bl), "trace_ms": pr["trace_ms"], "blur_ms": pr["blur_ms"], "halo_ms": pr["halo_ms"],
                            "gather_ms": pr["gather_ms"], "enqueue_us": pr["enqueue_us"], "rows": pr["rows"]}
+        def alive(fn, *a):
+            """a setter of the tiling between two legs: not on a tiling that a failed leg left in an unknown state"""
+            if sweep_dead[0] is None:
+                fn(*a)
         reserve0 = tinfo["grid_reserve"]
         for rsv in (0, 16, 64):
-            r.tiled_set_reserve(rsv)
+            alive(r.tiled_set_reserve, rsv)
             point("reserve_%d" % rsv, "PWN_TILED_RESERVE = %d workgroups of the persistent trace grid left free for the transport's kernels" % rsv)
-        r.tiled_set_reserve(reserve0)
+        alive(r.tiled_set_reserve, reserve0)
         # the host collecting frames four behind its submissions instead of two
         tiled_depth[0] = 5
         point("five_in_flight", "five frames in flight instead of three (PWN_TILED_SLOTS - 1): the host waits for frame f-4 after submitting f")
@@ -1096,15 +1202,15 @@ def main():
         # the gather spread over the ranks: frame f assembled on rank f mod N (pwn_tiled_gather_root) -- no rank's links carry every
         # frame; what a consumer on every GPU would get
         try:
-            r.tiled_gather_root(True)
+            alive(r.tiled_gather_root, True)
             point("rotating_root", "pwn_tiled_gather_root(ROTATE): frame f is gathered on rank f mod N in turn instead of always on rank 0")
         except Exception as e:                                       # noqa: BLE001
             sweep["rotating_root"] = {"error": str(e)}
         finally:
-            r.tiled_gather_root(False)
+            alive(r.tiled_gather_root, False)
         bal = tinfo["balance_every"]
-        r.tiled_balance(0)
-        r.tiled_set_cuts([min(k * tinfo["rows_per_rank"], h) for k in range(world)] + [h])
+        alive(r.tiled_balance, 0)
+        alive(r.tiled_set_cuts, [min(k * tinfo["rows_per_rank"], h) for k in range(world)] + [h])
         point("equal_strips", "pwn_tiled_balance(0) with the equal split (the reference's static schedule, screen.h:63-64)")
         # rank 0 takes in every other rank's finished strip and sends none: with a taller strip of its own the strips that cross the
         # links into it get shorter (the gather is what the prediction says binds)
@@ -1114,11 +1220,11 @@ def main():
             each = rest // (world - 1) // 8 * 8
             cuts_tall = [0] + [tall + k * each for k in range(world - 1)] + [h]
             try:
-                r.tiled_set_cuts(cuts_tall)
+                alive(r.tiled_set_cuts, cuts_tall)
                 point("rank0_tall", "rank 0 traces %d rows, the others %d: less crosses the links into rank 0 per frame" % (tall, each))
             except Exception as e:                                   # noqa: BLE001 -- (cuts outside the library's bounds: no point)
                 sweep["rank0_tall"] = {"error": str(e)}
-        r.tiled_balance(bal)
+        alive(r.tiled_balance, bal)
         # ---- legs that set the tiling up again, the ones a first multi-GPU run learns most from first.  (The options are read by
         # pwn_tiled_init and refuse to change while a tiling exists: each leg shuts the last one down, then sets its own.)
         t_sweep = time.perf_counter()
@@ -1126,6 +1232,9 @@ def main():
         def again(name, what, comms=False, streams=2, split=False, overlap=True, halo=None, depth=3, rotate=False):
             # every one of these legs makes its communicator(s) anew: together they stay inside --sweep-budget seconds (every rank
             # takes the same decision: the slowest rank's clock)
+            if sweep_dead[0] is not None:
+                sweep[name] = {"skipped": "an earlier leg failed: " + sweep_dead[0]}
+                return
             if max_over_ranks(time.perf_counter() - t_sweep) > args.sweep_budget:
                 sweep[name] = {"skipped": "--sweep-budget %.0f s used up by the legs in front" % args.sweep_budget}
                 return
@@ -1135,7 +1244,10 @@ def main():
             r.set_tiled_streams(streams)
             r.set_tiled_choreo(split)
             r.set_frame_overlap(overlap)
-            ok, _ = bring_up(transport, halo=halo, tag="sweep.%s:" % name)
+            ok, why = bring_up(transport, halo=halo, tag="sweep.%s:" % name)
+            if not ok:
+                sweep[name] = {"what": what, "error": "the tiling did not come up: %s" % (why or "on another rank")}
+                sweep_dead[0] = "%s: the tiling did not come up" % name
             if ok:
                 if rotate:
                     r.tiled_gather_root(True)                        # (gone with the tiling at the next leg's shutdown)
@@ -1144,6 +1256,13 @@ def main():
                     point(name, what)
                 finally:
                     tiled_depth[0] = 3
+        # the other choreography first among the legs that set the tiling up again: the in-stream default has run between GPUs as little as
+        # this one -- the first multi-GPU line says which a host should ask for
+        again("choreo_split", "PWN_OPT_TILED_CHOREO = split (rounds 2-3): the exchanges on a third stream tied to the kernels by events, blur f enqueued by submit f+1 "
+                              "and its gather by submit f+2 (the headline: everything of a frame in order on the frame's own stream)", split=True)
+        if first_legs is not None and "value" in sweep.get("choreo_split", {}):
+            first_legs["choreo_split"] = {"what": "the split choreography (PWN_OPT_TILED_CHOREO), fixed root", "measured_ms": sweep["choreo_split"]["ms_per_step"],
+                                          "value": sweep["choreo_split"]["value"], "predicted_ms": link_model("fixed_root")}
         if transport == "rccl" or os.environ.get("PWN_BENCH_ALL_LEGS"):        # (the test hook runs these lines over shm, where the option changes nothing)
             # a communicator per compute stream: the streams' exchanges do not wait for each other (one communicator runs its
             # launches in the order they were made); then that with three streams and four frames in flight -- on one GPU, a
@@ -1155,8 +1274,6 @@ def main():
             again("three_streams_comm_per_stream_rotating_root", "the same with frame f gathered on rank f mod N: no rank's links carry every frame and the "
                   "streams' exchanges are independent -- the form with the most overlap", comms=True, streams=3, depth=4, rotate=True)
         again("three_streams", "PWN_OPT_TILED_STREAMS = 3: frame f on compute stream f mod 3 (one GPU: a strip-sized frame 8 % faster, a whole 4K frame 8 % slower)", streams=3)
-        again("choreo_split", "PWN_OPT_TILED_CHOREO = split (rounds 2-3): the exchanges on a third stream tied to the kernels by events, blur f enqueued by submit f+1 "
-                              "and its gather by submit f+2 (the headline: everything of a frame in order on the frame's own stream)", split=True)
         again("one_stream", "PWN_OPT_FRAME_OVERLAP 0: every frame's kernels on ONE compute stream", overlap=False)
         again("whole_strips", "halo 0: every rank's whole pre-blur strip to every rank instead of the bounded halo rows", halo=0)
         if transport == "rccl" and args.sweep_nonblocking:

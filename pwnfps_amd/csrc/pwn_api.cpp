@@ -680,8 +680,7 @@ static void unit_div_magic(uint32_t d, uint32_t *magic, int *shift)
 	int s = 0;
 	while((2u << s) < d) s++;                  // 2^s < d <= 2^(s+1)
 	const unsigned long long two = 1ull << (32 + s);
-	const unsigned long long M = (two + d - 1u) / d;
-	if(M >> 32) return;
+	const unsigned long long M = (two + d - 1u) / d;        // < 2^32: 2^s < d
 	*magic = (uint32_t)M; *shift = s;
 }
 
@@ -763,6 +762,8 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	const int th = pwn_trace_tile_h();
 	P.tiles_total = P.tiles_x * ((y1 - y0 + th - 1) / th);
 	unit_div_magic((uint32_t)P.tiles_x, &P.ux_magic, &P.ux_shift);
+	// (the kernel takes unit / tiles_x = unit where there is no shift: true for one unit per row only)
+	if(P.ux_shift < 0 && P.tiles_x != 1) { snprintf(c->err, sizeof(c->err), "no division constant for %d units per row", P.tiles_x); return PWN_EINVAL; }
 	P.blob_bytes = (uint32_t)c->blob.size();
 	P.off_sph = c->off_sph;
 	P.sbuf = d_sbuf; P.zbuf = d_zbuf;

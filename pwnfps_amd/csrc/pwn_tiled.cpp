@@ -803,21 +803,34 @@ extern "C" int pwn_tiled_preflight(pwn_ctx *c, char *json, size_t n)
 	}
 	char err[200]; err[0] = 0;
 	rccl_api *api = rccl_load(err, sizeof(err));
+	// (what goes into the JSON text below as strings comes from the environment, the loader and the driver: quotes, backslashes and
+	// control characters would end the string early -- in the very case the report exists for, a dlopen that failed)
+	auto json_safe = [](char *dst, size_t n, const char *src)
+	{
+		size_t k = 0;
+		for(; src != NULL && *src && k + 1 < n; src++) dst[k++] = (*src == '"' || *src == '\\' || (unsigned char)*src < 0x20) ? '?' : *src;
+		dst[k] = 0;
+	};
+	char err_s[200], path_s[256], pci_s[32], ipc_s[64];
+	json_safe(err_s, sizeof(err_s), err);
+	json_safe(path_s, sizeof(path_s), api ? api->path : "");
 	int ver = 0;
 	if(api != NULL && api->GetVersion != NULL) (void)api->GetVersion(&ver);
 	char pci[32]; pci[0] = 0;
 	if(hipDeviceGetPCIBusId(pci, (int)sizeof(pci), c->device) != hipSuccess) { (void)hipGetLastError(); pci[0] = 0; }
 	const char *ipc = getenv("HSA_ENABLE_IPC_MODE_LEGACY");
+	json_safe(pci_s, sizeof(pci_s), pci);
+	json_safe(ipc_s, sizeof(ipc_s), ipc);
 	const int len = snprintf(json, n,
 		"{\"device\": %d, \"pci\": \"%s\", \"devices_visible\": %d, \"can_access_peer\": [%s], "
 		"\"librccl\": %s%s%s, \"rccl_version\": %d, \"rccl_has_nonblocking_api\": %s, \"rccl_has_abort\": %s, "
 		"\"rccl_mode\": \"%s\", \"choreography\": \"%s\", \"init_timeout_ms\": %d, \"wait_timeout_ms\": %d, \"HSA_ENABLE_IPC_MODE_LEGACY\": %s%s%s%s%s%s}",
-		c->device, pci, count, peers,
-		api ? "\"" : "", api ? api->path : "null", api ? "\"" : "", ver,
+		c->device, pci_s, count, peers,
+		api ? "\"" : "", api ? path_s : "null", api ? "\"" : "", ver,
 		(api && api->CommInitRankConfig && api->CommGetAsyncError) ? "true" : "false", (api && api->CommAbort) ? "true" : "false",
 		rccl_mode_nonblocking() ? "nonblocking" : "blocking", c->tiled_choreo == PWN_TILED_CHOREO_SPLIT ? "split" : "instream", init_timeout_ms(c), wait_timeout_ms(c),
-		ipc ? "\"" : "", ipc ? ipc : "null", ipc ? "\"" : "",
-		api ? "" : ", \"librccl_error\": \"", api ? "" : err, api ? "" : "\"");
+		ipc ? "\"" : "", ipc ? ipc_s : "null", ipc ? "\"" : "",
+		api ? "" : ", \"librccl_error\": \"", api ? "" : err_s, api ? "" : "\"");
 	if(len < 0) return PWN_EINVAL;
 	return len < (int)n ? len : (int)n - 1;
 }

@@ -153,9 +153,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 #include "trace_walk.inc"
 			// trace.h:250,677: out of steps
 			if(--maxsteps == 0 && ev == 0) ev = EV_EXHAUSTED;
-			// (Round 4: two cell steps per trip, so that what a step hands to the next one -- the cell word just fetched, the
-			// distance -- needs no register copy at the back edge: the two v_mov per step are gone in the ISA and the launch is
-			// as long as before, 0.3386 against 0.3371 ms at 4K.  Commit fe41695, profiles/r4/walk_variants.txt.)
 		} while(ev == 0);
 		// what the ray ended on is read back from the register: without this the compiler keeps
 		// "ev == EV_EXHAUSTED" as a lane mask that it updates in every iteration of the walk

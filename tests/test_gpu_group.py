@@ -238,6 +238,17 @@ def test_a_member_that_stops_answering_is_an_error_not_a_hang(oracle_lib, cases,
     r.close()
 
 
+def test_preflight_report_stays_json_whatever_the_environment_holds(monkeypatch):
+    """pwn_tiled_preflight pastes strings from the environment and the loader into its JSON text: a quote or a backslash in one of
+    them (a dlopen error is the very case the report exists for) must not end the string early"""
+    import pwnfps_amd
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", 'a"b\\c\td')
+    for r in (pwnfps_amd.Renderer(64, 64), _group(64, 64, 2)):
+        pre = r.tiled_preflight()                      # json.loads inside
+        assert pre["HSA_ENABLE_IPC_MODE_LEGACY"] == "a?b?c?d" and pre["devices_visible"] >= 1
+        r.close()
+
+
 def test_two_devices_over_rccl(oracle_lib, cases):
     """the same handle on two real GPUs: one RCCL communicator rank per device, brought up inside the process"""
     import torch
