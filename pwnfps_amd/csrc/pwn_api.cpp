@@ -74,6 +74,8 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	c->dbg_blocks_per_cu = 0;
 	c->dbg_blur_th = 0;
 	if(const char *e = getenv("PWN_DBG_BLUR_TH")) c->dbg_blur_th = atoi(e);
+	c->dbg_sphere_lists = 0; c->off_recsph = 0;
+	if(const char *e = getenv("PWN_SPHERE_LISTS")) c->dbg_sphere_lists = strcmp(e, "indexed") == 0 ? 1 : (strcmp(e, "inline") == 0 ? 2 : 0);
 	c->dbg_blur_tw = 0; c->dbg_blur_batch = -1;          // (sweeps with a -DPWN_BLUR_SWEEP build: tools/r3/run_w.sh)
 	if(const char *e = getenv("PWN_DBG_BLUR_TW")) c->dbg_blur_tw = atoi(e);
 	if(const char *e = getenv("PWN_DBG_BLUR_BATCH")) if(*e) c->dbg_blur_batch = atoi(e);
@@ -291,7 +293,10 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 			for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
 			c->blur_passes = value; return PWN_OK;
 		case PWN_OPT_COUNTERS: c->counters_on = value ? 1 : 0; return PWN_OK;
-		case PWN_OPT_SCHEDULER: if(value < 0 || value > PWN_SCHED_REFILL) return PWN_EINVAL; c->scheduler = value; return PWN_OK;
+		case PWN_OPT_SCHEDULER:
+			if(value < 0 || value > PWN_SCHED_REFILL) return PWN_EINVAL;
+			if(value != c->scheduler) c->blob_dirty = true;          // (the form of the per-cell sphere lists goes with the scheduler: pack_blob)
+			c->scheduler = value; return PWN_OK;
 		case PWN_OPT_WAVE_LOG: c->wave_log_on = value ? 1 : 0; return PWN_OK;
 		case PWN_OPT_FRAME_TIMING: if(value < 0) return PWN_EINVAL; c->frame_timing = value; return PWN_OK;
 		case PWN_OPT_REFILL_LIMIT: if(value < 1 || value > 64000) return PWN_EINVAL; c->refill_limit = value; return PWN_OK;
@@ -348,6 +353,21 @@ static int pack_blob(pwn_ctx *c)
 	if(nbin > 32767u || nsph * 32u >= PWN_LIST_END) return PWN_ETOOBIG;      // list entries are byte offsets (index * 32) in 16 bits
 	uint32_t total = (pwn_t_total(nbin, nsph) + 15u) & ~15u;
 	if(total > PWN_BLOB_MAX) return PWN_ETOOBIG;
+	// Which form the per-cell lists take (tables.h): inline sphere records -- one LDS read per test instead of two dependent ones --
+	// for the unit scheduler's kernels wherever the bigger blob leaves as many workgroups per CU as the indexed one (2 KiB granules of
+	// 152 KiB: pwn_i_launch_trace); level.txt 26.5 against 26.3 KB, synth64 30.0 against 28.3 (both five), synth256 32.8 against
+	// 30.5 (four against five: indexed).  PWN_SPHERE_LISTS=indexed|inline in the environment forces one (experiments, tests).
+	uint32_t nrec = (uint32_t)c->bin_off[4096];
+	bool inl = false;
+	{
+		const uint32_t total_inl = (pwn_t_total_inl(nrec, nsph) + 15u) & ~15u;
+		const uint32_t extra = pwn_trace_lds_extra();
+		const uint32_t fit_idx = 155648u / ((total + extra + 2047u) & ~2047u), fit_inl = 155648u / ((total_inl + extra + 2047u) & ~2047u);
+		inl = c->scheduler == PWN_SCHED_UNITS && nrec > 0u && total_inl <= PWN_BLOB_MAX && fit_inl >= (fit_idx < 5u ? fit_idx : 5u);
+		if(c->dbg_sphere_lists == 1) inl = false;
+		if(c->dbg_sphere_lists == 2) inl = c->scheduler == PWN_SCHED_UNITS && nrec > 0u && total_inl <= PWN_BLOB_MAX;
+		if(inl) total = total_inl;
+	}
 	c->blob.assign(total, 0);        // (nothing has changed up to here: a failed call leaves the context as it was)
 	uint8_t *b = c->blob.data();
 	uint32_t *ci = (uint32_t *)(b + PWN_T_CELLINFO);
@@ -369,7 +389,7 @@ static int pack_blob(pwn_ctx *c)
 	}
 	memcpy(ci, c->cell_base, sizeof(c->cell_base));
 	uint32_t at = 0;
-	for(int i = 0; i < 4096; i++)
+	for(int i = 0; i < 4096 && !inl; i++)
 	{
 		int32_t k0 = c->bin_off[i], k1 = c->bin_off[i + 1];
 		if(k1 > k0)
@@ -377,6 +397,30 @@ static int pack_blob(pwn_ctx *c)
 			ci[(i >> 6) * PWN_GRID_PITCH + (i & 63)] |= PWN_C_SPH | (at << 16);
 			for(int32_t k = k0; k < k1; k++) bi[at++] = (uint16_t)(c->bin_idx[k] * 32);
 			bi[at++] = (uint16_t)PWN_LIST_END;
+		}
+	}
+	if(inl)
+	{
+		// records in the lists' order (bin_idx is that order already: cell by cell, object order inside a cell), the last of a cell signed
+		float *rec = (float *)(b + PWN_T_BINIDX);
+		uint16_t *which = (uint16_t *)(b + pwn_t_recsph_offset(nrec));
+		for(int i = 0; i < 4096; i++)
+		{
+			const int32_t k0 = c->bin_off[i], k1 = c->bin_off[i + 1];
+			if(k1 <= k0) continue;
+			ci[(i >> 6) * PWN_GRID_PITCH + (i & 63)] |= PWN_C_SPH | ((uint32_t)k0 << 16);
+			for(int32_t k = k0; k < k1; k++)
+			{
+				const pwn_sphere &q = c->spheres[(size_t)c->bin_idx[k]];
+				float r2 = q.r * q.r;
+				if(r2 < 1.17549435e-38f) r2 = 0.0f;          // (as below: the reference build's flush to zero)
+				rec[4 * k + 0] = q.x; rec[4 * k + 1] = q.y; rec[4 * k + 2] = q.z;
+				uint32_t wbits;
+				memcpy(&wbits, &r2, 4);
+				if(k == k1 - 1) wbits |= 0x80000000u;
+				memcpy(&rec[4 * k + 3], &wbits, 4);
+				which[k] = (uint16_t)(c->bin_idx[k] * 32);
+			}
 		}
 	}
 	memcpy(b + PWN_T_RCP, c->tabs, 4096);
@@ -389,7 +433,8 @@ static int pack_blob(pwn_ctx *c)
 		pm[2 * i] = (uint32_t)(p.x1 & 0xff) | ((uint32_t)(p.z1 & 0xff) << 8) | ((uint32_t)(p.x2 & 0xff) << 16) | ((uint32_t)(p.z2 & 0xff) << 24);
 		pm[2 * i + 1] = (uint32_t)(p.rot12 & 0xff) | ((uint32_t)(p.c1 & 0xff) << 8) | ((uint32_t)(p.c2 & 0xff) << 16);
 	}
-	c->off_sph = pwn_t_sph_offset(nbin);
+	c->off_sph = inl ? pwn_t_sph_offset_inl(nrec) : pwn_t_sph_offset(nbin);
+	c->off_recsph = inl ? pwn_t_recsph_offset(nrec) : 0u;
 	// the kernels' layout of a sphere (tables.h): position and r*r in one 16-byte half, the rest in the other
 	{
 		float *sp = (float *)(b + c->off_sph);
@@ -766,6 +811,7 @@ int pwn_i_launch_trace(pwn_ctx *c, const float cam[16], float sec, int y0, int y
 	if(P.ux_shift < 0 && P.tiles_x != 1) { snprintf(c->err, sizeof(c->err), "no division constant for %d units per row", P.tiles_x); return PWN_EINVAL; }
 	P.blob_bytes = (uint32_t)c->blob.size();
 	P.off_sph = c->off_sph;
+	P.off_recsph = c->off_recsph;
 	P.sbuf = d_sbuf; P.zbuf = d_zbuf;
 	const int cur = c->blob_cur;
 	P.blob = (const uint32_t *)c->d_blob[cur];

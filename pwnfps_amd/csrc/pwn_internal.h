@@ -149,6 +149,7 @@ struct pwn_ctx
 	hipStream_t up_stream;
 	uint16_t tabs[4096];             // expanded rcp + rsqrt tables (never change)
 	uint32_t off_sph;
+	uint32_t off_recsph; int dbg_sphere_lists;      // inline sphere records in the per-cell lists (tables.h): where their "which sphere" array is, 0 = indexed lists; PWN_SPHERE_LISTS
 	bool blob_dirty;
 	size_t occ_lds[8]; int occ_blocks[8];    // cached occupancy query per kernel variant
 

@@ -71,6 +71,15 @@ static inline uint32_t pwn_t_total(uint32_t nbin, uint32_t nsph)
 {
 	return pwn_t_sph_offset(nbin) + nsph * 32u;
 }
+// The per-cell lists with the sphere records INLINE (round 5; the unit scheduler's kernels, where the blob still leaves five
+// workgroups per CU): at PWN_T_BINIDX nrec records of 16 bytes -- x, y, z, r*r of the sphere, one per (cell, sphere) pair in
+// object order, the LAST record of a cell's list with the sign bit of r*r set (r*r is never negative) -- then nrec u16 "which
+// sphere" (its byte offset in the sphere array: read when a hit is shaded, not per test), then the spheres as before.  A test is
+// then ONE LDS read whose address does not depend on another read (level.txt: all 14 spheres sit in one cell, a ray through it
+// makes 14 tests in a row).  The cell word's offset field counts records.
+static inline uint32_t pwn_t_recsph_offset(uint32_t nrec) { return PWN_T_BINIDX + nrec * 16u; }
+static inline uint32_t pwn_t_sph_offset_inl(uint32_t nrec) { return pwn_t_recsph_offset(nrec) + ((nrec * 2u + 15u) & ~15u); }
+static inline uint32_t pwn_t_total_inl(uint32_t nrec, uint32_t nsph) { return pwn_t_sph_offset_inl(nrec) + nsph * 32u; }
 
 // glibc 2.35 e_expf.c / exp2f_data: 2^(i/32) as double bit patterns with the exponent adjusted (N = 32)
 #define PWN_EXP2F_TAB_INIT { \
@@ -154,6 +163,7 @@ struct pwn_trace_params
 	uint32_t perm_cap;                        // every queue: perm[q * perm_cap + ticket] = the unit that ticket of queue q stands for
 	uint32_t *clear_word;                     // NULL, or a word this launch sets to 0 (the row tiling's miss word of the frame:
 	                                          // the blur of the same frame, behind this launch on the stream, counts in it)
+	uint32_t off_recsph;                      // != 0: the blob holds the per-cell lists with inline sphere records (above); where their "which sphere" array is
 };
 
 #ifndef PWN_QUEUES

@@ -39,11 +39,12 @@ struct Lds
 	const PWN_LDS uint16_t *rcp, *rsq;
 	const PWN_LDS uint32_t *pmap;
 	const PWN_LDS uint16_t *binidx;
+	const PWN_LDS uint16_t *recsph;       // inline sphere records (tables.h): which sphere a record is of
 	const PWN_LDS float *sph;
 	const PWN_LDS uint64_t *exp2;         // tables.h PWN_T_EXP2
 	const PWN_LDS pwn_f4 *faces;           // tables.h PWN_T_FACES: [0..4) wall colours, [4 + 2 * face ..] face constants
 };
-__device__ __forceinline__ Lds lds_tables(uint32_t off_sph)
+__device__ __forceinline__ Lds lds_tables(uint32_t off_sph, uint32_t off_recsph = 0u)
 {
 	Lds L;
 	L.cellinfo = lds_at<uint32_t>(PWN_T_CELLINFO);
@@ -54,6 +55,7 @@ __device__ __forceinline__ Lds lds_tables(uint32_t off_sph)
 	L.faces = lds_at<pwn_f4>(PWN_T_FACES);
 	L.exp2 = lds_at<uint64_t>(PWN_T_EXP2);
 	L.sph = lds_at<float>(off_sph);
+	L.recsph = lds_at<uint16_t>(off_recsph);
 	return L;
 }
 

@@ -31,7 +31,7 @@
 
 
 // One pixel = trace_ray(0, ...) of screen.h:22-24 with the recursion unrolled.
-template<bool COUNT, bool HAS_W>
+template<bool COUNT, bool HAS_W, bool INL>
 __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uint32_t seed,
 	Vec<HAS_W> from, Vec<HAS_W> iray, float &out_x, float &out_y, float &out_z, float &out_w,
 	float *zpix, Counters &cnt)
@@ -208,6 +208,8 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 			//@R p_sphere
 			RG(RG_SPHERE);
 			// trace.h:283-291 for the committed sphere
+			// (inline records: aux_idx is the record's LDS address; which sphere it is of -- a byte offset -- is looked up here, once per hit)
+			if constexpr(INL) aux_idx = L.recsph[(aux_idx - PWN_T_BINIDX) >> 4];
 			const PWN_LDS pwn_f4 *sp = (const PWN_LDS pwn_f4 *)((const PWN_LDS unsigned char *)L.sph + aux_idx);      // (a byte offset)
 			const pwn_f4 s0 = sp[0], s1 = sp[1];
 			V d;
@@ -329,7 +331,7 @@ template<bool HAS_W> __device__ __forceinline__ void chain_rounds(Vec<HAS_W> &v,
 // ORDER: the launch writes what every unit cost its wave and / or hands its units out by a table (PWN_OPT_UNIT_ORDER, the
 // wave log).  A template parameter, not a test of the two pointers: as dormant code -- two wave-uniform branches and a
 // clock read per unit -- it cost launches that do not use it 2.5-3 % (profiles/r4/unit_order_dormant_cost.txt).
-template<bool COUNT, bool HAS_W, bool ORDER>
+template<bool COUNT, bool HAS_W, bool ORDER, bool INL>
 __global__ void __launch_bounds__(PWN_BLOCK, PWN_MIN_WAVES)
 pwn_trace_kernel(pwn_trace_params P)
 {
@@ -349,7 +351,7 @@ pwn_trace_kernel(pwn_trace_params P)
 
 	// (the tables are addressed from LDS address 0 on, trace_common.h; the launcher checks that this kernel has
 	// no static LDS in front of the dynamic allocation)
-	const Lds L = lds_tables(P.off_sph);
+	const Lds L = lds_tables(P.off_sph, P.off_recsph);
 
 	typedef Vec<HAS_W> V;
 	V rayb, rdx, rdy, from;
@@ -566,7 +568,7 @@ pwn_trace_kernel(pwn_trace_params P)
 
 			float ox, oy, oz, ow;
 			const uint32_t o = __umul24((uint32_t)y, (uint32_t)P.w) + (uint32_t)x;      // w, h <= 32768 (pwn_init)
-			trace_pixel<COUNT, HAS_W>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
+			trace_pixel<COUNT, HAS_W, INL>(L, P.sec_current, seed, from, rayl, ox, oy, oz, ow, P.zbuf + o, cnt);
 			P.sbuf[o] = col_pack4(ox, oy, oz, ow);
 		}
 		// what this unit cost its wave (the add chain and the ticket arithmetic in front of it are the same for every unit)
@@ -638,7 +640,7 @@ pwn_trace_kernel(pwn_trace_params P)
 	}
 }
 
-template<bool COUNT, bool HAS_W, bool ORDER>
+template<bool COUNT, bool HAS_W, bool ORDER, bool INL>
 static hipError_t launch_variant(const pwn_trace_params *P, int grid, size_t lds_bytes, hipStream_t stream)
 {
 	// the dynamic-LDS limit is a per-function attribute: raise it only when the blob grew
@@ -656,30 +658,36 @@ static hipError_t launch_variant(const pwn_trace_params *P, int grid, size_t lds
 			// the kernel addresses its tables from LDS address 0 (trace_common.h): that holds while it has no
 			// static LDS, which would be laid out in front of the dynamic allocation
 			hipFuncAttributes fa;
-			hipError_t e = hipFuncGetAttributes(&fa, (const void *)pwn_trace_kernel<COUNT, HAS_W, ORDER>);
+			hipError_t e = hipFuncGetAttributes(&fa, (const void *)pwn_trace_kernel<COUNT, HAS_W, ORDER, INL>);
 			if(e != hipSuccess) return e;
 			if(fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
-			e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W, ORDER>,
+			e = hipFuncSetAttribute((const void *)pwn_trace_kernel<COUNT, HAS_W, ORDER, INL>,
 				hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
 			if(e != hipSuccess) return e;
 			lds_set = lds_bytes;
 		}
 	}
-	hipLaunchKernelGGL((pwn_trace_kernel<COUNT, HAS_W, ORDER>), dim3(grid), dim3(PWN_BLOCK), lds_bytes, stream, *P);
+	hipLaunchKernelGGL((pwn_trace_kernel<COUNT, HAS_W, ORDER, INL>), dim3(grid), dim3(PWN_BLOCK), lds_bytes, stream, *P);
 	return hipGetLastError();
 }
 
-template<bool ORDER>
+template<bool ORDER, bool INL>
 static hipError_t launch_ordered(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream)
 {
-	if(count) return P->has_w ? launch_variant<true, true, ORDER>(P, grid, lds_bytes, stream) : launch_variant<true, false, ORDER>(P, grid, lds_bytes, stream);
-	return P->has_w ? launch_variant<false, true, ORDER>(P, grid, lds_bytes, stream) : launch_variant<false, false, ORDER>(P, grid, lds_bytes, stream);
+	if(count) return P->has_w ? launch_variant<true, true, ORDER, INL>(P, grid, lds_bytes, stream) : launch_variant<true, false, ORDER, INL>(P, grid, lds_bytes, stream);
+	return P->has_w ? launch_variant<false, true, ORDER, INL>(P, grid, lds_bytes, stream) : launch_variant<false, false, ORDER, INL>(P, grid, lds_bytes, stream);
 }
 
 extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int grid, size_t lds_bytes, bool count, hipStream_t stream)
 {
-	if(P->perm != NULL || P->unit_cost != NULL) return launch_ordered<true>(P, grid, lds_bytes, count, stream);
-	return launch_ordered<false>(P, grid, lds_bytes, count, stream);
+	// (the blob says which form its per-cell lists have: pack_blob, pwn_api.cpp)
+	if(P->off_recsph != 0u)
+	{
+		if(P->perm != NULL || P->unit_cost != NULL) return launch_ordered<true, true>(P, grid, lds_bytes, count, stream);
+		return launch_ordered<false, true>(P, grid, lds_bytes, count, stream);
+	}
+	if(P->perm != NULL || P->unit_cost != NULL) return launch_ordered<true, false>(P, grid, lds_bytes, count, stream);
+	return launch_ordered<false, false>(P, grid, lds_bytes, count, stream);
 }
 
 // resident 256-thread workgroups per CU for this variant and LDS size
@@ -695,10 +703,10 @@ extern "C" int pwn_trace_blocks_per_cu(size_t lds_bytes, bool count, bool has_w)
 {
 	int n = 0;
 	hipError_t e;
-	if(count) e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, true, false>, PWN_BLOCK, lds_bytes)
-	                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, false, false>, PWN_BLOCK, lds_bytes);
-	else e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, true, false>, PWN_BLOCK, lds_bytes)
-	               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, false, false>, PWN_BLOCK, lds_bytes);
+	if(count) e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, true, false, false>, PWN_BLOCK, lds_bytes)
+	                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<true, false, false, false>, PWN_BLOCK, lds_bytes);
+	else e = has_w ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, true, false, false>, PWN_BLOCK, lds_bytes)
+	               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, pwn_trace_kernel<false, false, false, false>, PWN_BLOCK, lds_bytes);
 	if(e != hipSuccess || n < 1) n = 2;
 	return n;
 }

@@ -454,6 +454,7 @@ pwn_trace_refill_kernel(pwn_trace_params P)
 #pragma unroll 1
 			do
 			{
+			constexpr bool INL = false;          // (this scheduler reads the indexed lists: pack_blob packs those for it)
 #include "trace_walk.inc"
 				// wave-uniform: a young ray still walks, and the ended ones have not waited too long
 				const unsigned long long w = __ballot(ev == EV_NONE);

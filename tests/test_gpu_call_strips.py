@@ -196,3 +196,32 @@ def test_strips_mixed_with_frames_in_flight(oracle_lib, cases):
     assert oracle_lib.fnv64(r.wait_frame(0)["sbuf"]) == c["post"]
     r.frames_config(0)
     r.close()
+
+
+@pytest.mark.parametrize("lists", ["indexed", "inline"])
+def test_both_forms_of_the_sphere_lists_give_the_goldens(oracle_lib, cases, monkeypatch, lists):
+    """the per-cell sphere lists (trace.h:252-296) as u16 indices into the sphere array or with the sphere records inline (tables.h, round 5):
+    chosen by the size of the tables, here forced each way -- every level, both lane forms, counters included"""
+    monkeypatch.setenv("PWN_SPHERE_LISTS", lists)
+    names = ("level_spawn_1280x720", "level_pose1_1280x720", "synth64_cam1_1920x1080", "synth256_cam1_480x272", "level_spawn_320x200", "level_spawn_nosph_320x240")
+    for hasw in (False, True):
+        if hasw:
+            monkeypatch.setenv("PWN_DBG_FORCE_HASW", "1")
+        for name in names:
+            c = _case(cases, name)
+            r = _renderer(c["w"], c["h"])
+            cam = _load(r, c)
+            r.set_counters(True)
+            post, z = r.trace_screen_centred(cam, c["sec"])
+            st = r.stats()
+            assert oracle_lib.fnv64(post) == c["post"] and oracle_lib.fnv64(z) == c["z"], (lists, hasw, name)
+            if "steps" in c:
+                assert (st["rays"], st["steps"], st["portals"], st["sphere_tests"], st["exhausted"]) == (c["rays"], c["steps"], c["portals"], c["sphere_tests"], c["exhausted"]), (lists, hasw, name)
+            r.set_counters(False)
+            post2, _ = r.trace_screen_centred(cam, c["sec"])
+            assert (post2 == post).all()
+            # the other scheduler reads indexed lists: the tables are packed again behind the option
+            r.set_scheduler("refill")
+            post3, _ = r.trace_screen_centred(cam, c["sec"])
+            assert (post3 == post).all(), (lists, hasw, name)
+            r.close()
