@@ -1,4 +1,9 @@
-"""Row-tiled frames across the GPUs of a node: the choreography of
+"""FROZEN (round 5): a second implementation of the row tiling's choreography, kept because the gloo tests
+(tests/test_dist_gloo.py) prove the PROTOCOL on CPU with it -- not the product path, and not to be extended.  New host logic
+goes into ``pwnfps_amd/csrc/pwn_tiled.cpp`` / ``pwn_group.cpp``, whose C code itself now runs on the CPU in the suite
+(tools/sanitize/: stand-in HIP runtime and kernels, TSan / ASan; tests/test_sanitize_host.py).
+
+Row-tiled frames across the GPUs of a node: the choreography of
 ``pwnfps_amd/csrc/pwn_tiled.cpp`` restated over ``torch.distributed`` point-to-point
 operations.
 
