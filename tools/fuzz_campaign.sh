@@ -17,3 +17,12 @@ run frames$((S+8)) python tools/fuzz_frames.py 300 $((S+8)) 1280x720
 run frames4k$((S+9)) python tools/fuzz_frames.py 120 $((S+9)) 3840x2160
 run tiled$((S+10)) python tools/fuzz_tiled.py 14 $((S+10))
 run deadlines$((S+11)) python tools/fuzz_deadlines.py 12 $((S+11))
+# round 5: the blocking call in row strips at every size (PWN_CALL_STRIPS: explicit counts ignore the size rule), both forms of the per-cell
+# sphere lists forced, and the one-process group (tools/fuzz_group.py: 2..7 members on device 0 against one context)
+run strips$((S+12)) env PWN_CALL_STRIPS=5 python tools/fuzz_parity.py 2000 $((S+12))
+run stripsl$((S+13)) env PWN_CALL_STRIPS=3 python tools/fuzz_parity.py 2000 $((S+13)) --lattice
+run stripsbig$((S+14)) env PWN_CALL_STRIPS=8 python tools/fuzz_parity.py 100 $((S+14)) --size 1920x1080
+run inl$((S+15)) env PWN_SPHERE_LISTS=inline python tools/fuzz_parity.py 2000 $((S+15))
+run inlw$((S+16)) env PWN_SPHERE_LISTS=inline PWN_DBG_FORCE_HASW=1 python tools/fuzz_parity.py 1500 $((S+16)) --lattice
+run idx$((S+17)) env PWN_SPHERE_LISTS=indexed python tools/fuzz_parity.py 1500 $((S+17))
+run group$((S+18)) python tools/fuzz_group.py 90 $((S+18))
