@@ -491,9 +491,9 @@ int pwn_group_trace_screen_centred(pwn_ctx *h, const float cam[16], float sec, u
 		// test hook (tests/test_gpu_group.py): PWN_DBG_GROUP_STALL=member:call:milliseconds -- that member's thread is late to that
 		// blocking call by so long (a device that stops answering): the others must come back with PWN_ETIMEDOUT at the deadline
 		if(g->stall_member == i && g->stall_call == call) { struct timespec ts = { g->stall_ms / 1000, (long)(g->stall_ms % 1000) * 1000000L }; nanosleep(&ts, NULL); }
-		// (carry_depth: one call at a time -- every call's depth lives in the same plane, so that a pixel whose primary ray
-		// runs out of steps keeps the previous call's value, trace.h:677, as on one device)
-		int r = pwn_i_tiled_submit(g->m[i], cm.data(), sec, sbuf, zbuf, 1);
+		// (depth plane PWN_MAX_SLOTS: the blocking calls' own -- every call's depth lives in the same plane, so that a pixel whose
+		// primary ray runs out of steps keeps the previous call's value, trace.h:677, as the context's plane does on one device)
+		int r = pwn_i_tiled_submit(g->m[i], cm.data(), sec, sbuf, zbuf, PWN_MAX_SLOTS);
 		if(r == PWN_OK) r = pwn_tiled_wait(g->m[i], 0, &g->tf[i]);
 		return r;
 	});
@@ -541,7 +541,8 @@ int pwn_group_submit_frame(pwn_ctx *h, const float cam[16], float sec, int slot)
 	// (posted, not waited for: the members enqueue the frame while the host goes on; a failure shows at the frame's pwn_wait_frame)
 	std::array<float, 16> cm;
 	memcpy(cm.data(), cam, sizeof(float) * 16);
-	(void)post(g, [g, cm, sec, hs, hz](int i) { return pwn_i_tiled_submit(g->m[i], cm.data(), sec, hs, hz, 0); });
+	// (depth plane `slot`: a frame slot's depth carries from the slot's previous frame, as a one-device context's slot planes do)
+	(void)post(g, [g, cm, sec, hs, hz, slot](int i) { return pwn_i_tiled_submit(g->m[i], cm.data(), sec, hs, hz, slot); });
 	g->in_flight[slot] = true; g->delivered[slot] = false; g->sec[slot] = sec;
 	g->fifo[g->fifo_n++] = slot;
 	memset(&g->fdone[slot], 0, sizeof(pwn_frame));
@@ -585,7 +586,18 @@ int pwn_group_frame_ready(pwn_ctx *h, int slot)
 {
 	pwn_group *g = h->grp;
 	if(slot < 0 || slot >= g->nslots) return PWN_EINVAL;
-	return (!g->in_flight[slot] || g->delivered[slot]) ? 1 : 0;       // (a frame is taken off the devices by pwn_wait_frame)
+	if(!g->in_flight[slot] || g->delivered[slot]) return 1;
+	// every member's share of the slot's frame -- the k-th oldest in flight -- is through on its device (a job on the members'
+	// threads, behind the submissions that were posted: it waits for those to be ENQUEUED, not for the GPUs)
+	int k = -1;
+	for(int i = 0; i < g->fifo_n; i++) if(g->fifo[i] == slot) k = i;
+	if(k < 0) return 0;
+	std::atomic<int> *all = new std::atomic<int>(1);
+	const int rc = run_all(g, [g, k, all](int i) { const int r = pwn_i_tiled_ready(g->m[i], k); if(r < 0) return r; if(r == 0) all->store(0); return PWN_OK; });
+	const int ready = all->load();
+	delete all;
+	if(rc != PWN_OK) return frame_failed(g, rc);
+	return ready;
 }
 
 int pwn_group_get_stats(pwn_ctx *h, pwn_stats *out)

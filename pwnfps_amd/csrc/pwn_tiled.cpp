@@ -743,8 +743,9 @@ struct pwn_tiled
 	// a group (pwn_init_multi): where the slot's frame goes -- the caller's own sbuf / zbuf (main.c:31,33) or the group's pinned
 	// frames -- instead of a place in host_base; and what the members share
 	uint32_t *hdst[NSLOT]; float *hzdst[NSLOT];
-	float *fz[NSLOT];                   // the depth plane of the slot's frame: z[s], or -- a group's blocking call, one frame at a time -- always z[0], so
-	                                    // that a pixel whose primary ray runs out of steps keeps the PREVIOUS call's depth (trace.h:677) as on one device
+	float *fz[NSLOT];                   // the depth plane of the slot's frame: z[s], or -- a group -- the plane the group names: one per frame slot of ITS
+	                                    // host and one for the blocking calls, so that a pixel whose primary ray runs out of steps keeps the depth of the
+	                                    // slot's previous frame / of the previous call (trace.h:677), exactly as a one-device context's planes do
 	pwn_hub *hub;
 	hipStream_t copy;
 	hipEvent_t ev_h[NSLOT];             // behind the copy of the slot's strip into the host frame
@@ -926,6 +927,7 @@ extern "C" int pwn_tiled_unique_id(void *id, int transport)
 	rccl_api *api = rccl_load(err, sizeof(err));
 	if(api == NULL) return PWN_ENOTSUP;
 	static_assert(NSLOT == PWN_TILED_SLOTS, "the host sink holds one frame per buffer set");
+	static_assert(PWN_MAX_SLOTS < NSLOT, "a group names a depth plane per frame slot of its host and one more for its blocking calls");
 	static_assert(sizeof(ncclUniqueId) == PWN_TILED_ID_BYTES, "the id is an ncclUniqueId");
 	return api->GetUniqueId((ncclUniqueId *)id) == ncclSuccess ? PWN_OK : PWN_EHIP;
 }
@@ -1529,9 +1531,9 @@ static double now_us(void)
 	return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
 }
 
-extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec) { return pwn_i_tiled_submit(c, cam, sec, NULL, NULL, 0); }
+extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec) { return pwn_i_tiled_submit(c, cam, sec, NULL, NULL, -1); }
 
-int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *host_sbuf, float *host_zbuf, int carry_depth)
+int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *host_sbuf, float *host_zbuf, int zplane)
 {
 	GRP_REFUSE(c);
 	if(c == NULL || cam == NULL || c->tiled == NULL) return PWN_EINVAL;
@@ -1551,7 +1553,7 @@ int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *hos
 	hipStream_t cs = counted ? t->cs[0] : t->cs[f % (unsigned long long)t->ncs];
 	t->fstream[s] = cs;
 	t->hdst[s] = host_sbuf; t->hzdst[s] = host_zbuf;
-	t->fz[s] = (carry_depth && t->submitted == t->delivered) ? t->z[0] : t->z[s];        // (carried only with nothing else in flight)
+	t->fz[s] = (zplane >= 0 && zplane < NSLOT) ? t->z[zplane] : t->z[s];        // (the caller's frames in flight name different planes)
 	// (a counted frame right behind uncounted ones on the OTHER streams: wait for those frames' traces, so that the
 	// counters and the wave log are this launch's alone)
 	for(int back = 1; counted && back < t->ncs && (unsigned long long)back <= f; back++)
@@ -1683,6 +1685,26 @@ static int wait_event(pwn_ctx *c, pwn_tiled *t, hipEvent_t ev, const char *what,
 		struct timespec ts = { 0, 20 * 1000 };
 		nanosleep(&ts, NULL);
 	}
+}
+
+// Without blocking: is the frame `ahead` behind the oldest one in flight through on this rank's device -- its strip blurred and copied
+// to the host (sink) or its gather's group finished?  1 / 0 / PWN_E*.  (A hint for pwn_frame_ready on a group's handle: a frame
+// whose taps left the halo still has its repeat in front of it, which pwn_tiled_wait runs.)
+int pwn_i_tiled_ready(pwn_ctx *c, int ahead)
+{
+	if(c == NULL || c->tiled == NULL || ahead < 0) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	const unsigned long long d = t->delivered + (unsigned long long)ahead;
+	if(d >= t->submitted) return PWN_EINVAL;
+	if(t->tp->dead) return PWN_ETIMEDOUT;
+	(void)hipSetDevice(c->device);
+	const int s = (int)(d % NSLOT);
+	hipEvent_t ev = t->sink ? t->ev_h[s] : (t->gathered > d ? t->gathered_by[s] : NULL);
+	if(ev == NULL) return 0;
+	const hipError_t e = hipEventQuery(ev);
+	if(e == hipSuccess) return 1;
+	(void)hipGetLastError();
+	return e == hipErrorNotReady ? 0 : PWN_EHIP;
 }
 
 extern "C" int pwn_tiled_wait(pwn_ctx *c, int flags, pwn_tiled_frame *out)

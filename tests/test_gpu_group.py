@@ -82,9 +82,14 @@ def test_frames_that_stay_on_the_devices_are_gathered_on_member_0(oracle_lib, ca
             assert oracle_lib.fnv64(r.read_plane(f["d_sbuf"])) == c["post"]
         r.set_objects(load_spheres(c["spheres"]))
         r.submit_frame(cam, c["sec"], i % 3)
+    import time
+    t0 = time.time()
+    while not all(r.frame_ready(i) for i in (0, 1, 2)):          # pwn_frame_ready: without blocking, true before long
+        assert time.time() - t0 < 10.0
     for i in (0, 1, 2):
         f = r.wait_frame(i)
         assert oracle_lib.fnv64(r.read_plane(f["d_sbuf"])) == c["post"]
+        assert r.frame_ready(i)
     assert not r.group_info()["host_sink"]
     # the same handle, now with its frames delivered: the tiling is set up again behind the call
     r.frames_config(2, sbuf=True)

@@ -99,13 +99,9 @@ for it in range(n):
         gi = grp.group_info()
         for f, ((sa, za), (sb, zb)) in enumerate(zip(a, b)):
             frames_checked += 1
-            # (frames in flight: depth of a pixel whose ray ran out of steps is the slot's previous frame's, on one context and in a group
-            # alike -- but a group's slots are the tiling's six, not the host's three: compared where no ray ran out, i.e. frame by frame
-            # through colour, and depth for the blocking calls, where both carry from call to call)
-            same = (sa == sb).all() and (mode != 0 or (za.view(np.uint32) == zb.view(np.uint32)).all())
-            if not same and mode != 0:
-                # a stale-depth pixel feeds the blur: accept only if one context with ZERO-ed history disagrees with itself too -- not checked here
-                pass
+            # colour of every frame; depth of the blocking calls and of the delivered frames (a pixel whose ray ran out of steps keeps the depth
+            # of the slot's previous frame / of the previous call, on one context and in a group alike)
+            same = (sa == sb).all() and (za is None or (za.view(np.uint32) == zb.view(np.uint32)).all())
             if not same:
                 bad += 1
                 print("MISMATCH scene %d (seed %d) frame %d: %dx%d, %d members, mode %d, blur %d, %d px differ, cuts %s" % (

@@ -27,7 +27,7 @@ extern "C" hipError_t pwn_launch_trace(const pwn_trace_params *P, int, size_t, b
 			const size_t o = (size_t)y * P->w + x;
 			P->sbuf[o] = mix(mix(mix((uint32_t)x, (uint32_t)y), secbits ^ tab), cambits);
 			// (like a ray that runs out of steps, trace.h:677: every 97th pixel keeps the depth it had)
-			if((x + 3 * y) % 97 != 0) P->zbuf[o] = (P->sec_current >= 100.0f && y >= deep0 && y < deep0 + 8) ? 400.0f : 1.0f + (float)((x + y) % 9);
+			if((x + 3 * y) % 97 != 0) P->zbuf[o] = (P->sec_current >= 100.0f && y >= deep0 && y < deep0 + 8) ? 400.0f : 1.0f + (float)((x + y + (secbits >> 20)) % 9);
 		}
 	if(P->clear_word) *P->clear_word = 0u;
 	if(P->cost_word) *P->cost_word += (uint32_t)(P->y1 - P->y0) * 10u + (uint32_t)(P->y0 % 7);
