@@ -152,9 +152,10 @@ typedef struct pwn_stats
                                   main.c:107): handing a 4K frame to the host over PCIe takes twice as long as its kernels, so the call
                                   works in row strips -- strip k is traced while strip k - 1 is blurred from the rows traced so far and
                                   strip k - 2 travels to sbuf / zbuf on the copy stream.  A tap of the blur that lands below the rows
-                                  traced so far (taps reach 0.002*h*|depth-1| rows, screen.h:100-102) is counted; such a frame's blur is
-                                  repeated over the whole frame before the call returns, and the next calls run in one piece for a
-                                  while: the frame delivered is always the exact one.  -1 (default): strips for frames of 3 Mpixels
+                                  traced so far (taps reach 0.002*h*|depth-1| rows, screen.h:100-102; a strip is blurred where taps of
+                                  depth <= 8 are covered) is counted; such a frame's blur is repeated over the whole frame before the call
+                                  returns and the next calls cover depth 24; a frame that exceeds that too sends the next calls through in
+                                  one piece for a while: the frame delivered is always the exact one.  -1 (default): strips for frames of 3 Mpixels
                                   and more into registered buffers (pwn_host_register), of 6 Mpixels and more into others, with
                                   POSTPROC_BLUR 0 or 1, not for counted or wave-logged frames; 0: one launch per pass,
                                   then the copies (what pwn_stats.trace_ms / blur_ms time as single launches); 2..32: that many

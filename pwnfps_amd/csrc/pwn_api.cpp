@@ -108,9 +108,12 @@ extern "C" int pwn_init(pwn_ctx **out, int device, int width, int height)
 	if(const char *e = getenv("PWN_TILED_CHOREO")) c->tiled_choreo = (strcmp(e, "split") == 0 || strcmp(e, "1") == 0) ? PWN_TILED_CHOREO_SPLIT : PWN_TILED_CHOREO_INSTREAM;
 	memset(c->ev, 0, sizeof(c->ev));
 	memset(&c->stats, 0, sizeof(c->stats));
+	c->strip_reach = 0;
 	c->call_strips = -1; c->strip_ev_n = 0; c->d_strip_miss = NULL; c->h_strip_miss = NULL; c->strip_backoff = 0;
 	c->strip_calls = c->strip_redone = 0; c->strips_last = 1; c->host_regs_n = 0;
 	memset(c->strip_ev, 0, sizeof(c->strip_ev));
+	c->strip_copy_streams = 0; c->strip_calib_n = 0;
+	if(const char *e = getenv("PWN_CALL_COPY_STREAMS")) if(atoi(e) == 1 || atoi(e) == 2) c->strip_copy_streams = atoi(e);
 	if(const char *e = getenv("PWN_CALL_STRIPS")) if(*e) { const int v = atoi(e); if(v >= -1 && v <= PWN_CALL_STRIPS_MAX && v != 1) c->call_strips = v; }
 	c->frame_timing = 1; c->wave_log_on = 0; c->d_wave_log = NULL; c->wave_log_cap = 0;
 	c->nslots = 0; c->frame_flags = 0; c->frame_scale = 1; c->frame_pitch = 0; c->frame_seq = 0;
@@ -316,7 +319,7 @@ extern "C" int pwn_set_option(pwn_ctx *c, int option, int value)
 		case PWN_OPT_TRACE_ROOM: if(value < -1 || value > 4096) return PWN_EINVAL; memset(&c->room, 0, sizeof(c->room)); c->room.mode = value; return PWN_OK;
 		case PWN_OPT_CALL_STRIPS:
 			if(value < -1 || value == 1 || value > PWN_CALL_STRIPS_MAX) return PWN_EINVAL;
-			c->call_strips = value; c->strip_backoff = 0; return PWN_OK;
+			c->call_strips = value; c->strip_backoff = 0; c->strip_reach = 0; return PWN_OK;
 		case PWN_OPT_FRAME_OVERLAP:
 			for(int i = 0; i < c->nslots; i++) if(c->slot[i].in_flight) return PWN_EBUSY;
 			c->frame_overlap = value ? 1 : 0; return PWN_OK;
@@ -1082,7 +1085,9 @@ extern "C" int pwn_blur_rows_device_bounded(pwn_ctx *c, int y0, int y1, const vo
 // first strips are blurred and runs beside the kernels of the rest: the call is the copy plus the first strips.
 // Strips grow from the top -- the first ones small so that the copy starts early, each later one 1.2 times the one before.
 
-static int blur_reach_rows(int h) { return (int)(0.002 * h * 24.0) + 2; }      // taps of depth <= 24 (screen.h:100-102), like the row tiling's halo
+// rows a blur tap of depth <= `depth` reaches (screen.h:100-102): 24 is the row tiling's halo; the strips of a blocking call begin with 8
+// (level.txt from its spawn pose: taps reach 32 rows at 4K, depth 8 covers 36) and go to 24 after the first frame whose taps went further
+static int blur_reach_rows(int h, double depth = 24.0) { return (int)(0.002 * h * depth) + 2; }
 
 static int strip_cuts(const pwn_ctx *c, int want, int *cuts)
 {
@@ -1168,11 +1173,19 @@ extern "C" int pwn_call_strips_state(pwn_ctx *c, unsigned long long out[4])
 
 static int call_in_strips(pwn_ctx *c, const float cam[16], float sec, uint32_t *sbuf, float *zbuf, const int *cuts, int K)
 {
-	// chunks go to the host on two copy streams in turn: a DMA copy behind another on ONE stream starts ~11 us after that one ended
-	// (five chunks of a 4K frame: 0.05 of 0.77 ms), on two the link is busy throughout
+	// Chunks go to the host on ONE copy stream or on TWO in turn.  A DMA copy behind another on one stream starts ~11 us after that one
+	// ended, and small copies run at 35-47 GB/s; on two streams the next copy's start-up hides behind the current one's bytes -- on
+	// some boxes: 0.745-0.755 against 0.77-0.79 ms per 4K call on three of them, 0.805 against 0.773 on a fourth
+	// (profiles/r5/call_strips.txt).  So a context finds out once: its first 8 calls in strips use one stream, the next 8 two, and the
+	// faster (by the median of the calls' own wall times, the first of each eight left out) is kept.  PWN_CALL_COPY_STREAMS=1|2 in the
+	// environment fixes it.
 	if(c->copy_stream2 == NULL && hipStreamCreateWithFlags(&c->copy_stream2, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); c->copy_stream2 = NULL; }
-	hipStream_t cs = c->copy_stream, cpy[2] = { c->copy_stream, c->copy_stream2 != NULL ? c->copy_stream2 : c->copy_stream };
-	if(const char *e = getenv("PWN_DBG_STRIP_COPY_STREAMS")) if(atoi(e) == 1) cpy[1] = cpy[0];
+	int ncopy = c->strip_copy_streams;
+	if(ncopy == 0) ncopy = c->strip_calib_n < 8 ? 1 : 2;               // (finding out)
+	if(c->copy_stream2 == NULL) ncopy = 1;
+	hipStream_t cs = c->copy_stream, cpy[2] = { c->copy_stream, ncopy == 2 ? c->copy_stream2 : c->copy_stream };
+	struct timespec t_call0;
+	clock_gettime(CLOCK_MONOTONIC, &t_call0);
 	// Successive strips' trace launches alternate between the context's two compute streams (the pattern the work-queue
 	// counters are made for, include/pwnhip.h): strip k + 1's grid moves onto the CUs as strip k's waves run out of units.
 	// On one stream every launch waits for the tail of the one before it: 8 strips of a 4K frame took 0.61 ms where the
@@ -1193,9 +1206,9 @@ static int call_in_strips(pwn_ctx *c, const float cam[16], float sec, uint32_t *
 	*c->h_strip_miss = 0u;
 	uint32_t *pre = c->d_pre, *fin = blur ? c->d_out : c->d_pre;
 	// The blur is cut apart from the trace: behind strip k's trace the rows [0, cuts[k + 1]) are there, and every row whose
-	// taps of depth <= 24 stay inside them is blurred and sent -- chunk k = rows [sent, cuts[k + 1] - H), the last one to the end.
+	// taps of depth <= 8 (24 once a frame's taps went further) stay inside them is blurred and sent -- chunk k = rows [sent, cuts[k + 1] - H), the last one to the end.
 	// So the first bytes leave behind the FIRST strip's trace, not the second's.
-	int H = blur ? blur_reach_rows(c->h) : 0;
+	int H = blur ? blur_reach_rows(c->h, c->strip_reach ? 24.0 : 8.0) : 0;
 	if(const char *e = getenv("PWN_DBG_STRIP_REACH")) if(*e && blur) H = atoi(e);
 	// A copy into memory the device does not know is staged by the runtime and holds this thread until it is through:
 	// two strips of kernels are then enqueued ahead of every copy, so that the GPU has work while the host waits in it.
@@ -1279,6 +1292,24 @@ static int call_in_strips(pwn_ctx *c, const float cam[16], float sec, uint32_t *
 	if(blur) HIPCHK(c, hipMemcpyAsync(c->h_strip_miss, c->d_strip_miss, 4, hipMemcpyDeviceToHost, cs));
 	HIPCHK(c, hipEventRecord(c->ev[3], cs));
 	HIPCHK(c, hipEventSynchronize(c->ev[3]));
+	if(c->strip_copy_streams == 0)
+	{
+		struct timespec t1;
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		c->strip_calib_ms[c->strip_calib_n++] = (double)(t1.tv_sec - t_call0.tv_sec) * 1e3 + (double)(t1.tv_nsec - t_call0.tv_nsec) * 1e-6;
+		if(c->strip_calib_n == 16)
+		{
+			double med[2];
+			for(int m = 0; m < 2; m++)
+			{
+				double v[7];
+				for(int i = 0; i < 7; i++) v[i] = c->strip_calib_ms[8 * m + 1 + i];
+				for(int i = 1; i < 7; i++) for(int k = i; k > 0 && v[k] < v[k - 1]; k--) { const double t = v[k]; v[k] = v[k - 1]; v[k - 1] = t; }
+				med[m] = v[3];
+			}
+			c->strip_copy_streams = med[1] < med[0] ? 2 : 1;
+		}
+	}
 	if(timeline)
 	{
 		fprintf(stderr, "strips %d, chunks %d:", K, chunks);
@@ -1297,7 +1328,8 @@ static int call_in_strips(pwn_ctx *c, const float cam[16], float sec, uint32_t *
 		// a tap landed below the rows that were traced when its chunk was blurred: the whole pre-blur frame is there now, so
 		// the pass again in one piece, and the frame again to the host (depth is what it was); the next calls in one piece
 		c->strip_redone++;
-		c->strip_backoff = 64;
+		// (the short reach was not enough for this view: the long one from now on; that one too: one-piece calls for a while)
+		if(c->strip_reach == 0) c->strip_reach = 1; else c->strip_backoff = 64;
 		rc = pwn_i_launch_blur(c, 0, c->h, pre, c->d_z, fin, st[0], 0, 0, NULL, NULL, NULL);
 		if(rc != PWN_OK) return rc;
 		HIPCHK(c, hipEventRecord(c->ev[2], st[0]));

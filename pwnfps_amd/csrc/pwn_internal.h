@@ -194,14 +194,17 @@ struct pwn_ctx
 	int frame_overlap;               // PWN_OPT_FRAME_OVERLAP
 	hipEvent_t last_frame_done; hipStream_t last_frame_stream;   // "kernels done" of the frame submitted last, and its stream
 	hipStream_t copy_stream;         // frames in flight: D2H of finished frames
-	hipStream_t copy_stream2;        // the blocking call in strips: chunks go out on the two in turn (made on first use)
 	hipEvent_t ev[4];
 	// The blocking call in row strips (PWN_OPT_CALL_STRIPS; pwn_api.cpp, call_in_strips): trace strip k, blur strip k - 1 from the
 	// rows traced so far, strip k - 2 on its way to the caller's buffer -- the copy over PCIe is twice a 4K frame's kernels
 	int call_strips;                 // the option: -1 = by frame size (default), 0 = one launch per pass, n >= 2 = that many strips
+	hipStream_t copy_stream2;        // the blocking call in strips: chunks go out on one copy stream or on the two in turn
+	int strip_copy_streams;          // ... 1 or 2 as found out by the context's first sixteen calls in strips (0: still finding out); PWN_CALL_COPY_STREAMS
+	int strip_calib_n; double strip_calib_ms[16];
 	hipEvent_t strip_ev[2 * PWN_CALL_STRIPS_MAX]; int strip_ev_n;      // behind strip k's trace [2k] and blur [2k + 1]; made on first use
 	uint32_t *d_strip_miss, *h_strip_miss;     // taps of a strip's blur that left the rows traced so far: the device word, its pinned copy
 	int strips_last;                 // strips of the last blocking call (1 = one launch per pass)
+	int strip_reach;                 // 0: chunks are blurred where taps of depth <= 8 are traced, 1: <= 24 (after a frame whose taps went further)
 	int strip_backoff;               // blocking calls left before strips are tried again after such a frame
 	unsigned long long strip_calls, strip_redone;      // blocking calls that ran in strips; ... whose blur was repeated over the whole frame
 	struct host_reg { void *base; size_t bytes; } host_regs[PWN_HOST_REGS_MAX]; int host_regs_n;     // pwn_host_register

@@ -29,3 +29,13 @@ def test_fuzz_campaign(n, seed, force_w, sched):
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "%d scenes, 0 mismatches" % n in p.stdout
+
+
+def test_group_campaign():
+    """tools/fuzz_group.py, a short run: pwn_init_multi with 2..7 members on device 0 -- blocking calls with depth carried over 20 calls
+    while the cuts move, frames in flight delivered and resident -- against the same calls on one context, colour and depth"""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_group.py"), "18", "5150"], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and ", 0 bad" in p.stdout, (p.stdout[-2000:], p.stderr[-2000:])

@@ -68,7 +68,8 @@ def main():
         leg("one launch per pass, registered", 0, True, want_z)
         leg("default strips, pageable", -1, False, want_z)
         leg("default strips, registered", -1, True, want_z)
-        leg("default strips, registered, one copy stream", -1, True, want_z, {"PWN_DBG_STRIP_COPY_STREAMS": "1"})
+        leg("default strips, registered, one copy stream", -1, True, want_z, {"PWN_CALL_COPY_STREAMS": "1"})
+        leg("default strips, registered, two copy streams", -1, True, want_z, {"PWN_CALL_COPY_STREAMS": "2"})
         if not want_z:
             for k in (4, 6, 8):
                 leg("%d equal strips, registered" % k, k, True, want_z)
