@@ -161,18 +161,18 @@ def nonfinite_scenes(pwnfps_amd):
 
 
 def model_over_measured(w, h, level, launch_ms):
-    """VALU issue time of one launch by the committed issue model (tools/issue_model.py -> profiles/r4_issue_model.json) over the
+    """VALU issue time of one launch by the committed issue model (tools/issue_model.py -> profiles/r5_issue_model.json) over the
     measured launch time.  NOT a roofline fraction: the model's costs per opcode class come from this repo's own
     microbenchmark, and a value near 1 says "this instruction stream has no stall slack", not "no faster kernel exists"
     (the architectural fractions are roofline.valu_issue_frac_of_peak / lane_slot_frac).  None when the model was not made
     for this frame."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r4_issue_model.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r5_issue_model.json")) as f:
             m = json.load(f)
         for c in m["cases"]:
             if (c["w"], c["h"], c["level"]) == (w, h, level) and launch_ms > 0:
                 return {"valu_issue_ms_model": c["valu_issue_ms"], "ratio": round(c["valu_issue_ms"] / launch_ms, 4),
-                        "model": "profiles/r4_issue_model.txt",
+                        "model": "profiles/r5_issue_model.txt",
                         "what": "the builder's cost model over the measured launch; > 1 only says the cost table over-predicts"}
     except (OSError, KeyError, ValueError):
         pass
@@ -1025,7 +1025,7 @@ def main():
                          "valu_issue_frac_of_peak": vf["valu_issue_frac_of_peak"] if vf else None,
                          "lane_slot_frac": vf["lane_slot_frac"] if vf else None,
                          "valu": vf,
-                         # ... and against the builder's own cost model (profiles/r4_issue_model.json: per-block instruction mix x
+                         # ... and against the builder's own cost model (profiles/r5_issue_model.json: per-block instruction mix x
                          # measured execution counts x issue cost per opcode class from this repo's microbenchmark) -- a ratio, not a
                          # roofline fraction (it was `issue_frac` until round 3)
                          "model_over_measured": model_over_measured(w, h, args.level, trace_ms) if world == 1 else None,
@@ -1289,6 +1289,7 @@ def main():
             del os.environ["PWN_TILED_RCCL_MODE"]
 
     if world == 1:
+        r.set_call_strips(0)               # counters, wave stamps and kernel_ms: one launch per pass
         r.set_counters(True)
         sb = np.empty((h, w), np.uint32)
         r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
@@ -1320,27 +1321,36 @@ def main():
                 r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
                 best = min(best, time.perf_counter() - t1)
             return best
-        r.set_call_strips(0)
         blocking_one_piece = blocking()
         st = r.stats()                     # kernel times of an uncounted frame, one launch per pass
         kernel_ms = {"trace": round(st["trace_ms"], 4), "blur": round(st["blur_ms"], 4)}
+        blocking_best = blocking_one_piece
+        if not args.no_d2h:
+            # (--no-d2h is the form run under rocprofv3: no strip-sized launches, so the profile's per-kernel average is the
+            # whole-frame launch the roofline object quotes)
+            r.set_call_strips(-1)
+            blocking_pageable = blocking()
+            strips_pageable = r.call_strips_state()["strips_last"]
+            r.host_register(sb)
+            # (a context's first sixteen calls in strips find out whether its chunks go out on one copy stream or on two: the steady
+            # state is what is timed)
+            for _ in range(20):
+                r.trace_screen_centred(cam, sec, want_z=False, sbuf=sb)
+            blocking_best = blocking(9)
+            cs_state = r.call_strips_state()
+            blocking_same = bool(oracle.fnv64(sb) == frame_hash) if (oracle is not None and frame_hash is not None) else None
+            r.host_unregister(sb)
+            blocking_call = {"one_piece_mpix_s": round(w * h / blocking_one_piece / 1e6, 2), "one_piece_ms": round(blocking_one_piece * 1e3, 4),
+                             "strips_pageable_mpix_s": round(w * h / blocking_pageable / 1e6, 2), "strips_pageable_ms": round(blocking_pageable * 1e3, 4),
+                             "strips_registered_mpix_s": round(w * h / blocking_best / 1e6, 2), "strips_registered_ms": round(blocking_best * 1e3, 4),
+                             "strips": cs_state["strips_last"], "strips_pageable": strips_pageable, "blur_repeated": cs_state["redone"],
+                             "copy_streams": cs_state["copy_streams"], "reach_depth": cs_state["reach_depth"],
+                             "frame_equals_resident_frame": blocking_same,
+                             "pcie_floor_ms": round(4 * w * h / 54e9 * 1e3, 4),
+                             "what": "best of 7 (registered: of 9 behind 20 calls) wall times of one pwn_trace_screen_centred(cam, sec, sbuf, NULL): one launch per pass and then "
+                                     "the copy (PWN_OPT_CALL_STRIPS 0); in row strips (the default) into a malloc'ed sbuf; in row strips into the same "
+                                     "sbuf registered with pwn_host_register"}
         r.set_call_strips(-1)
-        blocking_pageable = blocking()
-        strips_pageable = r.call_strips_state()["strips_last"]
-        r.host_register(sb)
-        blocking_best = blocking()
-        cs_state = r.call_strips_state()
-        blocking_same = bool(oracle.fnv64(sb) == frame_hash) if (oracle is not None and frame_hash is not None) else None
-        r.host_unregister(sb)
-        blocking_call = {"one_piece_mpix_s": round(w * h / blocking_one_piece / 1e6, 2), "one_piece_ms": round(blocking_one_piece * 1e3, 4),
-                         "strips_pageable_mpix_s": round(w * h / blocking_pageable / 1e6, 2), "strips_pageable_ms": round(blocking_pageable * 1e3, 4),
-                         "strips_registered_mpix_s": round(w * h / blocking_best / 1e6, 2), "strips_registered_ms": round(blocking_best * 1e3, 4),
-                         "strips": cs_state["strips_last"], "strips_pageable": strips_pageable, "blur_repeated": cs_state["redone"],
-                         "frame_equals_resident_frame": blocking_same,
-                         "pcie_floor_ms": round(4 * w * h / 54e9 * 1e3, 4),
-                         "what": "best of 7 wall times of one pwn_trace_screen_centred(cam, sec, sbuf, NULL): one launch per pass and then "
-                                 "the copy (PWN_OPT_CALL_STRIPS 0); in row strips (the default) into a malloc'ed sbuf; in row strips into the same "
-                                 "sbuf registered with pwn_host_register"}
     if world == 1 and not args.no_d2h:
         pcie = d2h_leg_one_gpu(r, args, w, h, cam, sec, spheres, blocking_best,
                                (lambda buf: oracle.fnv64(buf) == frame_hash) if (oracle is not None and frame_hash is not None) else None)

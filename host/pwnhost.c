@@ -495,8 +495,7 @@ int main(int argc, char **argv)
 	if(slots > 0)
 	{
 		/* frames in flight: the loop of main.c:93-140 with the present step SLOTS-1 frames behind */
-		/* (a group delivers sbuf; its sink runs on the delivered frame: pwn_screen_upscale below) */
-		CHK(pwn_frames_config(ctx, slots, group > 1 ? PWN_FRAME_SBUF : (PWN_FRAME_SBUF | PWN_FRAME_SURFACE), rscale, pitch));
+		CHK(pwn_frames_config(ctx, slots, PWN_FRAME_SBUF | PWN_FRAME_SURFACE, rscale, pitch));
 		pwn_frame fr;
 		memset(&fr, 0, sizeof(fr));
 		double t0 = now_s(), t1 = t0;
@@ -525,11 +524,6 @@ int main(int argc, char **argv)
 			}
 		}
 		double t2 = now_s();
-		if(group > 1)
-		{
-			CHK(pwn_screen_upscale(ctx, fr.sbuf, rscale, surface.pitch, surface.pixels));      /* main.c:108 */
-			fr.surface = surface.pixels;
-		}
 		printf("frame %dx%d x%d: sbuf fnv64 %016llx, surface fnv64 %016llx\n", rwidth, rheight, rscale,
 			(unsigned long long)fnv64(fr.sbuf, npix),
 			(unsigned long long)fnv64(fr.surface, (size_t)(pitch / 4) * (size_t)rheight * (size_t)rscale));

@@ -185,9 +185,9 @@ void pwn_destroy(pwn_ctx *ctx);
  *                   members share that device (tests on a box with one GPU; no use otherwise).  ndev = 1 is pwn_init.
  *   frames          pwn_trace_screen_centred: every device copies its finished strip (and its depth strip) straight into the
  *                   caller's sbuf / zbuf over its own PCIe link.  pwn_frames_config with PWN_FRAME_SBUF / _ZBUF: the same
- *                   into the group's pinned frames, up to PWN_MAX_SLOTS in flight; with flags 0 the finished strips are
- *                   gathered on devices[0] (pwn_frame.d_sbuf) and nothing goes to the host.  PWN_FRAME_SURFACE: PWN_ENOTSUP
- *                   (pwn_screen_upscale works on the delivered frame).
+ *                   into the group's pinned frames, up to PWN_MAX_SLOTS in flight; PWN_FRAME_SURFACE: every device upscales its own
+ *                   strip (screen_upscale, screen.h:126-149) and copies those rows of the surface to the host as well; with flags 0
+ *                   the finished strips are gathered on devices[0] (pwn_frame.d_sbuf) and nothing goes to the host.
  *   exchange        between devices: RCCL (ncclSend / ncclRecv groups over xGMI, one communicator rank per device, made
  *                   in-process under the bring-up deadline) when the ordinals are distinct and librccl loads, else -- and
  *                   with PWN_GROUP_TRANSPORT=local in the environment -- PWN_TRANSPORT_LOCAL: peer-to-peer copies behind
@@ -290,11 +290,14 @@ int pwn_trace_screen_centred(pwn_ctx *ctx, const float cam[16], float sec_curren
  *   pwn_host_unregister  before the memory is freed -- a registered range that is freed and handed out again by
  *                        malloc is still the OLD pages to the device; pwn_destroy unregisters what is left
  * *_state: out[0] the option, out[1] strips of the last blocking call (1 = it ran in one piece), out[2] blocking calls
- * that ran in strips, out[3] how many of those had their blur repeated over the whole frame.
+ * that ran in strips, out[3] how many of those had their blur repeated over the whole frame, out[4] the copy streams the
+ * chunks go out on (1 or 2; 0 = the context is still finding out: its first 8 calls in strips use one, the next 8 two, the
+ * faster stays -- which it is depends on the queues the runtime handed out; PWN_CALL_COPY_STREAMS=1|2 in the environment
+ * fixes it), out[5] the depth whose taps a chunk's blur waits for (8, or 24 after a frame whose taps went further).
  */
 int pwn_host_register(pwn_ctx *ctx, void *base, size_t bytes);
 int pwn_host_unregister(pwn_ctx *ctx, void *base);
-int pwn_call_strips_state(pwn_ctx *ctx, unsigned long long out[4]);
+int pwn_call_strips_state(pwn_ctx *ctx, unsigned long long out[6]);
 
 /*
  * Frames in flight.  The reference presents every frame on the host

@@ -1163,11 +1163,12 @@ extern "C" int pwn_host_unregister(pwn_ctx *c, void *base)
 	return PWN_EINVAL;
 }
 
-extern "C" int pwn_call_strips_state(pwn_ctx *c, unsigned long long out[4])
+extern "C" int pwn_call_strips_state(pwn_ctx *c, unsigned long long out[6])
 {
 	if(GRP_HEAD(c)) return pwn_call_strips_state(GRP_M0(c), out);
 	if(c == NULL || out == NULL) return PWN_EINVAL;
 	out[0] = (unsigned long long)(long long)c->call_strips; out[1] = (unsigned long long)c->strips_last; out[2] = c->strip_calls; out[3] = c->strip_redone;
+	out[4] = (unsigned long long)c->strip_copy_streams; out[5] = c->strip_reach ? 24ull : 8ull;
 	return PWN_OK;
 }
 

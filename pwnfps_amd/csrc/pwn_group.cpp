@@ -58,7 +58,9 @@ struct pwn_group
 	int init_ms, wait_ms;
 	// frames in flight
 	int nslots, flags;
-	uint32_t *h_sbuf[PWN_MAX_SLOTS]; float *h_zbuf[PWN_MAX_SLOTS];
+	uint32_t *h_sbuf[PWN_MAX_SLOTS]; float *h_zbuf[PWN_MAX_SLOTS]; uint32_t *h_surface[PWN_MAX_SLOTS];
+	int surf_scale, surf_pitch;                  // PWN_FRAME_SURFACE as configured; the tiling in force upscales with these (tiling_surf_*)
+	int tiling_surf_scale, tiling_surf_pitch;
 	bool in_flight[PWN_MAX_SLOTS], delivered[PWN_MAX_SLOTS];
 	pwn_frame fdone[PWN_MAX_SLOTS];
 	float sec[PWN_MAX_SLOTS];
@@ -196,7 +198,8 @@ static void frames_free(pwn_group *g)
 	{
 		if(g->h_sbuf[i]) (void)hipHostFree(g->h_sbuf[i]);
 		if(g->h_zbuf[i]) (void)hipHostFree(g->h_zbuf[i]);
-		g->h_sbuf[i] = NULL; g->h_zbuf[i] = NULL; g->in_flight[i] = g->delivered[i] = false;
+		if(g->h_surface[i]) (void)hipHostFree(g->h_surface[i]);
+		g->h_sbuf[i] = NULL; g->h_zbuf[i] = NULL; g->h_surface[i] = NULL; g->in_flight[i] = g->delivered[i] = false;
 	}
 	g->nslots = 0; g->flags = 0; g->fifo_n = 0;
 }
@@ -207,6 +210,7 @@ static int tiling_down(pwn_group *g)
 	if(g->mode == MODE_NONE) return PWN_OK;
 	(void)run_all(g, [g](int i) { pwn_tiled_shutdown(g->m[i]); return PWN_OK; }, true);
 	g->mode = MODE_NONE;
+	g->tiling_surf_scale = g->tiling_surf_pitch = 0;
 	mend(g);
 	g->hub.failed.store(0);
 	g->hub.bar_count.store(0);
@@ -216,7 +220,8 @@ static int tiling_down(pwn_group *g)
 
 static int tiling_up(pwn_group *g, int mode)
 {
-	if(g->mode == mode) return PWN_OK;
+	const int sscale = (mode == MODE_SINK && (g->flags & PWN_FRAME_SURFACE)) ? g->surf_scale : 0, spitch = sscale ? g->surf_pitch : 0;
+	if(g->mode == mode && (sscale == 0 || (sscale == g->tiling_surf_scale && spitch == g->tiling_surf_pitch))) return PWN_OK;
 	tiling_down(g);
 	unsigned char id[PWN_TILED_ID_BYTES];
 	memset(id, 0, sizeof(id));
@@ -226,13 +231,14 @@ static int tiling_up(pwn_group *g, int mode)
 		if(rc != PWN_OK) { snprintf(g->head->err, sizeof(g->head->err), "librccl: no unique id (%s)", pwn_strerror(rc)); return rc; }
 	}
 	std::vector<unsigned char> idv(id, id + sizeof(id));
-	const int rc = run_all(g, [g, idv, mode](int i)
+	const int rc = run_all(g, [g, idv, mode, sscale, spitch](int i)
 	{
 		const unsigned char *id = idv.data();
 		pwn_ctx *c = g->m[i];
 		int r = pwn_tiled_set_timeouts(c, g->init_ms ? g->init_ms : 0, g->wait_ms ? g->wait_ms : 0);
 		if(r == PWN_OK) r = pwn_tiled_init(c, i, g->n, id, g->transport, -1);
 		if(r == PWN_OK && mode == MODE_SINK) r = pwn_i_tiled_sink(c);
+		if(r == PWN_OK && sscale) r = pwn_i_tiled_surface(c, sscale, spitch);
 		return r;
 	});
 	if(rc != PWN_OK)
@@ -245,6 +251,7 @@ static int tiling_up(pwn_group *g, int mode)
 		return rc;
 	}
 	g->mode = mode;
+	g->tiling_surf_scale = sscale; g->tiling_surf_pitch = spitch;
 	return PWN_OK;
 }
 
@@ -276,7 +283,8 @@ extern "C" int pwn_init_multi(pwn_ctx **out, const int *devices, int ndev, int w
 	g->prof = getenv("PWN_DBG_GROUP_PROF") != NULL; g->p_join = 0.0; g->p_jobs = g->p_joins = 0;
 	for(int i = 0; i < MAXM; i++) { g->p_job[i] = 0.0; g->done[i].store(0); }
 	g->init_ms = g->wait_ms = 0; g->nslots = 0; g->flags = 0; g->fifo_n = 0; g->frame_seq = 0; g->last_sbuf = NULL;
-	for(int i = 0; i < PWN_MAX_SLOTS; i++) { g->h_sbuf[i] = NULL; g->h_zbuf[i] = NULL; g->in_flight[i] = g->delivered[i] = false; }
+	for(int i = 0; i < PWN_MAX_SLOTS; i++) { g->h_sbuf[i] = NULL; g->h_zbuf[i] = NULL; g->h_surface[i] = NULL; g->in_flight[i] = g->delivered[i] = false; }
+	g->surf_scale = g->surf_pitch = g->tiling_surf_scale = g->tiling_surf_pitch = 0;
 	for(int i = 0; i < MAXM; i++) { g->m[i] = NULL; g->devices[i] = -1; g->hub.member[i] = NULL; }
 	g->hub.world = ndev; g->hub.failed.store(0); g->hub.bar_count.store(0); g->hub.bar_gen.store(0); g->hub.boxes = NULL;
 	// the handle: no device of its own, the frame's size and the group
@@ -493,7 +501,7 @@ int pwn_group_trace_screen_centred(pwn_ctx *h, const float cam[16], float sec, u
 		if(g->stall_member == i && g->stall_call == call) { struct timespec ts = { g->stall_ms / 1000, (long)(g->stall_ms % 1000) * 1000000L }; nanosleep(&ts, NULL); }
 		// (depth plane PWN_MAX_SLOTS: the blocking calls' own -- every call's depth lives in the same plane, so that a pixel whose
 		// primary ray runs out of steps keeps the previous call's value, trace.h:677, as the context's plane does on one device)
-		int r = pwn_i_tiled_submit(g->m[i], cm.data(), sec, sbuf, zbuf, PWN_MAX_SLOTS);
+		int r = pwn_i_tiled_submit(g->m[i], cm.data(), sec, sbuf, zbuf, PWN_MAX_SLOTS, NULL);
 		if(r == PWN_OK) r = pwn_tiled_wait(g->m[i], 0, &g->tf[i]);
 		return r;
 	});
@@ -509,21 +517,31 @@ int pwn_group_trace_screen_centred(pwn_ctx *h, const float cam[16], float sec, u
 int pwn_group_frames_config(pwn_ctx *h, int nslots, int flags, int scale, int pitch_bytes)
 {
 	pwn_group *g = h->grp;
-	(void)scale; (void)pitch_bytes;
 	if(nslots < 0 || nslots > PWN_MAX_SLOTS || (flags & ~(PWN_FRAME_SBUF | PWN_FRAME_ZBUF | PWN_FRAME_SURFACE)) != 0) return PWN_EINVAL;
-	if(flags & PWN_FRAME_SURFACE) { snprintf(h->err, sizeof(h->err), "PWN_FRAME_SURFACE is not available on a group: pwn_screen_upscale the delivered frame"); return PWN_ENOTSUP; }
+	if(flags & PWN_FRAME_SURFACE)
+	{
+		if(scale <= 0) return PWN_EINVAL;
+		if(pitch_bytes == 0) pitch_bytes = h->w * scale * 4;
+		if((pitch_bytes & 3) != 0 || (long long)pitch_bytes < (long long)h->w * scale * 4) return PWN_EINVAL;
+	}
+	else { scale = 1; pitch_bytes = 0; }
 	for(int i = 0; i < PWN_MAX_SLOTS; i++) if(g->in_flight[i]) return PWN_EBUSY;
 	frames_free(g);
-	const size_t bytes = (size_t)h->w * (size_t)h->h * 4;
+	const size_t bytes = (size_t)h->w * (size_t)h->h * 4, surf_bytes = (size_t)pitch_bytes * (size_t)h->h * (size_t)scale;
 	(void)hipSetDevice(g->devices[0]);
 	for(int i = 0; i < nslots; i++)
 	{
-		// (portable: every member's device copies into them)
-		if((flags & (PWN_FRAME_SBUF | PWN_FRAME_ZBUF)) && hipHostMalloc((void **)&g->h_sbuf[i], bytes, hipHostMallocPortable) != hipSuccess) { frames_free(g); return PWN_ENOMEM; }
+		// (portable: every member's device copies into them.  Whatever is delivered, the members' strips land in a host frame)
+		if(flags != 0 && hipHostMalloc((void **)&g->h_sbuf[i], bytes, hipHostMallocPortable) != hipSuccess) { frames_free(g); return PWN_ENOMEM; }
 		if((flags & PWN_FRAME_ZBUF) && hipHostMalloc((void **)&g->h_zbuf[i], bytes, hipHostMallocPortable) != hipSuccess) { frames_free(g); return PWN_ENOMEM; }
+		if(flags & PWN_FRAME_SURFACE)
+		{
+			if(hipHostMalloc((void **)&g->h_surface[i], surf_bytes, hipHostMallocPortable) != hipSuccess) { frames_free(g); return PWN_ENOMEM; }
+			memset(g->h_surface[i], 0, surf_bytes);           // bytes between the rows of a wider pitch read 0
+		}
 	}
-	g->nslots = nslots; g->flags = flags;
-	h->nslots = nslots; h->frame_flags = flags;
+	g->nslots = nslots; g->flags = flags; g->surf_scale = (flags & PWN_FRAME_SURFACE) ? scale : 0; g->surf_pitch = (flags & PWN_FRAME_SURFACE) ? pitch_bytes : 0;
+	h->nslots = nslots; h->frame_flags = flags; h->frame_pitch = pitch_bytes; h->frame_scale = scale;
 	return PWN_OK;
 }
 
@@ -533,16 +551,17 @@ int pwn_group_submit_frame(pwn_ctx *h, const float cam[16], float sec, int slot)
 	if(cam == NULL || slot < 0 || slot >= g->nslots) return PWN_EINVAL;
 	if(h->blur_passes > 0 && (h->w & 3) != 0) return PWN_EINVAL;
 	if(g->in_flight[slot]) return PWN_EBUSY;
-	const bool sink = (g->flags & (PWN_FRAME_SBUF | PWN_FRAME_ZBUF)) != 0;
+	const bool sink = g->flags != 0;
 	int rc = tiling_up(g, sink ? MODE_SINK : MODE_RESIDENT);
 	if(rc != PWN_OK) return rc;
 	uint32_t *hs = sink ? g->h_sbuf[slot] : NULL;
 	float *hz = (g->flags & PWN_FRAME_ZBUF) ? g->h_zbuf[slot] : NULL;
+	uint32_t *hsurf = (g->flags & PWN_FRAME_SURFACE) ? g->h_surface[slot] : NULL;
 	// (posted, not waited for: the members enqueue the frame while the host goes on; a failure shows at the frame's pwn_wait_frame)
 	std::array<float, 16> cm;
 	memcpy(cm.data(), cam, sizeof(float) * 16);
 	// (depth plane `slot`: a frame slot's depth carries from the slot's previous frame, as a one-device context's slot planes do)
-	(void)post(g, [g, cm, sec, hs, hz, slot](int i) { return pwn_i_tiled_submit(g->m[i], cm.data(), sec, hs, hz, slot); });
+	(void)post(g, [g, cm, sec, hs, hz, slot, hsurf](int i) { return pwn_i_tiled_submit(g->m[i], cm.data(), sec, hs, hz, slot, hsurf); });
 	g->in_flight[slot] = true; g->delivered[slot] = false; g->sec[slot] = sec;
 	g->fifo[g->fifo_n++] = slot;
 	memset(&g->fdone[slot], 0, sizeof(pwn_frame));
@@ -563,6 +582,8 @@ static int deliver_oldest(pwn_group *g)
 	f.sec_current = g->sec[slot];
 	f.sbuf = (g->flags & PWN_FRAME_SBUF) ? g->h_sbuf[slot] : NULL;
 	f.zbuf = (g->flags & PWN_FRAME_ZBUF) ? g->h_zbuf[slot] : NULL;
+	f.surface = (g->flags & PWN_FRAME_SURFACE) ? g->h_surface[slot] : NULL;
+	f.surface_pitch_bytes = g->surf_pitch;
 	f.d_sbuf = g->tf[0].d_sbuf;               // nothing delivered: the frame as gathered on member 0's device
 	g->delivered[slot] = true;
 	return PWN_OK;

@@ -245,7 +245,8 @@ void pwn_tiled_destroy(pwn_ctx *c);
 bool pwn_tiled_busy(pwn_ctx *c);        // frames of the row tiling in flight
 // pwn_tiled.cpp internals used by pwn_group.cpp: a member's frame with the host buffers its strip is delivered into (NULL: the
 // frame stays on the devices and is gathered on member 0), and the switch that makes the tiling deliver to the host
-int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *host_sbuf, float *host_zbuf, int zplane);
+int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *host_sbuf, float *host_zbuf, int zplane, uint32_t *host_surface);
+int pwn_i_tiled_surface(pwn_ctx *c, int scale, int pitch_bytes);
 int pwn_i_tiled_sink(pwn_ctx *c);
 int pwn_i_tiled_ready(pwn_ctx *c, int ahead);
 // pwn_api.cpp: level_prepare_render's binning of a compact list of live spheres (no context: PWN_ETOOBIG where the lists would not

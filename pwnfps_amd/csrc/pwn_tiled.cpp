@@ -743,6 +743,11 @@ struct pwn_tiled
 	// a group (pwn_init_multi): where the slot's frame goes -- the caller's own sbuf / zbuf (main.c:31,33) or the group's pinned
 	// frames -- instead of a place in host_base; and what the members share
 	uint32_t *hdst[NSLOT]; float *hzdst[NSLOT];
+	// a group's frames with the SDL sink (PWN_FRAME_SURFACE; screen_upscale, screen.h:126-149): every member upscales its own strip on
+	// its device -- a strip of source rows [y0, y1) is the surface's words [y0 * rowadv, y1 * rowadv) -- and copies that into the
+	// host surface of the slot's frame; dsurf: one device plane per frame slot of the group's host (pwn_i_tiled_surface)
+	uint32_t *hsurf[NSLOT], *fsurf[NSLOT], *dsurf[PWN_MAX_SLOTS];
+	int surf_scale, surf_pitch_words;
 	float *fz[NSLOT];                   // the depth plane of the slot's frame: z[s], or -- a group -- the plane the group names: one per frame slot of ITS
 	                                    // host and one for the blocking calls, so that a pixel whose primary ray runs out of steps keeps the depth of the
 	                                    // slot's previous frame / of the previous call (trace.h:677), exactly as a one-device context's planes do
@@ -956,6 +961,7 @@ void pwn_tiled_destroy(pwn_ctx *c)
 		for(size_t i = 0; i < sizeof(evs) / sizeof(evs[0]); i++) if(*evs[i]) (void)hipEventDestroy(*evs[i]);
 	}
 	(void)hipFree(t->cost_acc); (void)hipFree(t->self_buf);
+	for(int i = 0; i < PWN_MAX_SLOTS; i++) (void)hipFree(t->dsurf[i]);
 	if(t->copy) (void)hipStreamDestroy(t->copy);
 	if(t->host_registered) (void)hipHostUnregister(t->host_registered);
 	if(t->h_missv) (void)hipHostFree(t->h_missv);
@@ -1276,6 +1282,25 @@ extern "C" int pwn_tiled_host_sink(pwn_ctx *c, void *base, size_t bytes)
 	return PWN_OK;
 }
 
+// ... and, with the sink of screen.h:126-149 wanted, upscales on every member: the device planes, zeroed (bytes between the rows of a
+// wider pitch read 0).  Behind pwn_i_tiled_sink, before the first frame.
+int pwn_i_tiled_surface(pwn_ctx *c, int scale, int pitch_bytes)
+{
+	if(c == NULL || c->tiled == NULL || scale < 1 || (pitch_bytes & 3) != 0 || (long long)pitch_bytes < (long long)c->w * scale * 4) return PWN_EINVAL;
+	pwn_tiled *t = c->tiled;
+	if(t->submitted != 0 || !t->sink) return PWN_EBUSY;
+	(void)hipSetDevice(c->device);
+	const size_t bytes = (size_t)pitch_bytes * (size_t)c->h * (size_t)scale;
+	for(int i = 0; i < PWN_MAX_SLOTS; i++)
+	{
+		if(hipMalloc((void **)&t->dsurf[i], bytes) != hipSuccess) return PWN_ENOMEM;
+		if(hipMemset(t->dsurf[i], 0, bytes) != hipSuccess) return PWN_EHIP;
+	}
+	if(hipDeviceSynchronize() != hipSuccess) return PWN_EHIP;
+	t->surf_scale = scale; t->surf_pitch_words = pitch_bytes / 4;
+	return PWN_OK;
+}
+
 // A group's tiling delivers to the host too, into the buffers handed over with every frame (pwn_i_tiled_submit): every
 // member copies its strip there over its own PCIe link.  Before the first frame.
 int pwn_i_tiled_sink(pwn_ctx *c)
@@ -1405,6 +1430,15 @@ static int copy_strip_to_host(pwn_ctx *c, pwn_tiled *t, int s)
 	}
 	HIPCHK(c, hipMemcpyAsync(frame_at + (size_t)y0 * w4, src + (size_t)y0 * c->w,
 		(size_t)(y1 - y0) * w4, hipMemcpyDeviceToHost, t->copy));
+	if(t->hsurf[s] != NULL)
+	{
+		// screen_upscale of this strip (the kernel of pwn_screen_upscale on the strip's rows: a source row's words start at row * rowadv),
+		// then its words to the host surface -- on the copy stream, behind the strip's colour
+		const size_t rowadv = (size_t)c->w * (size_t)t->surf_scale + (size_t)t->surf_pitch_words * (size_t)(t->surf_scale - 1);
+		HIPCHK(c, pwn_launch_upscale(src + (size_t)y0 * c->w, t->fsurf[s] + (size_t)y0 * rowadv, c->w, y1 - y0, t->surf_scale, t->surf_pitch_words, t->copy));
+		HIPCHK(c, hipMemcpyAsync(t->hsurf[s] + (size_t)y0 * rowadv, t->fsurf[s] + (size_t)y0 * rowadv, (size_t)(y1 - y0) * rowadv * 4, hipMemcpyDeviceToHost, t->copy));
+		t->info.bytes_to_host += (unsigned long long)(y1 - y0) * rowadv * 4ull;
+	}
 	HIPCHK(c, hipEventRecord(t->ev_h[s], t->copy));
 	t->info.bytes_to_host += (unsigned long long)(y1 - y0) * w4;
 	return PWN_OK;
@@ -1531,9 +1565,9 @@ static double now_us(void)
 	return (double)ts.tv_sec * 1e6 + (double)ts.tv_nsec * 1e-3;
 }
 
-extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec) { return pwn_i_tiled_submit(c, cam, sec, NULL, NULL, -1); }
+extern "C" int pwn_tiled_submit(pwn_ctx *c, const float cam[16], float sec) { return pwn_i_tiled_submit(c, cam, sec, NULL, NULL, -1, NULL); }
 
-int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *host_sbuf, float *host_zbuf, int zplane)
+int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *host_sbuf, float *host_zbuf, int zplane, uint32_t *host_surface)
 {
 	GRP_REFUSE(c);
 	if(c == NULL || cam == NULL || c->tiled == NULL) return PWN_EINVAL;
@@ -1553,6 +1587,12 @@ int pwn_i_tiled_submit(pwn_ctx *c, const float cam[16], float sec, uint32_t *hos
 	hipStream_t cs = counted ? t->cs[0] : t->cs[f % (unsigned long long)t->ncs];
 	t->fstream[s] = cs;
 	t->hdst[s] = host_sbuf; t->hzdst[s] = host_zbuf;
+	t->hsurf[s] = NULL; t->fsurf[s] = NULL;
+	if(host_surface != NULL)
+	{
+		if(t->surf_scale < 1 || zplane < 0 || zplane >= PWN_MAX_SLOTS || t->dsurf[zplane] == NULL) return PWN_EINVAL;
+		t->hsurf[s] = host_surface; t->fsurf[s] = t->dsurf[zplane];
+	}
 	t->fz[s] = (zplane >= 0 && zplane < NSLOT) ? t->z[zplane] : t->z[s];        // (the caller's frames in flight name different planes)
 	// (a counted frame right behind uncounted ones on the OTHER streams: wait for those frames' traces, so that the
 	// counters and the wave log are this launch's alone)

@@ -233,10 +233,11 @@ class Renderer:
         self._chk(lib.pwn_set_option(self._ctx, _lib.PWN_OPT_CALL_STRIPS, int(n)), "pwn_set_option(CALL_STRIPS)")
 
     def call_strips_state(self):
-        v = (C.c_ulonglong * 4)()
+        v = (C.c_ulonglong * 6)()
         self._chk(lib.pwn_call_strips_state(self._ctx, v), "pwn_call_strips_state")
         opt = int(v[0])
-        return {"option": opt - (1 << 64) if opt >= (1 << 63) else opt, "strips_last": int(v[1]), "calls_in_strips": int(v[2]), "redone": int(v[3])}
+        return {"option": opt - (1 << 64) if opt >= (1 << 63) else opt, "strips_last": int(v[1]), "calls_in_strips": int(v[2]), "redone": int(v[3]),
+                "copy_streams": int(v[4]), "reach_depth": int(v[5])}
 
     def host_register(self, arr):
         """pwn_host_register: the host's frame buffer (main.c:395-400), made known to the device once"""

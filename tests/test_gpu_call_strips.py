@@ -229,3 +229,29 @@ def test_both_forms_of_the_sphere_lists_give_the_goldens(oracle_lib, cases, monk
             post3, _ = r.trace_screen_centred(cam, c["sec"])
             assert (post3 == post).all(), (lists, hasw, name)
             r.close()
+
+
+def test_a_context_finds_out_about_its_copy_streams_once(oracle_lib, cases, monkeypatch):
+    """chunks go to the host on one copy stream or on two in turn -- which is faster depends on the queues the runtime handed the context --
+    so the first 8 calls in strips use one, the next 8 two, and the faster stays; every call delivers the golden frame meanwhile"""
+    c = _case(cases, "level_spawn_1920x1080")
+    r = _renderer(c["w"], c["h"])
+    cam = _load(r, c)
+    r.set_call_strips(6)
+    sb = np.zeros((c["h"], c["w"]), np.uint32)
+    r.host_register(sb)
+    for i in range(18):
+        r.trace_screen_centred(cam, c["sec"], want_z=False, sbuf=sb)
+        assert oracle_lib.fnv64(sb) == c["post"], i
+        st = r.call_strips_state()
+        assert (st["copy_streams"] == 0) == (i < 15) and st["copy_streams"] in (0, 1, 2), (i, st)
+    assert st["reach_depth"] == 8 and st["redone"] == 0
+    r.host_unregister(sb)
+    r.close()
+    monkeypatch.setenv("PWN_CALL_COPY_STREAMS", "2")
+    r = _renderer(c["w"], c["h"])
+    cam = _load(r, c)
+    r.set_call_strips(6)
+    post, _ = r.trace_screen_centred(cam, c["sec"])
+    assert r.call_strips_state()["copy_streams"] == 2 and oracle_lib.fnv64(post) == c["post"]
+    r.close()

@@ -100,6 +100,33 @@ def test_frames_that_stay_on_the_devices_are_gathered_on_member_0(oracle_lib, ca
     r.close()
 
 
+@pytest.mark.parametrize("members,scale,pad", [(2, 3, 0), (5, 2, 64), (3, 1, 0)])
+def test_frames_in_flight_with_the_sdl_sink(oracle_lib, cases, members, scale, pad):
+    """PWN_FRAME_SURFACE on a group: every member upscales its own strip (screen_upscale, screen.h:126-149) and copies those rows of the
+    surface to the host; with a pitch wider than the rows the reference's packed layout, the bytes between rows 0"""
+    c = _case(cases, "level_spawn_320x200")
+    w, h = c["w"], c["h"]
+    r = _group(w, h, members)
+    cam = _load(r, c)
+    pitch = w * scale * 4 + pad
+    r.frames_config(3, sbuf=True, surface_scale=scale, pitch_bytes=pitch)
+    O = oracle_lib.Oracle()
+    for f in range(7):
+        if f >= 3:
+            fr = r.wait_frame(f % 3)
+            assert oracle_lib.fnv64(fr["sbuf"]) == c["post"]
+            want = O.upscale(fr["sbuf"], scale, pitch_bytes=pitch)
+            assert fr["surface"].shape == want.shape and (fr["surface"] == want).all(), (f, members, scale, pad)
+        if f < 4:
+            r.set_objects(load_spheres(c["spheres"]))
+            r.submit_frame(cam, c["sec"], f % 3)
+    r.frames_config(0)
+    # the same handle's blocking call behind it
+    sb, _ = r.trace_screen_centred(cam, c["sec"])
+    assert oracle_lib.fnv64(sb) == c["post"]
+    r.close()
+
+
 def test_one_object_table_behind_the_handle(oracle_lib):
     """obj_new / obj_set / obj_free (script.h:10-51) act on the handle's ONE table; level_prepare_render (main.c:95) brings every
     member's device up to date.  Against the oracle, frame by frame, while spheres move, appear and go."""
@@ -186,7 +213,7 @@ def test_upscale_of_the_delivered_frame_and_what_a_group_refuses(oracle_lib, cas
     big = r.screen_upscale(None, 3)                 # main.c:108 behind main.c:107
     assert (big == O.upscale(sb, 3)).all()
     for call in (lambda: r.tiled_info(), lambda: r.tiled_submit(cam, 0.0), lambda: r.tiled_wait(),
-                 lambda: r.trace_rows_device(cam, 0.0, 0, 8, 1, 1), lambda: r.frames_config(2, sbuf=True, surface_scale=2)):
+                 lambda: r.trace_rows_device(cam, 0.0, 0, 8, 1, 1)):
         with pytest.raises(pwnfps_amd.PwnError) as e:
             call()
         assert e.value.code == _lib.PWN_ENOTSUP

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Issue model of pwn_trace_kernel<false,false>: what its instruction stream costs the SIMDs, region by region.
+"""Issue model of pwn_trace_kernel<false,false,false,true> (no counters, 3 lanes, unit order, inline sphere records): what its instruction stream costs the SIMDs, region by region.
 
     static    the kernel's ISA (hipcc -S with line tables, the Makefile's flags), every instruction attributed to a REGION
               of the source through its .loc chain (the `//@R name` comments of trace_kernel.hip / trace_walk.inc mark
@@ -8,13 +8,13 @@
               branch, LDS, vector memory, other (waitcnt, nop)
     dynamic   how often a wave64 runs each region with at least one lane: the counting variant's counters
               (pwn_stats.wave_steps, wave_paths, regions), taken on the GPU by tools/region_counts.py
-              -> profiles/r4_region_counts.json
+              -> profiles/r5_region_counts.json
     costs     ns of SIMD issue per wave-instruction, tools/ubench/valu_rate.hip (profiles/r3_valu_rate.txt): full-rate
               1 / 0.91, half-rate 1 / 0.545, quarter-rate 1 / 0.29 at 5 waves per SIMD with one opcode; 1 / 1.00, 1 / 0.57,
               1 / 0.293 saturated.  Scalar and branch instructions are counted, not priced: they issue beside the VALU
               instructions of other waves (the table shows what they would add if they did not)
 
-    python3 tools/issue_model.py [--counts profiles/r4_region_counts.json] [--out profiles/r4_issue_model]
+    python3 tools/issue_model.py [--counts profiles/r5_region_counts.json] [--out profiles/r5_issue_model]
 
 Prints the per-region table for the headline scene, the instruction totals against the PMC counters of the same
 launch (profiles/pmc_latest.csv: the check that the COUNTS are right, independent of any timing), and predicted
@@ -30,7 +30,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "pwnfps_amd", "csrc")
-KERNEL = "_Z16pwn_trace_kernelILb0ELb0ELb0EEv16pwn_trace_params"
+KERNEL = "_Z16pwn_trace_kernelILb0ELb0ELb0ELb1EEv16pwn_trace_params"
 
 FULL = {"v_add_f32", "v_sub_f32", "v_subrev_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mac_f32", "v_add_u32", "v_sub_u32",
         "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_mov_b32", "v_bitop3_b32", "v_not_b32", "v_add_co_u32", "v_addc_co_u32",
@@ -85,7 +85,7 @@ def slow_ranges():
 def region_maps():
     """file -> sorted [(line, region)] from the //@R markers"""
     out = {}
-    for name in ("trace_kernel.hip", "trace_walk.inc"):
+    for name in ("trace_kernel.hip", "trace_walk.inc", "trace_sphere.inc"):
         marks = []
         for i, line in enumerate(open(os.path.join(CSRC, name)), 1):
             m = re.search(r"//@R (\w+)", line)
@@ -204,7 +204,7 @@ COUNT_OF = {        # region -> key of the counts
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--counts", default=os.path.join(ROOT, "profiles", "r4_region_counts.json"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4_issue_model"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r5_issue_model"))
     ap.add_argument("--asm", default=None, help="an existing .s (else compiled here)")
     args = ap.parse_args()
 
@@ -221,7 +221,7 @@ def main():
         blocks[reg].add(b)
     lines = []
     P = lines.append
-    P("# issue model of pwn_trace_kernel<false,false> (tools/issue_model.py); static part: %d instructions in %d regions" % (len(ins), len(per)))
+    P("# issue model of pwn_trace_kernel<false,false,false,true> (tools/issue_model.py); static part: %d instructions in %d regions" % (len(ins), len(per)))
     P("# costs per wave-instruction and SIMD at 5 waves / SIMD (profiles/r3_valu_rate.txt): full-rate VALU %.2f ns, half-rate %.2f ns, quarter-rate %.2f ns"
       % (COST["full"], COST["half"], COST["quarter"]))
     P("")
@@ -243,7 +243,7 @@ def main():
     # the instruction counters of the 4K level.txt launch: the committed PMC summary of the same build
     try:
         rows = [ln.rstrip("\n").rsplit(",", 3) for ln in open(os.path.join(ROOT, "profiles", "pmc_latest.csv"))]
-        v = {r[1]: float(r[3]) for r in rows if len(r) == 4 and "pwn_trace_kernel" in r[0] and "<true" not in r[0] and ", true>" not in r[0]}
+        v = {r[1]: float(r[3]) for r in rows if len(r) == 4 and "pwn_trace_kernel<false, false, false, true>" in r[0]}
         for sc in scenes:
             if (sc["level"], sc["w"], sc["h"]) == ("pwnfps_level", 3840, 2160):
                 sc["pmc"] = {k: v[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS")}

@@ -18,6 +18,7 @@ for level, w, h in [("pwnfps_level", 3840, 2160), ("synth64", 1920, 1080), ("syn
     sph = np.load(os.path.join(gold, "spheres_t0.npy" if level == "pwnfps_level" else os.path.join("levels", level + "_spheres.npy")))
     r.set_objects(sph)
     r.set_blur_passes(0)
+    r.set_call_strips(0)   # one launch per pass
     _, _, spawn = r.get_level()
     cam = pwnfps_amd.spawn_camera(spawn)
     if level != "pwnfps_level":

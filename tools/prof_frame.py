@@ -24,6 +24,8 @@ if os.environ.get("PWN_NOSPH"):
     sph = sph[:0]
 r.set_objects(sph)
 r.set_blur_passes(blur)
+if not os.environ.get("PWN_PROF_STRIPS"):
+    r.set_call_strips(0)             # one launch per pass: the counters are per whole-frame dispatch
 _, _, spawn = r.get_level()
 cam = pwnfps_amd.spawn_camera(spawn)
 if level != "pwnfps_level":

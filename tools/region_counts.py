@@ -36,6 +36,7 @@ for level, w, h in (("pwnfps_level", 3840, 2160), ("pwnfps_level", 1280, 720), (
     r.level_load(os.path.join(gold, "levels", level + ".txt"))
     r.set_objects(np.load(os.path.join(gold, "spheres_t0.npy" if level == "pwnfps_level" else os.path.join("levels", level + "_spheres.npy"))))
     r.set_blur_passes(0)
+    r.set_call_strips(0)               # one launch per pass
     _, _, spawn = r.get_level()
     cam = pwnfps_amd.spawn_camera(spawn) if level == "pwnfps_level" else np.load(os.path.join(gold, "levels", level + "_cams.npy"))[0]
     sb = np.empty((h, w), np.uint32)

@@ -21,6 +21,7 @@ r = pwnfps_amd.Renderer(w, h)
 r.level_load(os.path.join(gold, "levels", level + ".txt"))
 r.set_objects(np.load(os.path.join(gold, "spheres_t0.npy" if level == "pwnfps_level" else os.path.join("levels", level + "_spheres.npy"))))
 r.set_blur_passes(0)
+r.set_call_strips(0)   # one launch per pass
 _, _, spawn = r.get_level()
 cam = pwnfps_amd.spawn_camera(spawn)
 if level != "pwnfps_level":

@@ -21,6 +21,7 @@ r.set_objects(np.load(os.path.join(gold, "spheres_t0.npy" if level == "pwnfps_le
 _, _, spawn = r.get_level()
 cam = pwnfps_amd.spawn_camera(spawn) if level == "pwnfps_level" else np.load(os.path.join(gold, "levels", level + "_cams.npy"))[0]
 r.set_blur_passes(0)
+r.set_call_strips(0)   # one launch per pass
 r.set_counters(True)
 r.trace_screen_centred(cam, 0.0, want_z=False)
 st = r.stats()
