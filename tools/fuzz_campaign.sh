@@ -25,4 +25,4 @@ run stripsbig$((S+14)) env PWN_CALL_STRIPS=8 python tools/fuzz_parity.py 100 $((
 run inl$((S+15)) env PWN_SPHERE_LISTS=inline python tools/fuzz_parity.py 2000 $((S+15))
 run inlw$((S+16)) env PWN_SPHERE_LISTS=inline PWN_DBG_FORCE_HASW=1 python tools/fuzz_parity.py 1500 $((S+16)) --lattice
 run idx$((S+17)) env PWN_SPHERE_LISTS=indexed python tools/fuzz_parity.py 1500 $((S+17))
-run group$((S+18)) python tools/fuzz_group.py 90 $((S+18))
+run group$((S+18)) python tools/fuzz_group.py 120 $((S+18))

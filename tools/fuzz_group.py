@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised campaign for pwn_init_multi: random levels, cameras, sphere sets, frame sizes and member counts -- every frame of a
 group of 2..7 members on device 0 (blocking calls with depth carried over 20 calls while the cuts move; frames in flight delivered
-and resident) against the SAME calls on one context, which tools/fuzz_parity.py holds against the oracle.  Run on the GPU box:
+resident, and with the upscaled SDL surface) against the SAME calls on one context, which tools/fuzz_parity.py holds against the oracle.  Run on the GPU box:
     python3 tools/fuzz_group.py [N_SCENES [SEED]]
 One line per mismatch, a summary, exit code 1 on any mismatch."""
 import os
@@ -58,7 +58,9 @@ for it in range(n):
     blur = int(rng.integers(0, 4) != 0)
     one.set_blur_passes(blur)
     grp.set_blur_passes(blur)
-    mode = it % 3                 # 0 blocking, 1 delivered in flight, 2 resident in flight
+    mode = it % 4                 # 0 blocking, 1 delivered in flight, 2 resident in flight, 3 delivered with the upscaled surface
+    rscale = int(rng.integers(1, 4))
+    pitch = 4 * (w * rscale + int(rng.integers(0, 9)))
     nframes = 20 if mode == 0 else 9
     cams, secs, sphs = [], [], []
     ay = rng.uniform(0, 6.28)
@@ -84,11 +86,18 @@ for it in range(n):
                 sb, zb = r.trace_screen_centred(cams[f], secs[f])
                 out.append((sb.copy(), zb.copy()))
             return out
-        r.frames_config(3, sbuf=(mode == 1), zbuf=(mode == 1))
+        if mode == 3:
+            r.frames_config(3, sbuf=True, zbuf=False, surface_scale=rscale, pitch_bytes=pitch)
+        else:
+            r.frames_config(3, sbuf=(mode == 1), zbuf=(mode == 1))
         for f in range(nframes + 3):
             if f >= 3:
                 fr = r.wait_frame(f % 3)
-                out.append((fr["sbuf"].copy(), fr["zbuf"].copy()) if mode == 1 else (r.read_plane(fr["d_sbuf"]), None))
+                if mode == 3:
+                    # (the surface's pixels: the pad columns behind w * rscale belong to the host)
+                    out.append((np.concatenate([fr["sbuf"].ravel(), fr["surface"][:, :w * rscale].ravel()]), None))
+                else:
+                    out.append((fr["sbuf"].copy(), fr["zbuf"].copy()) if mode == 1 else (r.read_plane(fr["d_sbuf"]), None))
             if f < nframes:
                 r.set_objects(sphs[f])
                 r.submit_frame(cams[f], secs[f], f % 3)

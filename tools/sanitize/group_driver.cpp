@@ -49,8 +49,10 @@ static int run_frames(pwn_ctx *ctx, int w, int h, int frames, std::vector<std::v
 		}
 		return 0;
 	}
-	// frames in flight: mode 1 delivered to the host, mode 2 left on the device(s)
-	CK(pwn_frames_config(ctx, 3, mode == 1 ? (PWN_FRAME_SBUF | PWN_FRAME_ZBUF) : 0, 1, 0));
+	// frames in flight: mode 1 delivered to the host, mode 2 left on the device(s), mode 3 delivered with the upscaled surface (pitch wider than the rows)
+	const int scale = 2, pitch = w * scale * 4 + 16;
+	if(mode == 3) CK(pwn_frames_config(ctx, 3, PWN_FRAME_SBUF | PWN_FRAME_SURFACE, scale, pitch));
+	else CK(pwn_frames_config(ctx, 3, mode == 1 ? (PWN_FRAME_SBUF | PWN_FRAME_ZBUF) : 0, 1, 0));
 	std::vector<uint32_t> tmp(n);
 	for(int f = 0; f < frames + 3; f++)
 	{
@@ -59,6 +61,14 @@ static int run_frames(pwn_ctx *ctx, int w, int h, int frames, std::vector<std::v
 			pwn_frame fr;
 			CK(pwn_wait_frame(ctx, f % 3, &fr));
 			if(mode == 1) { out.push_back(std::vector<uint32_t>(fr.sbuf, fr.sbuf + n)); zout.push_back(std::vector<float>(fr.zbuf, fr.zbuf + n)); }
+			else if(mode == 3)
+			{
+				// (screen.h:132,138-139: a source row takes w*scale + pitch*(scale-1) words of the surface)
+				std::vector<uint32_t> both(fr.sbuf, fr.sbuf + n);
+				const size_t rowadv = (size_t)w * scale + (size_t)(pitch / 4) * (scale - 1);
+				both.insert(both.end(), fr.surface, fr.surface + rowadv * (size_t)h);
+				out.push_back(both);
+			}
 			else { CK(pwn_read_plane(ctx, fr.d_sbuf, tmp.data(), n * 4)); out.push_back(tmp); }
 		}
 		if(f < frames)
@@ -90,8 +100,8 @@ static int group_runs(int w, int h)
 {
 	const int frames = 30;
 	pwn_ctx *ctx = NULL;
-	std::vector<std::vector<uint32_t>> ref[3]; std::vector<std::vector<float>> zref[3];
-	for(int mode = 0; mode < 3; mode++)
+	std::vector<std::vector<uint32_t>> ref[4]; std::vector<std::vector<float>> zref[4];
+	for(int mode = 0; mode < 4; mode++)
 	{
 		CK(pwn_init(&ctx, 0, w, h));
 		CK(pwn_level_load_mem(ctx, LEVEL, (int)strlen(LEVEL)));
@@ -100,7 +110,7 @@ static int group_runs(int w, int h)
 	}
 	int bad = 0;
 	for(int members = 2; members <= 5; members++)
-		for(int mode = 0; mode < 3; mode++)
+		for(int mode = 0; mode < 4; mode++)
 		{
 			int devs[8];
 			for(int i = 0; i < members; i++) devs[i] = (mode == 2) ? i : 0;       // (distinct ordinals too: the peer-copy branch of the transport)
@@ -108,9 +118,9 @@ static int group_runs(int w, int h)
 			CK(pwn_level_load_mem(ctx, LEVEL, (int)strlen(LEVEL)));
 			std::vector<std::vector<uint32_t>> got; std::vector<std::vector<float>> zgot;
 			run_frames(ctx, w, h, frames, got, zgot, mode);
-			bad |= same(ref[mode], got, mode == 0 ? "blocking" : mode == 1 ? "delivered" : "resident", members);
+			bad |= same(ref[mode], got, mode == 0 ? "blocking" : mode == 1 ? "delivered" : mode == 2 ? "resident" : "surface", members);
 			// (depth: a pixel the trace leaves alone keeps the previous call's value, or the value of the frame that had the slot before)
-			if(mode != 2) for(size_t f = 0; f < zgot.size(); f++) if(memcmp(zgot[f].data(), zref[mode][f].data(), zgot[f].size() * 4) != 0) { fprintf(stderr, "%s, %d members: depth of frame %zu differs\n", mode == 0 ? "blocking" : "delivered", members, f); bad = 1; break; }
+			if(mode < 2) for(size_t f = 0; f < zgot.size(); f++) if(memcmp(zgot[f].data(), zref[mode][f].data(), zgot[f].size() * 4) != 0) { fprintf(stderr, "%s, %d members: depth of frame %zu differs\n", mode == 0 ? "blocking" : "delivered", members, f); bad = 1; break; }
 			pwn_group_info gi;
 			CK(pwn_group_info_get(ctx, &gi));
 			// (a bounded halo is in force to begin with where the shortest strip of the equal split holds it: the deep band then forces a repeat)
