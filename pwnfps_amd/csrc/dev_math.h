@@ -89,13 +89,17 @@ template<class TP> __device__ __forceinline__ float tab_rcp_pos(TP tab, float x)
 	return __uint_as_float(rcp_entry(tab, a) - (a & 0x7f800000u));
 }
 
-template<class TP> __device__ __forceinline__ float tab_rsqrt(TP tab, float x)
+// (in two halves, so that a caller can put work of its own between the table read and its use)
+template<class TP> __device__ __forceinline__ uint32_t tab_rsqrt_entry(TP tab, uint32_t b)
 {
-	uint32_t b = __float_as_uint(x);
+	// every lane takes the table path (the index is in range whatever the bits are)
+	return (uint32_t)tab[(b >> 13) & 2047u];
+}
+__device__ __forceinline__ float tab_rsqrt_finish(uint32_t b, uint32_t entry)
+{
 	uint32_t r;
-	// every lane takes the table path (the index is in range whatever the bits are); the rest is patched in
-	// behind ONE wave-uniform branch
-	r = (PWN_RSQ_BASE + ((uint32_t)tab[(b >> 13) & 2047u] << 11)) - (((b + 0x00800000u) >> 1) & 0x7f800000u);
+	// ... the rest is patched in behind ONE wave-uniform branch
+	r = (PWN_RSQ_BASE + (entry << 11)) - (((b + 0x00800000u) >> 1) & 0x7f800000u);
 	const bool special = !(b - 0x00800000u < 0x7f000000u);
 	if(__builtin_expect(__ballot(special) != 0ull, 0))
 	{
@@ -110,6 +114,11 @@ template<class TP> __device__ __forceinline__ float tab_rsqrt(TP tab, float x)
 //@FAST
 	}
 	return __uint_as_float(r);
+}
+template<class TP> __device__ __forceinline__ float tab_rsqrt(TP tab, float x)
+{
+	const uint32_t b = __float_as_uint(x);
+	return tab_rsqrt_finish(b, tab_rsqrt_entry(tab, b));
 }
 
 template<class TP> __device__ __forceinline__ v4 v4_normalise(TP rsq, v4 a)

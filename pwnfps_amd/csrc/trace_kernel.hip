@@ -85,32 +85,57 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		aux_norm = aux_pos;
 		if(COUNT) cnt.rays++;
 
+		// The set-up's table reads (1/sqrt, the first cell's word, three reciprocals) are each issued ahead of work that does not
+		// need them -- the compiler leaves an LDS read where the source has it, directly in front of its use, and sinks one that
+		// only a branch uses into that branch: -0.3 % launch time at 4K, -0.5 % on synth64 (profiles/r5/sphere_lists_ab.txt).
 		V pos = from;
-		V ray = vnormalise<HAS_W>(L.rsq, iray);
+		const uint32_t lb = __float_as_uint(dot3<HAS_W>(iray, iray));
+		const uint32_t rsq_e = tab_rsqrt_entry(L.rsq, lb);
 		int cx = (int)from.x, cz = (int)from.z;
 		// signs of the UN-normalised input (trace.h:225-227)
 		int gx = (iray.x < 0.0f ? -1 : 1);
 		int gz = (iray.z < 0.0f ? -1 : 1);
 		const bool gyp = !(iray.y < 0.0f);          // gy > 0
+		// cell coordinates and steps in the packed form the walk uses (trace_common.h)
+		uint32_t cxz = cxz_pack_start(cx, cz), sx = (uint32_t)gx & 0xffffu, sz = (uint32_t)gz << 16;
+		uint32_t cw = cellword_pk(L, cxz);
+		float wx = pos.x - (float)cx, wy = pos.y, wz = pos.z - (float)cz;
+		const int ldy = gyp ? FYP : FYN;
+		int ldx = (gx < 0 ? FXN : FXP), ldz = (gz < 0 ? FZN : FZP);
+		// util.h:32-46
+		V ray = vscale<HAS_W>(tab_rsqrt_finish(lb, rsq_e), iray);
 		// trace.h:220-222 clamp |ray| to EPSILON, trace.h:230-231 take the three reciprocals.  A normalised ray
 		// has all three magnitudes in [EPSILON, 2^126) unless it is degenerate: ONE test on the bit patterns
 		// (a NaN's is above every number's) and one wave-uniform branch; then nothing is clamped and all three
-		// reciprocals are the one-subtract table path (one LDS round trip)
+		// reciprocals are the one-subtract table path (one LDS round trip, under way while the fractions are turned:
+		// a table index is in range whatever the bits are)
 		float iax, iaz, iay_;
 		{
 			const uint32_t EPSB = __float_as_uint(EPS);
 			const uint32_t bx = __float_as_uint(ray.x) & 0x7fffffffu, by = __float_as_uint(ray.y) & 0x7fffffffu,
 				bz = __float_as_uint(ray.z) & 0x7fffffffu;
+			uint32_t ex = rcp_entry(L.rcp, bx), ey = rcp_entry(L.rcp, by), ez = rcp_entry(L.rcp, bz);
 			const bool plain = max(max(bx - EPSB, by - EPSB), bz - EPSB) < 0x7e800000u - EPSB;
+			if(ray.x >= 0.0f) wx = 1.0f - wx;
+			if(ray.y >= 0.0f) wy = 1.0f - wy;
+			if(ray.z >= 0.0f) wz = 1.0f - wz;
+			// (statements the compiler may not reorder: the fractions first, then the wait for the table.  Not in the 4-lane
+			// variant: its ordered form would need 12 bytes of scratch per lane for them)
+			if constexpr(!HAS_W)
+			{
+				asm volatile("" : "+v"(wx), "+v"(wy), "+v"(wz));
+				asm volatile("" : "+v"(ex), "+v"(ey), "+v"(ez));
+			}
 			if(__builtin_expect(__ballot(!plain) == 0ull, 1))
 			{
-				iax = tab_rcp_pos(L.rcp, __uint_as_float(bx)); iay_ = tab_rcp_pos(L.rcp, __uint_as_float(by));
-				iaz = tab_rcp_pos(L.rcp, __uint_as_float(bz));
+				iax = __uint_as_float(ex - (bx & 0x7f800000u)); iay_ = __uint_as_float(ey - (by & 0x7f800000u));
+				iaz = __uint_as_float(ez - (bz & 0x7f800000u));
 			}
 			else
 			{
 				//@R p_setup_slow
 				RG(RG_SETUP_SLOW);
+				// (the fractions above were turned by the unclamped signs: the clamp keeps ">= 0" as it was -- -0 counts as +)
 				if(fabsf(ray.x) < EPS) ray.x = (ray.x < 0.0f ? -EPS : EPS);
 				if(fabsf(ray.y) < EPS) ray.y = (ray.y < 0.0f ? -EPS : EPS);
 				if(fabsf(ray.z) < EPS) ray.z = (ray.z < 0.0f ? -EPS : EPS);
@@ -119,22 +144,12 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		}
 		//@R p_setup
 		const float iay = iay_;
-		float wx = pos.x - (float)cx, wy = pos.y, wz = pos.z - (float)cz;
-		if(ray.x >= 0.0f) wx = 1.0f - wx;
-		if(ray.y >= 0.0f) wy = 1.0f - wy;
-		if(ray.z >= 0.0f) wz = 1.0f - wz;
 		wx *= iax; wy *= iay; wz *= iaz;
 		// the "-part of a two-level room shifts the floor by one: wy moves by -+iay
 		// (trace.h:345-349,381-385); iay_dn is the amount added when stepping DOWN into it
 		const float iay_dn = gyp ? iay : -iay;
-		const int ldy = gyp ? FYP : FYN;
-		int ldx = (gx < 0 ? FXN : FXP), ldz = (gz < 0 ? FZN : FZP);
 		uint32_t iay_up_bits = gyp ? __float_as_uint(iay) : 0u;         // +iay when looking up, else +0
 		asm volatile("" : "+v"(iay_up_bits));        // keep it a register, not a select on gyp per step
-		// cell coordinates and steps in the packed form the walk uses (trace_common.h)
-		uint32_t cxz = cxz_pack_start(cx, cz), sx = (uint32_t)gx & 0xffffu, sz = (uint32_t)gz << 16;
-
-		uint32_t cw = cellword_pk(L, cxz);
 		int ldir = FYN;
 		int ev = EV_NONE, base = BASE_ROOM_Y;
 
