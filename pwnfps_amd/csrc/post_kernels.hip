@@ -212,7 +212,7 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 	{
 		// The shipped form: (1) the thread's own two loads from HBM (skip-ahead constants, depths) are asked for first and
 		// used behind the barrier, and (2) all of its staging loads are in flight together, from an address clamped into the
-		// frame (what lies outside is not stored) -- as the plain loop above the compiler waits for every load before it
+		// frame (round 5: what lies outside IS stored, as the pixel its coordinates clamp to) -- as the plain loop above the compiler waits for every load before it
 		// issues the next, and a workgroup has nothing else to do until its tile is there (profiles/r3_blur_staging.txt,
 		// r3_blur_sweep.txt: batch 1 against batch 0).
 		const int gq = mine ? g : 0, cyq = mine ? cy : P.y0;
@@ -223,16 +223,20 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 		static_assert(NT >= 1 && NT <= 8, "the barrier below names its operands");
 		u32x4 r[NT];
 		int dst[NT];
+		int edge[NT];
 #pragma unroll
 		for(int k = 0; k < NT; k++)
 		{
 			const int i = (int)threadIdx.x + k * BLUR_THREADS;
 			const int row = i / (BLUR_LW / 4), c4 = i - row * (BLUR_LW / 4);
 			const int gy = ly0 + row, gx = lx0 + c4 * 4;
-			const bool in = i < NV && (unsigned)gy < (unsigned)P.h && (unsigned)gx < (unsigned)P.w;
-			dst[k] = in ? row * BLUR_PITCH + c4 * 4 : -4;
+			// every cell of the rectangle is stored: one outside the frame holds the pixel its coordinates CLAMP to (screen.h:103-106
+			// clamp x and y one by one), so that a tap is looked up by its unclamped coordinates and clamped only where it leaves
+			// the rectangle
+			dst[k] = i < NV ? row * BLUR_PITCH + c4 * 4 : -4;
 			const int gyc = min(max(gy, 0), P.h - 1), gxc = min(max(gx, 0), P.w - 4);
 			r[k] = *(const u32x4 *)(P.pre + (size_t)gyc * (size_t)P.w + (size_t)gxc);
+			edge[k] = gx < 0 ? 1 : (gx >= P.w ? 2 : 0);
 		}
 		// (all of them live at one point: the loads cannot be sunk to their stores one by one)
 		if constexpr(NT == 2) asm volatile("" : "+v"(r[0]), "+v"(r[1]));
@@ -242,6 +246,12 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 		if constexpr(NT == 6) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]));
 		if constexpr(NT == 7) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]));
 		if constexpr(NT == 8) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+#pragma unroll
+		for(int k = 0; k < NT; k++)
+		{
+			if(edge[k] == 1) r[k] = (u32x4){ r[k].x, r[k].x, r[k].x, r[k].x };
+			if(edge[k] == 2) r[k] = (u32x4){ r[k].w, r[k].w, r[k].w, r[k].w };
+		}
 #pragma unroll
 		for(int k = 0; k < NT; k++)
 			if(dst[k] >= 0) *(u32x4 *)__builtin_assume_aligned(tile + dst[k], 16) = r[k];
@@ -297,6 +307,34 @@ pwn_blur_tiled_kernel(pwn_blur_params P)
 				// screen.h:101-106
 				const float fx = fcx[j] + (lcg2_fs(t2) * fstr) * z[j];
 				const float fy = fcy + (lcg2_fs(t2) * fstr) * z[j];
+				if constexpr(BATCH == 1)
+				{
+					int cx_, cy_;
+					asm("v_cvt_i32_f32 %0, %1" : "=v"(cx_) : "v"(fx));
+					asm("v_cvt_i32_f32 %0, %1" : "=v"(cy_) : "v"(fy));
+					if(CHECK)
+					{
+						int y0c;
+						asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y0c) : "v"(cy_), "v"(vh1));
+						missed |= (unsigned)(y0c - P.avail_y0) >= (unsigned)(P.avail_y1 - P.avail_y0);
+					}
+					// (unclamped: the rectangle's cells outside the frame hold what the clamp would have fetched)
+					const unsigned tx = (unsigned)(cx_ - lx), ty = (unsigned)(cy_ - ly);
+					const uint32_t *p = tile + (ty * BLUR_PITCH + tx);
+					bool inside;
+					if constexpr(BLUR_LW == 64 && BLUR_LH == 64) inside = (tx | ty) < 64u;
+					else inside = tx < (unsigned)BLUR_LW && ty < (unsigned)BLUR_LH;
+					if(!inside)
+					{
+						asm volatile("");
+						int x0c, y0c;
+						asm("v_med3_i32 %0, %1, 0, %2" : "=v"(x0c) : "v"(cx_), "v"(vw1));
+						asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y0c) : "v"(cy_), "v"(vh1));
+						p = (const uint32_t *)(pre0 + ((uintptr_t)__umul24((unsigned)y0c, w0) + (uintptr_t)(unsigned)x0c) * 4u);
+					}
+					tap[i][j] = *p;
+					continue;
+				}
 				int x0c, y0c, cx_, cy_;
 				asm("v_cvt_i32_f32 %0, %1" : "=v"(cx_) : "v"(fx));
 				asm("v_cvt_i32_f32 %0, %1" : "=v"(cy_) : "v"(fy));

@@ -13,8 +13,8 @@ for t in $TAGS; do
 		python3 bench.py --level $1 --width $2 --height $3 --steps 50 --warmup 10 --min-time 1 --no-cpu-baseline --no-d2h 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][0])
-print('%-5s $1 $2x$3: two streams %.1f Mpix/s %.4f ms/frame | one stream %.4f ms/frame | launch by itself %.4f ms | hash %s' % (
- '$t', d['value'], d['ms_per_step'], d['timing']['roofline_leg']['ms_per_step'], d['roofline']['avg_launch_ms'], d['frame_fnv64']))"
+print('%-5s $1 $2x$3: two streams %.1f Mpix/s %.4f ms/frame | one stream %.4f ms/frame | launch by itself %.4f ms | blur %.4f ms | hash %s' % (
+ '$t', d['value'], d['ms_per_step'], d['timing']['roofline_leg']['ms_per_step'], d['roofline']['avg_launch_ms'], d['blur_roofline']['avg_launch_ms'], d['frame_fnv64']))"
 	done
 done
 done 2>&1 | tee $O/ab.txt
