@@ -417,7 +417,7 @@ def single_process(args):
         return float(np.median(blocks)), blocks
     r.frames_config(nsl, sbuf=False)
     dt, block_s = leg(args.warmup, args.min_time)
-    one = {"members": 1, "transport": None, "devices": devices, "cuts": [0, h], "halo_rows": 0, "host_sink": False, "frames": 0, "frames_redone": 0, "recuts": 0}
+    one = {"members": 1, "transport": None, "devices": devices, "cuts": [0, h], "halo_rows": 0, "host_sink": False, "frames": 0, "frames_redone": 0, "recuts": 0, "note": ""}
     gi = r.group_info() if n > 1 else one
     trace_ms = float(np.mean(launch_ms)) if launch_ms else 0.0
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -466,7 +466,7 @@ def single_process(args):
                   + (" -- ALL MEMBERS ON ONE DEVICE (test hook): not a multi-GPU figure" if one_device else ""),
         "value": round(pix * args.steps / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "single_process": True, "transport": gi["transport"], "devices": devices,
+        "single_process": True, "transport": gi["transport"], "transport_note": gi.get("note") or None, "devices": devices,
         "timing": {"blocks_of_k_steps": len(block_s), "value_is": "median block",
                    "block_ms_p10_p50_p90": [round(float(np.percentile(block_s, q)) * 1e3, 4) for q in (10, 50, 90)]},
         "config": {"workload": "pwnfps level.txt scene (14 game.lua spheres, spawn pose, sec_current=0), %dx%d, POSTPROC_BLUR=%d, one frame per step" % (w, h, args.blur),

@@ -203,6 +203,9 @@ typedef struct pwn_group_info
 	int cuts[65];                            /* member m traces rows [cuts[m], cuts[m + 1]) of the next frame */
 	int halo_rows, host_sink;                /* of the tiling in force (0, 0 before the first frame) */
 	uint64_t frames, frames_redone, recuts;  /* delivered; repeated with whole strips; how often the cuts moved */
+	char note[160];                          /* why the transport is not RCCL (members on one device; librccl did not load; its
+	                                            bring-up between the members failed -- the group then goes on with copies, once, unless
+	                                            PWN_GROUP_TRANSPORT named the transport), or empty */
 } pwn_group_info;
 int pwn_init_multi(pwn_ctx **out, const int *devices, int ndev, int width, int height);
 int pwn_group_info_get(pwn_ctx *ctx, pwn_group_info *out);

@@ -68,7 +68,7 @@ class TiledInfo(C.Structure):
 
 class GroupInfo(C.Structure):
     _fields_ = [("members", C.c_int), ("transport", C.c_int), ("devices", C.c_int * 64), ("cuts", C.c_int * 65),
-                ("halo_rows", C.c_int), ("host_sink", C.c_int), ("frames", C.c_uint64), ("frames_redone", C.c_uint64), ("recuts", C.c_uint64)]
+                ("halo_rows", C.c_int), ("host_sink", C.c_int), ("frames", C.c_uint64), ("frames_redone", C.c_uint64), ("recuts", C.c_uint64), ("note", C.c_char * 160)]
 
 
 PWN_TILED_ID_BYTES = 128

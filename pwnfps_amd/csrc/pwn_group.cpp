@@ -36,6 +36,8 @@ enum { MODE_NONE = 0, MODE_SINK = 1, MODE_RESIDENT = 2 };
 struct pwn_group
 {
 	int n, transport;
+	bool transport_fixed;                        // PWN_GROUP_TRANSPORT named it: no falling back
+	char note[160];                              // why RCCL is not what carries the rows (pwn_group_info.note), or empty
 	pwn_ctx *head, *m[MAXM];
 	int devices[MAXM];
 	pwn_hub hub;
@@ -248,6 +250,15 @@ static int tiling_up(pwn_group *g, int mode)
 		g->mode = mode;               // (whatever came up goes down again)
 		tiling_down(g);
 		memcpy(g->head->err, keep, sizeof(keep));
+		// RCCL did not come up between the members (it has never had to, on this pool): the rows can travel as copies between the
+		// members' planes instead -- in one process nothing else is needed.  Once, and said in pwn_group_info.note; a host that
+		// named the transport (PWN_GROUP_TRANSPORT) gets the error.
+		if(g->transport == PWN_TRANSPORT_RCCL && !g->transport_fixed)
+		{
+			snprintf(g->note, sizeof(g->note), "RCCL did not come up (%s: %.100s): copies between the members instead", pwn_strerror(rc), keep);
+			g->transport = PWN_TRANSPORT_LOCAL;
+			return tiling_up(g, mode);
+		}
 		return rc;
 	}
 	g->mode = mode;
@@ -314,12 +325,19 @@ extern "C" int pwn_init_multi(pwn_ctx **out, const int *devices, int ndev, int w
 	// the exchange between the members: RCCL where every member has a device of its own and the library loads, else copies
 	// between the members' planes behind events; PWN_GROUP_TRANSPORT=local|rccl in the environment says which
 	g->transport = PWN_TRANSPORT_LOCAL;
+	g->note[0] = 0;
 	const char *want = getenv("PWN_GROUP_TRANSPORT");
-	if(distinct && !(want != NULL && strcmp(want, "local") == 0))
+	g->transport_fixed = want != NULL && (strcmp(want, "local") == 0 || strcmp(want, "rccl") == 0);
+	// (PWN_DBG_GROUP_TRY_RCCL: RCCL is tried although two members share a device -- its bring-up then fails, which is how the tests
+	// see the fall-back without a second GPU)
+	const bool try_rccl = distinct || getenv("PWN_DBG_GROUP_TRY_RCCL") != NULL;
+	if(try_rccl && !(want != NULL && strcmp(want, "local") == 0))
 	{
 		unsigned char id[PWN_TILED_ID_BYTES];
 		if(pwn_tiled_unique_id(id, PWN_TRANSPORT_RCCL) == PWN_OK) g->transport = PWN_TRANSPORT_RCCL;
+		else snprintf(g->note, sizeof(g->note), "librccl did not load: copies between the members instead");
 	}
+	else if(!distinct) snprintf(g->note, sizeof(g->note), "members share a device: copies between the members");
 	// (peer-to-peer copies between two devices go over xGMI directly where each may address the other's memory)
 	for(int a = 0; a < ndev && distinct; a++)
 		for(int b = 0; b < ndev; b++)
@@ -362,6 +380,7 @@ extern "C" int pwn_group_info_get(pwn_ctx *h, pwn_group_info *out)
 	pwn_group *g = h->grp;
 	memset(out, 0, sizeof(*out));
 	out->members = g->n; out->transport = g->transport;
+	snprintf(out->note, sizeof(out->note), "%s", g->note);
 	for(int i = 0; i < g->n; i++) out->devices[i] = g->devices[i];
 	pwn_tiled_info ti;
 	(void)join(g, g->posted.load());          // (the members' threads are through what was posted: their tilings are at rest)

@@ -55,7 +55,8 @@ class Renderer:
         n = gi.members
         return {"members": n, "transport": {0: "rccl", 1: "shm", 2: "local"}.get(gi.transport, gi.transport), "devices": [gi.devices[i] for i in range(n)],
                 "cuts": [gi.cuts[i] for i in range(n + 1)], "halo_rows": gi.halo_rows, "host_sink": bool(gi.host_sink),
-                "frames": int(gi.frames), "frames_redone": int(gi.frames_redone), "recuts": int(gi.recuts)}
+                "frames": int(gi.frames), "frames_redone": int(gi.frames_redone), "recuts": int(gi.recuts),
+                "note": gi.note.decode("latin-1")}
 
     def close(self):
         if getattr(self, "_ctx", None) is not None and self._ctx.value:

@@ -281,6 +281,45 @@ def test_preflight_report_stays_json_whatever_the_environment_holds(monkeypatch)
         r.close()
 
 
+def test_rccl_that_does_not_come_up_is_replaced_by_copies(oracle_lib, cases):
+    """RCCL between the members has never had to come up on this pool.  Where its bring-up fails -- here: two members on ONE device, which
+    ncclCommInitRank refuses or the deadline ends -- the group goes on with copies between the members' planes, says so in
+    pwn_group_info.note, and the frames are the goldens; a host that named the transport (PWN_GROUP_TRANSPORT=rccl) gets the error."""
+    import pwnfps_amd
+    c = _case(cases, "level_spawn_1280x720")
+    os.environ["PWN_DBG_GROUP_TRY_RCCL"] = "1"
+    try:
+        r = pwnfps_amd.Renderer(c["w"], c["h"], devices=[0, 0])
+        gi = r.group_info()
+        if gi["transport"] != "rccl":
+            r.close()
+            pytest.skip("librccl did not load: " + gi["note"])
+        r.tiled_set_timeouts(8, 8)
+        cam = _load(r, c)
+        sb, zb = r.trace_screen_centred(cam, c["sec"])
+        assert oracle_lib.fnv64(sb) == c["post"] and oracle_lib.fnv64(zb) == c["z"]
+        gi = r.group_info()
+        assert gi["transport"] == "local" and "RCCL did not come up" in gi["note"], gi
+        r.frames_config(3, sbuf=True)
+        for i in range(3):
+            r.submit_frame(cam, c["sec"], i)
+        for i in range(3):
+            assert oracle_lib.fnv64(r.wait_frame(i)["sbuf"]) == c["post"]
+        r.frames_config(0)
+        r.close()
+        os.environ["PWN_GROUP_TRANSPORT"] = "rccl"
+        r = pwnfps_amd.Renderer(c["w"], c["h"], devices=[0, 0])
+        r.tiled_set_timeouts(8, 8)
+        cam = _load(r, c)
+        with pytest.raises(pwnfps_amd.PwnError):
+            r.trace_screen_centred(cam, c["sec"])
+        assert r.group_info()["transport"] == "rccl"
+        r.close()
+    finally:
+        os.environ.pop("PWN_DBG_GROUP_TRY_RCCL", None)
+        os.environ.pop("PWN_GROUP_TRANSPORT", None)
+
+
 def test_two_devices_over_rccl(oracle_lib, cases):
     """the same handle on two real GPUs: one RCCL communicator rank per device, brought up inside the process"""
     import torch
