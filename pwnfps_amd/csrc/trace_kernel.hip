@@ -64,6 +64,14 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	// lane-divergent bool carried across the walk loop costs three mask updates per iteration).
 	float w_acc = 0.0f;
 
+	// (carried from segment to segment: the position -- a segment starts where the one before ended, trace.h:86-89 -- and the
+	// sphere candidate's fields behind aux_dist, which alone is reset per segment)
+	V pos = from;
+	float aux_diff = 0.0f;
+	uint32_t aux_idx = 0;
+	V aux_pos, aux_norm;
+	aux_pos.x = aux_pos.y = aux_pos.z = aux_pos.w = 0.0f;
+	aux_norm = aux_pos;
 #pragma unroll 1
 	for(;;)
 	{
@@ -78,20 +86,17 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		// aux_dist: the reference's "none yet" value -1 (trace.h:200) is kept as +inf here, so that
 		// "a candidate exists and lies behind us" is one comparison; a candidate whose distance is
 		// exactly -1.0f counts as none there and is stored as +inf here too
-		float aux_dist = __builtin_inff(), aux_diff = 0.0f;
-		uint32_t aux_idx = 0;
-		V aux_pos, aux_norm;
-		aux_pos.x = aux_pos.y = aux_pos.z = aux_pos.w = 0.0f;
-		aux_norm = aux_pos;
+		// (the candidate's other fields are read only behind aux_dist: they keep what the segment before left in them -- declared in
+		// front of the loop -- instead of five moves per ray)
+		float aux_dist = __builtin_inff();
 		if(COUNT) cnt.rays++;
 
 		// The set-up's table reads (1/sqrt, the first cell's word, three reciprocals) are each issued ahead of work that does not
 		// need them -- the compiler leaves an LDS read where the source has it, directly in front of its use, and sinks one that
 		// only a branch uses into that branch: -0.3 % launch time at 4K, -0.5 % on synth64 (profiles/r5/sphere_lists_ab.txt).
-		V pos = from;
 		const uint32_t lb = __float_as_uint(dot3<HAS_W>(iray, iray));
 		const uint32_t rsq_e = tab_rsqrt_entry(L.rsq, lb);
-		int cx = (int)from.x, cz = (int)from.z;
+		int cx = (int)pos.x, cz = (int)pos.z;
 		// signs of the UN-normalised input (trace.h:225-227)
 		int gx = (iray.x < 0.0f ? -1 : 1);
 		int gz = (iray.z < 0.0f ? -1 : 1);
@@ -278,7 +283,6 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		st_refl1 = st_refl0; st_fog1 = st_fog0; sc1x = sc0x; sc1y = sc0y; sc1z = sc0z;
 		st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz;
 		seg++;
-		from = pos;
 		iray = ray;
 	}
 
