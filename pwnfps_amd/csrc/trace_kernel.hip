@@ -45,17 +45,23 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 	// shift register: a bounce moves the top entry down and writes the new one on top (plain moves; indexing by
 	// the segment number made ten selects of it).  The top entry's colour IS the next segment's icol
 	// (trace.h:90), so it starts as 1,1,1 and icol needs no registers of its own.
-	float st_refl0 = 0.0f, st_refl1 = 0.0f, st_fog0 = 0.0f, st_fog1 = 0.0f;
+	// (an entry is written when its surface is met and read only by a lane that bounced that often: the entries start as whatever
+	// their registers hold -- an asm statement without instructions, volatile so that two of them are not taken for one value)
+	float st_refl0, st_refl1, st_fog0, st_fog1;
 	float sc0x = 1.0f, sc0y = 1.0f, sc0z = 1.0f;
-	float sc1x = 0.0f, sc1y = 0.0f, sc1z = 0.0f;
+	float sc1x, sc1y, sc1z;
+	asm volatile("" : "=v"(st_refl0)); asm volatile("" : "=v"(st_refl1)); asm volatile("" : "=v"(st_fog0)); asm volatile("" : "=v"(st_fog1));
+	asm volatile("" : "=v"(sc1x)); asm volatile("" : "=v"(sc1y)); asm volatile("" : "=v"(sc1z));
 #define icx sc0x
 #define icy sc0y
 #define icz sc0z
 	// Every lane still in the segment loop is on the same segment, so the segment number `seg` is one scalar
 	// for the wave (tests on it are scalar branches); `depth`, the number of surfaces a pixel's ray bounced off,
 	// is per lane and set where the lane leaves the loop.
-	int depth = 0, seg = 0;
+	int depth, seg = 0;
+	asm volatile("" : "=v"(depth));
 	float vx, vy, vz, vw;
+	asm volatile("" : "=v"(vx)); asm volatile("" : "=v"(vy)); asm volatile("" : "=v"(vz));
 	// The colour's w lane is not carried: every surface colour has w = 0 (defs.h:16-18, spheres'
 	// col.w is never set), so col.w = diffuse * (icol.w * 0) is 0 -- unless the shading factor is
 	// not finite (a ray that went through 1/0 in a ramp, trace.h:461), when it is NaN and so is
@@ -196,7 +202,11 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		// leaves the old depth in place (trace.h:677)
 		if(seg == 0) *zpix = (ev == EV_SPHERE ? aux_dist : cdist);
 
-		float colx, coly, colz, refl;
+		// (the segment's colour is computed into the pixel's own registers: a segment that ends the ray has nothing to copy)
+		float refl;
+#define colx vx
+#define coly vy
+#define colz vz
 		if(ev == EV_WALL)
 		{
 			//@R p_wall
@@ -245,7 +255,7 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 
 		//@R p_post
 		// trace.h:3-7
-		if(seg >= REFLECT_MAX || refl == 0.0f) { vx = colx; vy = coly; vz = colz; vw = 0.0f; depth = seg; break; }
+		if(seg >= REFLECT_MAX || refl == 0.0f) { vw = 0.0f; depth = seg; break; }
 
 		// trace.h:9-75
 		if(ldir == FYN)
@@ -274,16 +284,20 @@ __device__ __forceinline__ void trace_pixel(const Lds &L, float sec_current, uin
 		//@R p_jitter
 		RG(RG_JITTER);
 		// trace.h:77-84: five draws, two discarded
-		ray.x += lcg2_fs(seed) * REFLECT_BLUR_F;
-		ray.y += lcg2_fs(seed) * REFLECT_BLUR_F;
+		// (straight into the next segment's direction; the entry below the top is moved down only once there is one)
+		iray.x = ray.x + lcg2_fs(seed) * REFLECT_BLUR_F;
+		iray.y = ray.y + lcg2_fs(seed) * REFLECT_BLUR_F;
 		lcg2_next(seed);
-		ray.z += lcg2_fs(seed) * REFLECT_BLUR_F;
+		iray.z = ray.z + lcg2_fs(seed) * REFLECT_BLUR_F;
 		lcg2_next(seed);
+		if constexpr(HAS_W) iray.w = ray.w;
 
-		st_refl1 = st_refl0; st_fog1 = st_fog0; sc1x = sc0x; sc1y = sc0y; sc1z = sc0z;
+		if(seg != 0) { st_refl1 = st_refl0; st_fog1 = st_fog0; sc1x = sc0x; sc1y = sc0y; sc1z = sc0z; }
 		st_refl0 = refl; st_fog0 = fog; sc0x = colx; sc0y = coly; sc0z = colz;
+#undef colx
+#undef coly
+#undef colz
 		seg++;
-		iray = ray;
 	}
 
 	//@R p_comp
