@@ -1102,9 +1102,11 @@ static int strip_cuts(const pwn_ctx *c, int want, int *cuts)
 		return n;
 	}
 	// (measured at 4K, profiles/r5/call_strips.txt: first strip 96 / 128 / 160 / 192 rows x growth 1.2 / 1.4 / 1.6 -- 128 x 1.2, eight
-	// strips, is the fastest; 1.6 costs 10 %: the last chunk's copy starts when everything else is done)
+	// strips, was the fastest; 1.6 costs 10 %: the last chunk's copy starts when everything else is done.  With the round's final trace
+	// kernel 160 rows, seven strips, is 0.5-0.8 % faster at 4K on one copy stream and on two, 128 against 96 rows 2.8 % at 1440p,
+	// 320 against 256 equal at 8K: the first strip is 2/27 of the frame)
 	double grow = 1.2;
-	int rows = (h / 17 + 31) & ~31;
+	int rows = (h * 2 / 27 + 31) & ~31;
 	if(const char *e = getenv("PWN_DBG_STRIP_FIRST")) if(atoi(e) >= 8) rows = (atoi(e) + 7) & ~7;        // (experiments)
 	if(const char *e = getenv("PWN_DBG_STRIP_GROW")) if(atof(e) >= 1.0) grow = atof(e);
 	while(cuts[n] < h)
