@@ -1221,7 +1221,10 @@ static int call_in_strips(pwn_ctx *c, const float cam[16], float sec, uint32_t *
 	const bool pinned = host_is_pinned(sbuf, n * 4) && host_is_pinned(zbuf, n * 4);
 	int ahead = pinned ? 0 : 2;
 	if(const char *e = getenv("PWN_DBG_STRIP_AHEAD")) if(*e) ahead = atoi(e);
-	int room = two ? c->num_cus : 0;        // (workgroups the grids leave free for the other stream's kernels: the blurs find a place at once)
+	// (workgroups the grids leave free for the other stream's kernels: the blurs find a place at once.  One per CU was the best of
+	// 0 / 128 / 256 / 512 / 768 when the plan was made; with the round's final kernels 384 is 2 % faster than 256 on two copy streams
+	// (0.732 -> 0.716 ms per 4K call), 512 nearly so, and equal on one: tools/r5/strip_plan_ab.py, profiles/r5/call_strips.txt)
+	int room = two ? c->num_cus + c->num_cus / 2 : 0;
 	if(const char *e = getenv("PWN_DBG_STRIP_ROOM")) if(*e) room = atoi(e);
 	int traced = 0, chunks = 0, copied = 0, rc;
 	int chunk_y[PWN_CALL_STRIPS_MAX + 1];          // chunk j = rows [chunk_y[j], chunk_y[j + 1]), blurred behind the trace of strip chunk_k[j]
