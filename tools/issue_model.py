@@ -109,7 +109,7 @@ def build_asm(path):
     flags = subprocess.check_output(["make", "-s", "-C", CSRC, "--no-print-directory", "-pn"], text=True, stderr=subprocess.DEVNULL)
     fp = re.search(r"^FPFLAGS = (.*)$", flags, re.M).group(1)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + fp.split() + [
-        "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-DPWN_MIN_WAVES=5"] + os.environ.get("PWN_ISA_EXTRA", "").split() + ["-gline-tables-only", "-S", "--cuda-device-only",
+        "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-DPWN_MIN_WAVES=5", "-mllvm", "-disable-lsr"] + os.environ.get("PWN_ISA_EXTRA", "").split() + ["-gline-tables-only", "-S", "--cuda-device-only",
         "-o", path, os.path.join(CSRC, "trace_kernel.hip")]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
 
